@@ -1,0 +1,139 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_common.h). PARITY UNPINNED.
+ *
+ * Public C interface of the CPU restatement. Plain pointers and sizes so that
+ * tests can bind it with ctypes.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 32
+#define ORC_NERF_GRIDSIZE 128u
+#define ORC_NERF_CASCADES 8u
+#define ORC_MAX_DEPTH 16384.0f
+#define ORC_MARCH_ITER 10000u /* src/testbed_nerf.cu:46 */
+
+enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LOGISTIC = 2, ORC_ACT_EXPONENTIAL = 3 };
+
+/* Model descriptor: what Testbed::reset_network + load_snapshot leave behind
+ * for the render path (src/testbed.cu:3928-3977, 5285-5463; nerf_network.h:81-101). */
+typedef struct orc_nerf_model {
+	/* multiresolution hash grid (tcnn GridEncoding, Hash / Linear) */
+	uint32_t n_levels;
+	uint32_t n_features_per_level;
+	uint32_t log2_hashmap_size;
+	uint32_t base_resolution;
+	float per_level_scale;
+	/* fully fused MLPs (bias-free, ReLU hidden, no output activation) */
+	uint32_t n_neurons;
+	uint32_t n_hidden_density; /* configs/nerf/base.json: 1 */
+	uint32_t n_hidden_rgb;     /* configs/nerf/base.json: 2 */
+	uint32_t density_out_dims; /* 16, nerf_network.h:88-90 */
+	uint32_t rgb_activation;   /* Logistic for LDR data, testbed_nerf.cu:2653 */
+	uint32_t density_activation; /* Exponential, nerf.h:151-152 */
+	/* parameters in tcnn order: density MLP, rgb MLP, grid (nerf_network.h:356-371); fp16 */
+	const uint16_t* params;
+	uint64_t n_params;
+	/* scene */
+	float aabb_min[3], aabb_max[3];               /* m_aabb (train aabb) */
+	float render_aabb_min[3], render_aabb_max[3]; /* m_render_aabb */
+	float render_aabb_to_local[9];                /* column-major mat3 */
+	uint32_t max_cascade;
+	float cone_angle_constant;
+	const uint8_t* density_grid_bitfield; /* 8 levels x 128^3 bits */
+	/* derived, filled by orc_nerf_prepare */
+	void* prepared;
+} orc_nerf_model;
+
+typedef struct orc_camera {
+	float matrix[12]; /* camera-to-world 4x3, column-major: x axis, y axis, z axis (fwd), position */
+	int32_t width, height;
+	float focal_length[2];  /* in pixels: relative_focal_length * res[fov_axis] * zoom */
+	float screen_center[2]; /* after Testbed::render_screen_center */
+	uint32_t spp_index;     /* render_buffer.spp */
+	int32_t snap_to_pixel_centers;
+	float near_distance;
+} orc_camera;
+
+typedef struct orc_render_opts {
+	float min_transmittance;      /* m_nerf.render_min_transmittance */
+	int32_t train_in_linear_colors; /* m_nerf.training.linear_colors */
+	int32_t depth_test;           /* 1: shade_kernel_nerf_geometry depth test against depth_buffer */
+	int32_t capped_skip;          /* 1: the 200-iteration skip of nerf_device.cuh:497-534 (trace_mesh) */
+	int32_t n_threads;            /* OpenMP threads, <=0: all */
+} orc_render_opts;
+
+typedef struct orc_render_stats {
+	uint64_t n_rays;
+	uint64_t n_rays_alive_after_init;
+	uint64_t n_rays_hit;     /* rays that reached shading (alpha > 0.001) */
+	uint64_t n_samples;      /* network queries that were composited or generated (sum over rays of marched samples) */
+} orc_render_stats;
+
+/* NerfPayload, nerf_device.cuh:144-152 (same member order, natural alignment). */
+typedef struct orc_payload {
+	float origin[3];
+	float dir[3];
+	float t;
+	float max_weight;
+	uint32_t idx;
+	uint16_t n_steps;
+	uint8_t alive;
+	uint8_t pad;
+} orc_payload;
+
+int orc_nerf_prepare(orc_nerf_model* m);
+void orc_nerf_release(orc_nerf_model* m);
+
+/* grid layout: offsets (in entries), resolutions and scales per level. */
+int orc_grid_layout(const orc_nerf_model* m, uint32_t* offsets /*n_levels+1*/, uint32_t* resolutions, float* scales);
+uint64_t orc_n_params(const orc_nerf_model* m); /* total fp16 parameter count */
+
+/* K5a: hash-grid encode. pos01: n x 3 floats in [0,1]; out: n x (L*F) fp16 */
+void orc_grid_encode(const orc_nerf_model* m, uint32_t n, const float* pos01, uint16_t* out);
+/* K5c: SH degree 4 of dir01 (n x 3, in [0,1]); out n x 16 fp16 */
+void orc_sh4_encode(uint32_t n, const float* dir01, uint16_t* out);
+/* K5: full network. out: n x 4 fp16 (rgb logits, density logit) */
+void orc_nerf_network(const orc_nerf_model* m, uint32_t n, const float* pos01, const float* dir01, uint16_t* out);
+
+/* K8/K9: density grid (float, Morton order, (max_cascade+1) x 128^3) -> bitfield (8 x 128^3 / 8 bytes) */
+void orc_density_grid_to_bitfield(const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* out_mean);
+
+/* sampling sequences, random_val.cuh:207-370 */
+float orc_ld_random_val(uint32_t index, uint32_t seed, uint32_t dim);
+void orc_ld_random_pixel_offset(uint32_t spp, float* out2);
+
+/* K1: primary ray for pixel (x,y) */
+void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* out);
+/* K2: start-of-ray jitter + skip to first occupied voxel */
+void orc_advance_pos(const orc_nerf_model* m, const orc_camera* cam, orc_payload* p);
+
+/* K3-K6 for one ray: marches until termination. rgba[4]/depth updated in place. returns #samples. */
+uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const orc_render_opts* o, orc_payload* p, float* rgba, float* depth);
+
+/* K1-K7 for a whole frame; frame_buffer (W*H*4) and depth_buffer (W*H) are read-modify-write
+ * exactly like CudaRenderBufferView after clear() (or after the mesh pass in Geometry mode). */
+void orc_render_nerf(const orc_nerf_model* m, const orc_camera* cam, const orc_render_opts* o,
+                     float* frame_buffer, float* depth_buffer, orc_render_stats* stats);
+
+/* Generic tracer over prepared payloads (irradiance probes): out rgba n x 4, depth n. */
+void orc_trace_payloads(const orc_nerf_model* m, const float* cam_matrix, const orc_render_opts* o,
+                        uint32_t n, orc_payload* payloads, float* rgba, float* depth, orc_render_stats* stats);
+
+/* P1: accumulate (linear colour space) + tonemap (identity curve) -> rgba_out (W*H*4) */
+void orc_accumulate(uint32_t n_pixels, const float* frame_buffer, float* accumulate_buffer, float sample_count);
+void orc_tonemap(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, float* rgba_out);
+
+float orc_srgb_to_linear(float v);
+float orc_linear_to_srgb(float v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

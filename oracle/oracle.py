@@ -1,0 +1,293 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (see oracle/orc_common.h).
+
+ctypes binding of the CPU restatement in oracle/*.c. Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product path never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+MAX_DEPTH = 16384.0
+ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
+
+
+def build(native=False, out_dir=None):
+    """Compile the C restatement (gcc). Returns the path of the shared library."""
+    out = out_dir or _BUILD
+    name = "liboracle_native.so" if native else "liboracle.so"
+    target = ["native"] if native else ["all"]
+    subprocess.run(["make", "-C", _HERE, "OUT=" + out] + target, check=True, capture_output=True)
+    return os.path.join(out, name)
+
+
+class NerfModel(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32),
+        ("n_features_per_level", C.c_uint32),
+        ("log2_hashmap_size", C.c_uint32),
+        ("base_resolution", C.c_uint32),
+        ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_uint32),
+        ("n_hidden_density", C.c_uint32),
+        ("n_hidden_rgb", C.c_uint32),
+        ("density_out_dims", C.c_uint32),
+        ("rgb_activation", C.c_uint32),
+        ("density_activation", C.c_uint32),
+        ("params", C.c_void_p),
+        ("n_params", C.c_uint64),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+        ("render_aabb_min", C.c_float * 3),
+        ("render_aabb_max", C.c_float * 3),
+        ("render_aabb_to_local", C.c_float * 9),
+        ("max_cascade", C.c_uint32),
+        ("cone_angle_constant", C.c_float),
+        ("density_grid_bitfield", C.c_void_p),
+        ("prepared", C.c_void_p),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("matrix", C.c_float * 12),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("focal_length", C.c_float * 2),
+        ("screen_center", C.c_float * 2),
+        ("spp_index", C.c_uint32),
+        ("snap_to_pixel_centers", C.c_int32),
+        ("near_distance", C.c_float),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("min_transmittance", C.c_float),
+        ("train_in_linear_colors", C.c_int32),
+        ("depth_test", C.c_int32),
+        ("capped_skip", C.c_int32),
+        ("n_threads", C.c_int32),
+    ]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_uint64),
+        ("n_rays_alive_after_init", C.c_uint64),
+        ("n_rays_hit", C.c_uint64),
+        ("n_samples", C.c_uint64),
+    ]
+
+
+PAYLOAD_DTYPE = np.dtype(
+    [("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"), ("max_weight", "<f4"), ("idx", "<u4"),
+     ("n_steps", "<u2"), ("alive", "u1"), ("pad", "u1")]
+)
+assert PAYLOAD_DTYPE.itemsize == 40
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Thin, explicit wrapper: numpy in, numpy out."""
+
+    def __init__(self, lib_path=None):
+        if lib_path is None:
+            lib_path = os.path.join(_BUILD, "liboracle.so")
+            if not os.path.exists(lib_path):
+                lib_path = build()
+        self.lib = C.CDLL(lib_path)
+        L = self.lib
+        L.orc_nerf_prepare.argtypes = [C.POINTER(NerfModel)]
+        L.orc_nerf_prepare.restype = C.c_int
+        L.orc_nerf_release.argtypes = [C.POINTER(NerfModel)]
+        L.orc_n_params.argtypes = [C.POINTER(NerfModel)]
+        L.orc_n_params.restype = C.c_uint64
+        L.orc_grid_layout.argtypes = [C.POINTER(NerfModel), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_grid_layout.restype = C.c_int
+        L.orc_grid_encode.argtypes = [C.POINTER(NerfModel), C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_sh4_encode.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_nerf_network.argtypes = [C.POINTER(NerfModel), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_density_grid_to_bitfield.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_ld_random_val.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_ld_random_val.restype = C.c_float
+        L.orc_ld_random_pixel_offset.argtypes = [C.c_uint32, C.c_void_p]
+        L.orc_init_ray.argtypes = [C.POINTER(NerfModel), C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_advance_pos.argtypes = [C.POINTER(NerfModel), C.POINTER(Camera), C.c_void_p]
+        L.orc_render_nerf.argtypes = [C.POINTER(NerfModel), C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
+        L.orc_trace_payloads.argtypes = [C.POINTER(NerfModel), C.c_void_p, C.POINTER(RenderOpts), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
+        L.orc_accumulate.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_float]
+        L.orc_tonemap.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p]
+        L.orc_srgb_to_linear.argtypes = [C.c_float]
+        L.orc_srgb_to_linear.restype = C.c_float
+        L.orc_linear_to_srgb.argtypes = [C.c_float]
+        L.orc_linear_to_srgb.restype = C.c_float
+        self._bind_mesh()
+
+    # ------------------------------------------------------------------ model
+    def make_model(self, scene):
+        """scene: dict produced by the package's synthetic/snapshot loaders (plain numpy + scalars)."""
+        m = NerfModel()
+        enc = scene["encoding"]
+        m.n_levels = enc["n_levels"]
+        m.n_features_per_level = enc["n_features_per_level"]
+        m.log2_hashmap_size = enc["log2_hashmap_size"]
+        m.base_resolution = enc["base_resolution"]
+        m.per_level_scale = enc["per_level_scale"]
+        m.n_neurons = scene["network"]["n_neurons"]
+        m.n_hidden_density = scene["network"]["n_hidden_layers"]
+        m.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]
+        m.density_out_dims = scene["network"].get("n_output_dims", 16)
+        m.rgb_activation = scene.get("rgb_activation", ACT_LOGISTIC)
+        m.density_activation = scene.get("density_activation", ACT_EXPONENTIAL)
+        params = np.ascontiguousarray(scene["params"], dtype=np.uint16)
+        bitfield = np.ascontiguousarray(scene["density_grid_bitfield"], dtype=np.uint8)
+        m.params = params.ctypes.data
+        m.n_params = params.size
+        for i in range(3):
+            m.aabb_min[i] = scene["aabb"][0][i]
+            m.aabb_max[i] = scene["aabb"][1][i]
+            m.render_aabb_min[i] = scene["render_aabb"][0][i]
+            m.render_aabb_max[i] = scene["render_aabb"][1][i]
+        r2l = np.asarray(scene.get("render_aabb_to_local", np.eye(3)), dtype=np.float32)
+        for c in range(3):
+            for r in range(3):
+                m.render_aabb_to_local[c * 3 + r] = r2l[r, c]
+        m.max_cascade = scene["max_cascade"]
+        m.cone_angle_constant = scene["cone_angle_constant"]
+        m.density_grid_bitfield = bitfield.ctypes.data
+        m._keep = (params, bitfield)
+        rc = self.lib.orc_nerf_prepare(C.byref(m))
+        if rc != 0:
+            raise RuntimeError(f"orc_nerf_prepare failed: {rc} (n_params={params.size}, need {self.lib.orc_n_params(C.byref(m))})")
+        return m
+
+    def release(self, m):
+        self.lib.orc_nerf_release(C.byref(m))
+
+    def grid_layout(self, m):
+        n = m.n_levels
+        off = np.zeros(n + 1, np.uint32)
+        res = np.zeros(n, np.uint32)
+        sc = np.zeros(n, np.float32)
+        self.lib.orc_grid_layout(C.byref(m), _ptr(off), _ptr(res), _ptr(sc))
+        return off, res, sc
+
+    # ------------------------------------------------------------------ stages
+    def grid_encode(self, m, pos01):
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        n = pos01.shape[0]
+        out = np.zeros((n, m.n_levels * m.n_features_per_level), np.uint16)
+        self.lib.orc_grid_encode(C.byref(m), n, _ptr(pos01), _ptr(out))
+        return out.view(np.float16)
+
+    def sh4(self, dir01):
+        dir01 = np.ascontiguousarray(dir01, np.float32)
+        out = np.zeros((dir01.shape[0], 16), np.uint16)
+        self.lib.orc_sh4_encode(dir01.shape[0], _ptr(dir01), _ptr(out))
+        return out.view(np.float16)
+
+    def network(self, m, pos01, dir01):
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        dir01 = np.ascontiguousarray(dir01, np.float32)
+        out = np.zeros((pos01.shape[0], 4), np.uint16)
+        self.lib.orc_nerf_network(C.byref(m), pos01.shape[0], _ptr(pos01), _ptr(dir01), _ptr(out))
+        return out.view(np.float16)
+
+    def density_grid_to_bitfield(self, grid, max_cascade):
+        grid = np.ascontiguousarray(grid, np.float32)
+        assert grid.size == 128 ** 3 * (max_cascade + 1)
+        bf = np.zeros(128 ** 3 // 8 * 8, np.uint8)
+        mean = C.c_float(0)
+        self.lib.orc_density_grid_to_bitfield(_ptr(grid), max_cascade, _ptr(bf), C.byref(mean))
+        return bf, mean.value
+
+    def ld_random_val(self, index, seed, dim=0):
+        return self.lib.orc_ld_random_val(index & 0xFFFFFFFF, seed & 0xFFFFFFFF, dim)
+
+    def pixel_offset(self, spp):
+        out = np.zeros(2, np.float32)
+        self.lib.orc_ld_random_pixel_offset(spp, _ptr(out))
+        return out
+
+    @staticmethod
+    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0):
+        """matrix_4x3: numpy (3,4) [R|t] camera-to-world in NGP convention."""
+        cam = Camera()
+        mat = np.asarray(matrix_4x3, np.float32)
+        assert mat.shape == (3, 4)
+        for c in range(4):
+            for r in range(3):
+                cam.matrix[c * 3 + r] = mat[r, c]
+        cam.width, cam.height = width, height
+        cam.focal_length[0], cam.focal_length[1] = focal_length
+        cam.screen_center[0], cam.screen_center[1] = screen_center
+        cam.spp_index = spp_index
+        cam.snap_to_pixel_centers = 1 if snap else 0
+        cam.near_distance = near
+        return cam
+
+    @staticmethod
+    def make_opts(min_transmittance=0.01, linear_colors=False, depth_test=False, capped_skip=False, n_threads=0):
+        o = RenderOpts()
+        o.min_transmittance = min_transmittance
+        o.train_in_linear_colors = int(linear_colors)
+        o.depth_test = int(depth_test)
+        o.capped_skip = int(capped_skip)
+        o.n_threads = n_threads
+        return o
+
+    def init_rays(self, m, cam, advance=True):
+        n = cam.width * cam.height
+        pl = np.zeros(n, PAYLOAD_DTYPE)
+        for i in range(n):
+            p = pl[i:i + 1]
+            self.lib.orc_init_ray(C.byref(m), C.byref(cam), i % cam.width, i // cam.width, _ptr(p))
+            if advance:
+                self.lib.orc_advance_pos(C.byref(m), C.byref(cam), _ptr(p))
+        return pl
+
+    def render_nerf(self, m, cam, opts=None, frame_buffer=None, depth_buffer=None):
+        opts = opts or self.make_opts()
+        n = cam.width * cam.height
+        fb = np.zeros((n, 4), np.float32) if frame_buffer is None else np.ascontiguousarray(frame_buffer, np.float32).reshape(n, 4).copy()
+        db = np.zeros(n, np.float32) if depth_buffer is None else np.ascontiguousarray(depth_buffer, np.float32).reshape(n).copy()
+        st = RenderStats()
+        self.lib.orc_render_nerf(C.byref(m), C.byref(cam), C.byref(opts), _ptr(fb), _ptr(db), C.byref(st))
+        stats = {k: getattr(st, k) for k, _ in RenderStats._fields_}
+        return fb.reshape(cam.height, cam.width, 4), db.reshape(cam.height, cam.width), stats
+
+    def trace_payloads(self, m, cam_matrix12, payloads, opts=None):
+        opts = opts or self.make_opts()
+        n = payloads.shape[0]
+        rgba = np.zeros((n, 4), np.float32)
+        depth = np.zeros(n, np.float32)
+        st = RenderStats()
+        cm = np.ascontiguousarray(cam_matrix12, np.float32)
+        self.lib.orc_trace_payloads(C.byref(m), _ptr(cm), C.byref(opts), n, _ptr(payloads), _ptr(rgba), _ptr(depth), C.byref(st))
+        return rgba, depth, {k: getattr(st, k) for k, _ in RenderStats._fields_}
+
+    def accumulate(self, frame_buffer, accumulate_buffer, sample_count):
+        fb = np.ascontiguousarray(frame_buffer, np.float32)
+        acc = np.ascontiguousarray(accumulate_buffer, np.float32).copy()
+        self.lib.orc_accumulate(fb.size // 4, _ptr(fb), _ptr(acc), float(sample_count))
+        return acc
+
+    def tonemap(self, accumulate_buffer, background=(0, 0, 0, 1), exposure=0.0, to_srgb=False):
+        acc = np.ascontiguousarray(accumulate_buffer, np.float32)
+        bg = np.asarray(background, np.float32)
+        out = np.zeros_like(acc)
+        self.lib.orc_tonemap(acc.size // 4, _ptr(acc), _ptr(bg), float(exposure), int(to_srgb), _ptr(out))
+        return out
+
+    # ------------------------------------------------------------------ mesh (orc_mesh.c); bound lazily
+    def _bind_mesh(self):
+        pass

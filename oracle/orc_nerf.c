@@ -1,0 +1,735 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_common.h). PARITY UNPINNED.
+ *
+ * NeRF inference path: ray generation, occupancy-grid marching, hash-grid + SH
+ * encoding, fully fused MLPs, alpha compositing, shading and the post pass.
+ * Every function names the reference file:line it restates; tcnn semantics are
+ * restated from the public upstream definition because
+ * dependencies/tiny-cuda-nn is absent from the reference mount.
+ */
+#include "oracle.h"
+#include "orc_common.h"
+
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ constants
+ * nerf_device.cuh:24-42 */
+#define NERF_GRIDSIZE 128u
+#define NERF_GRID_N_CELLS (128u * 128u * 128u)
+#define NERF_STEPS 1024u
+#define NERF_CASCADES 8u
+static const float SQRT3 = 1.73205080757f;
+static inline float STEPSIZE(void) { return SQRT3 / (float)NERF_STEPS; }
+static inline float MIN_CONE_STEPSIZE(void) { return STEPSIZE(); }
+static inline float MAX_CONE_STEPSIZE(void) { return STEPSIZE() * (float)(1u << (NERF_CASCADES - 1)) * (float)NERF_STEPS / (float)NERF_GRIDSIZE; }
+static const float NERF_MIN_OPTICAL_THICKNESS = 0.01f;
+static const float MAX_DEPTH = ORC_MAX_DEPTH;
+
+/* ------------------------------------------------------------------ Morton (tcnn common_device.h) */
+static inline uint32_t expand_bits(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+static inline uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
+	return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+static inline uint32_t morton3D_invert(uint32_t x) {
+	x = x & 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+
+/* ------------------------------------------------------------------ colour (common_device.cuh:34-64) */
+float orc_srgb_to_linear(float srgb) {
+	if (srgb <= 0.04045f) return srgb / 12.92f;
+	return powf((srgb + 0.055f) / 1.055f, 2.4f);
+}
+float orc_linear_to_srgb(float linear) {
+	if (linear < 0.0031308f) return 12.92f * linear;
+	return 1.055f * powf(linear, 0.41666f) - 0.055f;
+}
+
+/* ------------------------------------------------------------------ sampling sequences
+ * random_val.cuh:207-370 (Burley 2019 Owen-scrambled Sobol; direction numbers are data). */
+static const uint32_t SOBOL_DIRECTIONS[5][32] = {
+	{0x80000000, 0x40000000, 0x20000000, 0x10000000, 0x08000000, 0x04000000, 0x02000000, 0x01000000,
+	 0x00800000, 0x00400000, 0x00200000, 0x00100000, 0x00080000, 0x00040000, 0x00020000, 0x00010000,
+	 0x00008000, 0x00004000, 0x00002000, 0x00001000, 0x00000800, 0x00000400, 0x00000200, 0x00000100,
+	 0x00000080, 0x00000040, 0x00000020, 0x00000010, 0x00000008, 0x00000004, 0x00000002, 0x00000001},
+	{0x80000000, 0xc0000000, 0xa0000000, 0xf0000000, 0x88000000, 0xcc000000, 0xaa000000, 0xff000000,
+	 0x80800000, 0xc0c00000, 0xa0a00000, 0xf0f00000, 0x88880000, 0xcccc0000, 0xaaaa0000, 0xffff0000,
+	 0x80008000, 0xc000c000, 0xa000a000, 0xf000f000, 0x88008800, 0xcc00cc00, 0xaa00aa00, 0xff00ff00,
+	 0x80808080, 0xc0c0c0c0, 0xa0a0a0a0, 0xf0f0f0f0, 0x88888888, 0xcccccccc, 0xaaaaaaaa, 0xffffffff},
+	{0x80000000, 0xc0000000, 0x60000000, 0x90000000, 0xe8000000, 0x5c000000, 0x8e000000, 0xc5000000,
+	 0x68800000, 0x9cc00000, 0xee600000, 0x55900000, 0x80680000, 0xc09c0000, 0x60ee0000, 0x90550000,
+	 0xe8808000, 0x5cc0c000, 0x8e606000, 0xc5909000, 0x6868e800, 0x9c9c5c00, 0xeeee8e00, 0x5555c500,
+	 0x8000e880, 0xc0005cc0, 0x60008e60, 0x9000c590, 0xe8006868, 0x5c009c9c, 0x8e00eeee, 0xc5005555},
+	{0x80000000, 0xc0000000, 0x20000000, 0x50000000, 0xf8000000, 0x74000000, 0xa2000000, 0x93000000,
+	 0xd8800000, 0x25400000, 0x59e00000, 0xe6d00000, 0x78080000, 0xb40c0000, 0x82020000, 0xc3050000,
+	 0x208f8000, 0x51474000, 0xfbea2000, 0x75d93000, 0xa0858800, 0x914e5400, 0xdbe79e00, 0x25db6d00,
+	 0x58800080, 0xe54000c0, 0x79e00020, 0xb6d00050, 0x800800f8, 0xc00c0074, 0x200200a2, 0x50050093},
+	{0x80000000, 0x40000000, 0x20000000, 0xb0000000, 0xf8000000, 0xdc000000, 0x7a000000, 0x9d000000,
+	 0x5a800000, 0x2fc00000, 0xa1600000, 0xf0b00000, 0xda880000, 0x6fc40000, 0x81620000, 0x40bb0000,
+	 0x22878000, 0xb3c9c000, 0xfb65a000, 0xddb2d000, 0x78022800, 0x9c0b3c00, 0x5a0fb600, 0x2d0ddb00,
+	 0xa2878080, 0xf3c9c040, 0xdb65a020, 0x6db2d0b0, 0x800228f8, 0x400b3cdc, 0x200fb67a, 0xb00ddb9d},
+};
+
+static uint32_t sobol(uint32_t index, uint32_t dim) { /* random_val.cuh:207-264 */
+	uint32_t X = 0;
+	for (uint32_t bit = 0; bit < 32; ++bit) {
+		if ((index >> bit) & 1u) X ^= SOBOL_DIRECTIONS[dim][bit];
+	}
+	return X;
+}
+static uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+static uint32_t reverse_bits(uint32_t x) {
+	x = (((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1));
+	x = (((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2));
+	x = (((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4));
+	x = (((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8));
+	return (x >> 16) | (x << 16);
+}
+static uint32_t laine_karras_permutation(uint32_t x, uint32_t seed) {
+	x += seed;
+	x ^= x * 0x6c50b47cu;
+	x ^= x * 0xb82f1e52u;
+	x ^= x * 0xc7afe638u;
+	x ^= x * 0x8d22f6e6u;
+	return x;
+}
+static uint32_t nested_uniform_scramble_base2(uint32_t x, uint32_t seed) {
+	x = reverse_bits(x);
+	x = laine_karras_permutation(x, seed);
+	x = reverse_bits(x);
+	return x;
+}
+static const float LD_SCALE = 2.3283064365386963e-10f; /* float(1.0/(1ull<<32)) */
+
+float orc_ld_random_val(uint32_t index, uint32_t seed, uint32_t dim) { /* random_val.cuh:332-336 */
+	index = nested_uniform_scramble_base2(index, seed);
+	return (float)nested_uniform_scramble_base2(sobol(index, dim), hash_combine(seed, dim)) * LD_SCALE;
+}
+static void ld_random_val_2d(uint32_t index, uint32_t seed, float* out) { /* random_val.cuh:311-330 */
+	index = nested_uniform_scramble_base2(index, seed);
+	for (uint32_t i = 0; i < 2; ++i) {
+		uint32_t x = nested_uniform_scramble_base2(sobol(index, i), hash_combine(seed, i));
+		out[i] = (float)x * LD_SCALE;
+	}
+}
+static float fractf_(float x) { return x - floorf(x); }
+void orc_ld_random_pixel_offset(uint32_t spp, float* out2) { /* random_val.cuh:365-370 */
+	float a[2], b[2];
+	ld_random_val_2d(0, 0xdeadbeefu, a);
+	ld_random_val_2d(spp, 0xdeadbeefu, b);
+	out2[0] = fractf_((0.5f - a[0]) + b[0]);
+	out2[1] = fractf_((0.5f - a[1]) + b[1]);
+}
+
+/* ------------------------------------------------------------------ prepared model */
+typedef struct {
+	uint32_t offsets[ORC_MAX_LEVELS + 1];
+	uint32_t resolutions[ORC_MAX_LEVELS];
+	float scales[ORC_MAX_LEVELS];
+	uint32_t enc_dims;
+	/* float copies of the fp16 weights, row-major out x in per layer */
+	float* density_w;
+	float* rgb_w;
+	uint64_t n_density_w, n_rgb_w;
+	const uint16_t* grid;
+	aabb_t aabb, render_aabb;
+} prepared_t;
+
+static uint32_t next_multiple_u32(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
+
+/* tcnn GridEncoding constructor + grid_scale/grid_resolution. */
+int orc_grid_layout(const orc_nerf_model* m, uint32_t* offsets, uint32_t* resolutions, float* scales) {
+	if (m->n_levels == 0 || m->n_levels > ORC_MAX_LEVELS) return -1;
+	float log2_pls = log2f(m->per_level_scale);
+	uint32_t offset = 0;
+	for (uint32_t l = 0; l < m->n_levels; ++l) {
+		float scale = exp2f((float)l * log2_pls) * (float)m->base_resolution - 1.0f;
+		uint32_t res = (uint32_t)ceilf(scale) + 1u;
+		uint32_t max_params = 0xFFFFFFFFu / 2u;
+		uint32_t params_in_level = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+		params_in_level = next_multiple_u32(params_in_level, 8u);
+		uint32_t cap = 1u << m->log2_hashmap_size;
+		if (params_in_level > cap) params_in_level = cap;
+		offsets[l] = offset;
+		resolutions[l] = res;
+		scales[l] = scale;
+		offset += params_in_level;
+	}
+	offsets[m->n_levels] = offset;
+	return 0;
+}
+
+static uint64_t mlp_n_params(uint32_t in, uint32_t width, uint32_t n_hidden, uint32_t out_padded) {
+	return (uint64_t)width * in + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)out_padded * width;
+}
+
+uint64_t orc_n_params(const orc_nerf_model* m) {
+	uint32_t offsets[ORC_MAX_LEVELS + 1], res[ORC_MAX_LEVELS];
+	float scales[ORC_MAX_LEVELS];
+	if (orc_grid_layout(m, offsets, res, scales)) return 0;
+	uint32_t enc = m->n_levels * m->n_features_per_level;
+	uint64_t nd = mlp_n_params(enc, m->n_neurons, m->n_hidden_density, m->density_out_dims);
+	uint64_t nr = mlp_n_params(m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u);
+	return nd + nr + (uint64_t)offsets[m->n_levels] * m->n_features_per_level;
+}
+
+int orc_nerf_prepare(orc_nerf_model* m) {
+	if (m->n_hidden_density < 1 || m->n_hidden_rgb < 1) return -2;
+	prepared_t* p = (prepared_t*)calloc(1, sizeof(prepared_t));
+	if (!p) return -1;
+	if (orc_grid_layout(m, p->offsets, p->resolutions, p->scales)) { free(p); return -1; }
+	p->enc_dims = m->n_levels * m->n_features_per_level;
+	p->n_density_w = mlp_n_params(p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims);
+	p->n_rgb_w = mlp_n_params(m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u);
+	uint64_t need = p->n_density_w + p->n_rgb_w + (uint64_t)p->offsets[m->n_levels] * m->n_features_per_level;
+	if (m->n_params != need) { free(p); return -3; }
+	p->density_w = (float*)malloc(sizeof(float) * p->n_density_w);
+	p->rgb_w = (float*)malloc(sizeof(float) * p->n_rgb_w);
+	for (uint64_t i = 0; i < p->n_density_w; ++i) p->density_w[i] = orc_half_to_float(m->params[i]);
+	for (uint64_t i = 0; i < p->n_rgb_w; ++i) p->rgb_w[i] = orc_half_to_float(m->params[p->n_density_w + i]);
+	p->grid = m->params + p->n_density_w + p->n_rgb_w;
+	p->aabb.min = v3_make(m->aabb_min[0], m->aabb_min[1], m->aabb_min[2]);
+	p->aabb.max = v3_make(m->aabb_max[0], m->aabb_max[1], m->aabb_max[2]);
+	p->render_aabb.min = v3_make(m->render_aabb_min[0], m->render_aabb_min[1], m->render_aabb_min[2]);
+	p->render_aabb.max = v3_make(m->render_aabb_max[0], m->render_aabb_max[1], m->render_aabb_max[2]);
+	m->prepared = p;
+	return 0;
+}
+
+void orc_nerf_release(orc_nerf_model* m) {
+	prepared_t* p = (prepared_t*)m->prepared;
+	if (!p) return;
+	free(p->density_w);
+	free(p->rgb_w);
+	free(p);
+	m->prepared = NULL;
+}
+
+/* ------------------------------------------------------------------ K5a hash grid
+ * tcnn kernel_grid / pos_fract / grid_index / coherent prime hash (Appendix B.1):
+ *   pos = fma(scale, x, 0.5); cell = floor(pos); w = pos - cell
+ *   index = dense (x + y*R + z*R^2, strides stop once they exceed the level size) or
+ *           (x*1 ^ y*2654435761 ^ z*805459861), then % level size
+ *   result[f] += (half)(weight * (float)value[f])   -- fp16 accumulation, corner order 0..7,
+ *   bit d of the corner index selects the +1 neighbour along dimension d. */
+static inline uint32_t grid_index(uint32_t hashmap_size, uint32_t res, const uint32_t* pg) {
+	uint32_t stride = 1, index = 0;
+	for (uint32_t dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
+		index += pg[dim] * stride;
+		stride *= res;
+	}
+	if (hashmap_size < stride) {
+		index = (pg[0] * 1u) ^ (pg[1] * 2654435761u) ^ (pg[2] * 805459861u);
+	}
+	return index % hashmap_size;
+}
+
+static void grid_encode_one(const orc_nerf_model* m, const prepared_t* p, const float* x, uint16_t* out) {
+	const uint32_t F = m->n_features_per_level;
+	for (uint32_t l = 0; l < m->n_levels; ++l) {
+		const uint32_t size = p->offsets[l + 1] - p->offsets[l];
+		const uint16_t* level = p->grid + (uint64_t)p->offsets[l] * F;
+		const float scale = p->scales[l];
+		const uint32_t res = p->resolutions[l];
+		float pos[3];
+		uint32_t pg[3];
+		for (int d = 0; d < 3; ++d) {
+			float v = fmaf(scale, x[d], 0.5f);
+			float fl = floorf(v);
+			pg[d] = (uint32_t)(int)fl;
+			pos[d] = v - fl;
+		}
+		uint16_t result[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (uint32_t idx = 0; idx < 8; ++idx) {
+			float weight = 1.0f;
+			uint32_t pgl[3];
+			for (uint32_t d = 0; d < 3; ++d) {
+				if ((idx & (1u << d)) == 0) {
+					weight *= 1.0f - pos[d];
+					pgl[d] = pg[d];
+				} else {
+					weight *= pos[d];
+					pgl[d] = pg[d] + 1u;
+				}
+			}
+			const uint16_t* val = level + (uint64_t)grid_index(size, res, pgl) * F;
+			for (uint32_t f = 0; f < F; ++f) {
+				float prod = weight * orc_half_to_float(val[f]);
+				result[f] = orc_half_add(result[f], orc_float_to_half(prod));
+			}
+		}
+		for (uint32_t f = 0; f < F; ++f) out[l * F + f] = result[f];
+	}
+}
+
+void orc_grid_encode(const orc_nerf_model* m, uint32_t n, const float* pos01, uint16_t* out) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+	for (uint32_t i = 0; i < n; ++i) grid_encode_one(m, p, pos01 + 3 * (size_t)i, out + (size_t)p->enc_dims * i);
+}
+
+/* ------------------------------------------------------------------ K5c spherical harmonics, degree 4
+ * tcnn SphericalHarmonicsEncoding (Appendix B.3): input mapped 2x-1, 16 real SH values, cast to half. */
+static void sh4_one(const float* d01, uint16_t* out) {
+	float x = d01[0] * 2.0f - 1.0f, y = d01[1] * 2.0f - 1.0f, z = d01[2] * 2.0f - 1.0f;
+	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	float o[16];
+	o[0] = 0.28209479177387814f;
+	o[1] = -0.48860251190291987f * y;
+	o[2] = 0.48860251190291987f * z;
+	o[3] = -0.48860251190291987f * x;
+	o[4] = 1.0925484305920792f * xy;
+	o[5] = -1.0925484305920792f * yz;
+	o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+	o[7] = -1.0925484305920792f * xz;
+	o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+	o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+	o[10] = 2.8906114426405538f * xy * z;
+	o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+	o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+	o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+	o[14] = 1.4453057213202769f * z * (x2 - y2);
+	o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+	for (int i = 0; i < 16; ++i) out[i] = orc_float_to_half(o[i]);
+}
+
+void orc_sh4_encode(uint32_t n, const float* dir01, uint16_t* out) {
+	for (uint32_t i = 0; i < n; ++i) sh4_one(dir01 + 3 * (size_t)i, out + 16 * (size_t)i);
+}
+
+/* ------------------------------------------------------------------ K5b/K5d fully fused MLP
+ * tcnn FullyFusedMLP (Appendix B.2): bias-free, row-major (out x in) fp16 weights, ReLU on hidden
+ * layers, activations stored as fp16 between layers, fp16 output. The reference accumulates inside
+ * tensor-core fragments; here each dot product is accumulated exactly (double), rounded to fp32
+ * (the MFMA accumulator type of the MI355X build) and then to fp16. */
+static void mlp_layer(const float* w, uint32_t n_out, uint32_t n_in, const float* in, int relu, float* out_f, uint16_t* out_h) {
+	for (uint32_t o = 0; o < n_out; ++o) {
+		const float* row = w + (size_t)o * n_in;
+		double acc = 0.0;
+		for (uint32_t i = 0; i < n_in; ++i) acc += (double)row[i] * (double)in[i];
+		float a = (float)acc;
+		if (relu && !(a > 0.0f)) a = 0.0f;
+		uint16_t h = orc_float_to_half(a);
+		if (out_h) out_h[o] = h;
+		out_f[o] = orc_half_to_float(h);
+	}
+}
+
+/* returns pointer past the consumed weights */
+static void mlp_forward(const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const float* in, float* out_f, uint16_t* out_h) {
+	float a[256], b[256];
+	mlp_layer(w, width, n_in, in, 1, a, NULL);
+	w += (size_t)width * n_in;
+	float* cur = a;
+	float* nxt = b;
+	for (uint32_t l = 1; l < n_hidden; ++l) {
+		mlp_layer(w, width, width, cur, 1, nxt, NULL);
+		w += (size_t)width * width;
+		float* t = cur; cur = nxt; nxt = t;
+	}
+	mlp_layer(w, n_out, width, cur, 0, out_f, out_h);
+}
+
+/* nerf_network.h:105-139: pos enc -> density MLP -> [density out | dir enc] -> rgb MLP; row 3 <- density logit. */
+static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const float* pos01, const float* dir01, uint16_t* out4) {
+	uint16_t enc_h[ORC_MAX_LEVELS * 8];
+	float enc[ORC_MAX_LEVELS * 8];
+	grid_encode_one(m, p, pos01, enc_h);
+	for (uint32_t i = 0; i < p->enc_dims; ++i) enc[i] = orc_half_to_float(enc_h[i]);
+	float rgb_in[64];
+	uint16_t dens_h[32];
+	mlp_forward(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, rgb_in, dens_h);
+	uint16_t sh[16];
+	sh4_one(dir01, sh);
+	for (int i = 0; i < 16; ++i) rgb_in[m->density_out_dims + i] = orc_half_to_float(sh[i]);
+	float rgb_out[16];
+	uint16_t rgb_h[16];
+	mlp_forward(p->rgb_w, m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u, rgb_in, rgb_out, rgb_h);
+	out4[0] = rgb_h[0];
+	out4[1] = rgb_h[1];
+	out4[2] = rgb_h[2];
+	out4[3] = dens_h[0];
+}
+
+void orc_nerf_network(const orc_nerf_model* m, uint32_t n, const float* pos01, const float* dir01, uint16_t* out) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t i = 0; i < (int64_t)n; ++i) nerf_network_one(m, p, pos01 + 3 * i, dir01 + 3 * i, out + 4 * i);
+}
+
+/* ------------------------------------------------------------------ K8/K9 occupancy bitfield
+ * testbed_nerf.cu:284-331, 2863-2877 */
+void orc_density_grid_to_bitfield(const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* out_mean) {
+	const uint32_t n_elements = NERF_GRID_N_CELLS;
+	/* reduce_sum of fmaxf(val,0)/n_elements over level 0. The GPU reduction order is unspecified;
+	 * the sum is taken in double so that any order rounds to the same float. */
+	double sum = 0.0;
+	for (uint32_t i = 0; i < n_elements; ++i) sum += (double)(fmaxf(grid[i], 0.0f) / (float)n_elements);
+	float mean = (float)sum;
+	if (out_mean) *out_mean = mean;
+	float thresh = NERF_MIN_OPTICAL_THICKNESS < mean ? NERF_MIN_OPTICAL_THICKNESS : mean;
+	const uint32_t n_bytes_total = n_elements / 8 * NERF_CASCADES;
+	const uint32_t n_nonzero = n_elements / 8 * (max_cascade + 1);
+	for (uint32_t i = 0; i < n_bytes_total; ++i) {
+		if (i >= n_nonzero) { bitfield[i] = 0; continue; }
+		uint8_t bits = 0;
+		for (uint32_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? (uint8_t)(1u << j) : 0;
+		bitfield[i] = bits;
+	}
+	for (uint32_t level = 1; level < NERF_CASCADES; ++level) {
+		const uint8_t* prev = bitfield + (size_t)(level - 1) * (n_elements / 8);
+		uint8_t* next = bitfield + (size_t)level * (n_elements / 8);
+		for (uint32_t i = 0; i < n_elements / 64; ++i) {
+			uint8_t bits = 0;
+			for (uint32_t j = 0; j < 8; ++j) bits |= prev[(size_t)i * 8 + j] > 0 ? (uint8_t)(1u << j) : 0;
+			uint32_t x = morton3D_invert(i >> 0) + NERF_GRIDSIZE / 8;
+			uint32_t y = morton3D_invert(i >> 1) + NERF_GRIDSIZE / 8;
+			uint32_t z = morton3D_invert(i >> 2) + NERF_GRIDSIZE / 8;
+			next[morton3D(x, y, z)] |= bits;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ stepping (nerf_device.cuh:378-428) */
+static float to_stepping_space(float t, float cone_angle) {
+	if (cone_angle <= 1e-5f) return t / MIN_CONE_STEPSIZE();
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(MIN_CONE_STEPSIZE()) - logf(log1p_c)) / log1p_c;
+	float b = (logf(MAX_CONE_STEPSIZE()) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c);
+	float bt = expf(b * log1p_c);
+	if (t <= at) return (t - at) / MIN_CONE_STEPSIZE() + a;
+	else if (t <= bt) return logf(t) / log1p_c;
+	else return (t - bt) / MAX_CONE_STEPSIZE() + b;
+}
+static float from_stepping_space(float n, float cone_angle) {
+	if (cone_angle <= 1e-5f) return n * MIN_CONE_STEPSIZE();
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(MIN_CONE_STEPSIZE()) - logf(log1p_c)) / log1p_c;
+	float b = (logf(MAX_CONE_STEPSIZE()) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c);
+	float bt = expf(b * log1p_c);
+	if (n <= a) return (n - a) * MIN_CONE_STEPSIZE() + at;
+	else if (n <= b) return expf(n * log1p_c);
+	else return (n - b) * MAX_CONE_STEPSIZE() + bt;
+}
+static float advance_n_steps(float t, float cone_angle, float n) { return from_stepping_space(to_stepping_space(t, cone_angle) + n, cone_angle); }
+static float calc_dt(float t, float cone_angle) { return advance_n_steps(t, cone_angle, 1.0f) - t; }
+
+/* nerf_device.cuh:306-314 */
+static float warp_dt(float dt) {
+	float max_stepsize = MIN_CONE_STEPSIZE() * (float)(1u << (NERF_CASCADES - 1));
+	return (dt - MIN_CONE_STEPSIZE()) / (max_stepsize - MIN_CONE_STEPSIZE());
+}
+static float unwarp_dt(float dt) {
+	float max_stepsize = MIN_CONE_STEPSIZE() * (float)(1u << (NERF_CASCADES - 1));
+	return dt * (max_stepsize - MIN_CONE_STEPSIZE()) + MIN_CONE_STEPSIZE();
+}
+
+/* ------------------------------------------------------------------ occupancy lookups (nerf_device.cuh:316-367,430-447) */
+static uint32_t cascaded_grid_idx_at(v3 pos, uint32_t mip) {
+	float mip_scale = scalbnf(1.0f, -(int)mip);
+	pos = v3_adds(pos, -0.5f);
+	pos = v3_scale(pos, mip_scale);
+	pos = v3_adds(pos, 0.5f);
+	int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
+	int iy = (int)(pos.y * (float)NERF_GRIDSIZE);
+	int iz = (int)(pos.z * (float)NERF_GRIDSIZE);
+	if (ix < 0 || ix >= (int)NERF_GRIDSIZE || iy < 0 || iy >= (int)NERF_GRIDSIZE || iz < 0 || iz >= (int)NERF_GRIDSIZE) return 0xFFFFFFFFu;
+	return morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+}
+static int density_grid_occupied_at(v3 pos, const uint8_t* bitfield, uint32_t mip) {
+	uint32_t idx = cascaded_grid_idx_at(pos, mip);
+	if (idx == 0xFFFFFFFFu) return 0;
+	return (bitfield[idx / 8 + (NERF_GRID_N_CELLS * mip) / 8] & (1u << (idx % 8))) != 0;
+}
+static float signf_(float x) { return copysignf(1.0f, x); }
+static float distance_to_next_voxel(v3 pos, v3 dir, v3 idir, float res) {
+	v3 p = v3_scale(v3_adds(pos, -0.5f), res);
+	float tx = (floorf(p.x + 0.5f + 0.5f * signf_(dir.x)) - p.x) * idir.x;
+	float ty = (floorf(p.y + 0.5f + 0.5f * signf_(dir.y)) - p.y) * idir.y;
+	float tz = (floorf(p.z + 0.5f + 0.5f * signf_(dir.z)) - p.z) * idir.z;
+	float t = fminf(fminf(tx, ty), tz);
+	return fmaxf(t / res, 0.0f);
+}
+static float advance_to_next_voxel(float t, float cone_angle, v3 pos, v3 dir, v3 idir, uint32_t mip) {
+	float res = scalbnf((float)NERF_GRIDSIZE, -(int)mip);
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	t = to_stepping_space(t, cone_angle);
+	t_target = to_stepping_space(t_target, cone_angle);
+	return from_stepping_space(t + ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+}
+static uint32_t mip_from_pos(v3 pos, uint32_t max_cascade) {
+	int exponent;
+	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
+	(void)frexpf(maxval, &exponent);
+	int v = exponent + 1;
+	if (v < 0) v = 0;
+	if (v > (int)max_cascade) v = (int)max_cascade;
+	return (uint32_t)v;
+}
+static uint32_t clamp_u32(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* nerf_device.cuh:461-494 (and the 200-iteration variant :497-534 when capped != 0) */
+static float if_unoccupied_advance_to_next_occupied_voxel(float t, float cone_angle, v3 o, v3 d, v3 idir, const uint8_t* grid,
+                                                         uint32_t min_mip, uint32_t max_mip, const aabb_t* aabb, const float* to_local, int capped) {
+	uint32_t i = 1;
+	while (!capped || i < 200) {
+		v3 pos = v3_add(o, v3_scale(d, t));
+		if (t >= MAX_DEPTH || !aabb_contains(aabb, m3_mulv(to_local, pos))) return MAX_DEPTH;
+		uint32_t mip = clamp_u32(mip_from_pos(pos, NERF_CASCADES - 1), min_mip, max_mip);
+		if (!grid || density_grid_occupied_at(pos, grid, mip)) return t;
+		while (mip < max_mip && !density_grid_occupied_at(pos, grid, mip + 1)) ++mip;
+		t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+		++i;
+	}
+	return MAX_DEPTH;
+}
+
+/* ------------------------------------------------------------------ K1 ray generation
+ * testbed_nerf.cu:1428-1544 with the perspective branch of uv_to_ray (common_device.cuh:416-483).
+ * Restated for: no foveation, no hidden-area mask, Perspective lens, no distortion map, zero parallax
+ * shift, zero aperture, plane_z >= 0, render mode Shade, no env map, static camera (camera0 == camera1,
+ * so the per-pixel camera_slerp of get_xform_given_rolling_shutter is the identity up to rounding). */
+void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+	uint32_t idx = x + (uint32_t)cam->width * y;
+	float off[2];
+	orc_ld_random_pixel_offset(cam->snap_to_pixel_centers ? 0u : cam->spp_index, off);
+	float u = ((float)x + off[0]) / (float)cam->width;
+	float v = ((float)y + off[1]) / (float)cam->height;
+	v3 dir = v3_make((u - cam->screen_center[0]) * (float)cam->width / cam->focal_length[0],
+	                 (v - cam->screen_center[1]) * (float)cam->height / cam->focal_length[1], 1.0f);
+	dir = m3_mulv(cam->matrix, dir);
+	v3 origin = v3_make(cam->matrix[9], cam->matrix[10], cam->matrix[11]);
+	origin = v3_add(origin, v3_scale(dir, cam->near_distance));
+
+	memset(payload, 0, sizeof(*payload));
+	payload->max_weight = 0.0f;
+	if (dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) { /* !ray.is_valid() */
+		payload->origin[0] = origin.x; payload->origin[1] = origin.y; payload->origin[2] = origin.z;
+		payload->alive = 0;
+		return;
+	}
+	dir = v3_normalize(dir);
+	float tmin, tmax;
+	aabb_ray_intersect(&p->render_aabb, m3_mulv(m->render_aabb_to_local, origin), m3_mulv(m->render_aabb_to_local, dir), &tmin, &tmax);
+	float t = fmaxf(tmin, 0.0f) + 1e-6f;
+	payload->origin[0] = origin.x; payload->origin[1] = origin.y; payload->origin[2] = origin.z;
+	if (!aabb_contains(&p->render_aabb, m3_mulv(m->render_aabb_to_local, v3_add(origin, v3_scale(dir, t))))) {
+		payload->alive = 0;
+		return;
+	}
+	payload->dir[0] = dir.x; payload->dir[1] = dir.y; payload->dir[2] = dir.z;
+	payload->t = t;
+	payload->idx = idx;
+	payload->n_steps = 0;
+	payload->alive = 1;
+}
+
+/* K2: testbed_nerf.cu:333-362 */
+void orc_advance_pos(const orc_nerf_model* m, const orc_camera* cam, orc_payload* payload) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+	if (!payload->alive) return;
+	v3 origin = v3_make(payload->origin[0], payload->origin[1], payload->origin[2]);
+	v3 dir = v3_make(payload->dir[0], payload->dir[1], payload->dir[2]);
+	v3 idir = v3_make(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	float cone_angle = m->cone_angle_constant; /* calc_cone_angle returns the constant, nerf_device.cuh:369-376 */
+	float t = advance_n_steps(payload->t, cone_angle, orc_ld_random_val(cam->spp_index, payload->idx * 786433u, 0));
+	t = if_unoccupied_advance_to_next_occupied_voxel(t, cone_angle, origin, dir, idir, m->density_grid_bitfield, 0, m->max_cascade, &p->render_aabb, m->render_aabb_to_local, 0);
+	if (t >= MAX_DEPTH) payload->alive = 0;
+	else payload->t = t;
+}
+
+/* ------------------------------------------------------------------ activations (nerf_device.cuh:203-263) */
+static float logistic_(float x) { return 1.0f / (1.0f + expf(-x)); }
+static float clampf_(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static float network_to_rgb(float val, uint32_t act) {
+	switch (act) {
+		case ORC_ACT_NONE: return val;
+		case ORC_ACT_RELU: return val > 0.0f ? val : 0.0f;
+		case ORC_ACT_LOGISTIC: return logistic_(val);
+		case ORC_ACT_EXPONENTIAL: return expf(clampf_(val, -10.0f, 10.0f));
+	}
+	return 0.0f;
+}
+static float network_to_density(float val, uint32_t act) {
+	switch (act) {
+		case ORC_ACT_NONE: return val;
+		case ORC_ACT_RELU: return val > 0.0f ? val : 0.0f;
+		case ORC_ACT_LOGISTIC: return logistic_(val);
+		case ORC_ACT_EXPONENTIAL: return expf(val);
+	}
+	return 0.0f;
+}
+
+/* ------------------------------------------------------------------ K3-K6 for one ray
+ * generate_next_nerf_network_inputs (testbed_nerf.cu:430-477) + network + composite_kernel_nerf (:528-735,
+ * render mode Shade, no glow, show_accel < 0) chained sample by sample. The reference batches 1..8 samples
+ * between compactions (:2080-2081); a ray's result does not depend on that batching because compositing
+ * re-checks termination after every sample and samples past the terminating one are discarded.
+ * The loop bound restates MARCH_ITER (:46,2056): a ray that is still alive after that many steps is never
+ * compacted into the hit buffer and therefore never shaded. Returns the number of samples evaluated. */
+uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const orc_render_opts* o, orc_payload* payload, float* rgba, float* depth) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+	if (!payload->alive) return 0;
+	v3 origin = v3_make(payload->origin[0], payload->origin[1], payload->origin[2]);
+	v3 dir = v3_make(payload->dir[0], payload->dir[1], payload->dir[2]);
+	v3 idir = v3_make(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	v3 cam_fwd = v3_make(cam_matrix[6], cam_matrix[7], cam_matrix[8]);
+	v3 cam_pos = v3_make(cam_matrix[9], cam_matrix[10], cam_matrix[11]);
+	float cone_angle = m->cone_angle_constant;
+	float t = payload->t;
+	v3 diag = v3_sub(p->aabb.max, p->aabb.min);
+	float lr = rgba[0], lg = rgba[1], lb = rgba[2], la = rgba[3];
+	float local_depth = *depth;
+	uint32_t n = 0;
+	uint32_t step = 1;
+	for (; step < ORC_MARCH_ITER; ++step) {
+		t = if_unoccupied_advance_to_next_occupied_voxel(t, cone_angle, origin, dir, idir, m->density_grid_bitfield, 0, m->max_cascade,
+		                                                &p->render_aabb, m->render_aabb_to_local, o->capped_skip);
+		if (t >= MAX_DEPTH) { payload->alive = 0; break; }
+		float dt = calc_dt(t, cone_angle);
+		/* NerfCoordinate written by the generator ... */
+		v3 warped = v3_div(v3_sub(v3_add(origin, v3_scale(dir, t)), p->aabb.min), diag); /* warp_position, nerf_device.cuh:265 */
+		float wdir[3] = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; /* warp_direction :290 */
+		float wdt = warp_dt(dt);
+		t += dt;
+		/* ... network ... */
+		float wpos[3] = {warped.x, warped.y, warped.z};
+		uint16_t out4[4];
+		nerf_network_one(m, p, wpos, wdir, out4);
+		++n;
+		/* ... and read back by the compositor */
+		v3 pos = v3_add(p->aabb.min, v3_mul(warped, diag)); /* unwarp_position */
+		float T = 1.0f - la;
+		float dtu = unwarp_dt(wdt);
+		float alpha = 1.0f - expf(-network_to_density(orc_half_to_float(out4[3]), m->density_activation) * dtu);
+		float weight = alpha * T;
+		float r = network_to_rgb(orc_half_to_float(out4[0]), m->rgb_activation);
+		float g = network_to_rgb(orc_half_to_float(out4[1]), m->rgb_activation);
+		float b = network_to_rgb(orc_half_to_float(out4[2]), m->rgb_activation);
+		lr += r * weight; lg += g * weight; lb += b * weight; la += weight;
+		if (weight > payload->max_weight) {
+			payload->max_weight = weight;
+			local_depth = v3_dot(cam_fwd, v3_sub(pos, cam_pos));
+		}
+		if (la > (1.0f - o->min_transmittance)) {
+			lr /= la; lg /= la; lb /= la; la /= la;
+			payload->alive = 0;
+			break;
+		}
+	}
+	payload->t = t;
+	payload->n_steps = (uint16_t)(n > 65535u ? 65535u : n);
+	rgba[0] = lr; rgba[1] = lg; rgba[2] = lb; rgba[3] = la;
+	*depth = local_depth;
+	return n;
+}
+
+/* K7: shade_kernel_nerf (testbed_nerf.cu:1361-1401), render mode Shade; with o->depth_test the
+ * geometry variant (testbed_geometry_training.cu:1826-1871). */
+static void shade_one(const orc_render_opts* o, const float* rgba, float depth, uint32_t idx, float* frame_buffer, float* depth_buffer) {
+	if (o->depth_test && depth > depth_buffer[idx]) return;
+	float tmp[4] = {rgba[0], rgba[1], rgba[2], rgba[3]};
+	if (!o->train_in_linear_colors) {
+		tmp[0] = orc_srgb_to_linear(tmp[0]);
+		tmp[1] = orc_srgb_to_linear(tmp[1]);
+		tmp[2] = orc_srgb_to_linear(tmp[2]);
+	}
+	float* fb = frame_buffer + 4 * (size_t)idx;
+	float one_minus_a = 1.0f - tmp[3];
+	for (int c = 0; c < 4; ++c) fb[c] = tmp[c] + fb[c] * one_minus_a;
+	if (tmp[3] > 0.2f) depth_buffer[idx] = depth;
+}
+
+void orc_render_nerf(const orc_nerf_model* m, const orc_camera* cam, const orc_render_opts* o, float* frame_buffer, float* depth_buffer, orc_render_stats* stats) {
+	const int64_t n_pixels = (int64_t)cam->width * cam->height;
+	uint64_t n_alive = 0, n_hit = 0, n_samples = 0;
+#ifdef _OPENMP
+	if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : n_alive, n_hit, n_samples)
+	for (int64_t i = 0; i < n_pixels; ++i) {
+		uint32_t x = (uint32_t)(i % cam->width), y = (uint32_t)(i / cam->width);
+		orc_payload payload;
+		orc_init_ray(m, cam, x, y, &payload);
+		/* testbed_nerf.cu:1490-1493 */
+		if (depth_buffer[i] < 0.01f) depth_buffer[i] = MAX_DEPTH;
+		orc_advance_pos(m, cam, &payload);
+		if (!payload.alive) continue;
+		++n_alive;
+		float rgba[4] = {0, 0, 0, 0};
+		float depth = 0.0f;
+		n_samples += orc_trace_ray(m, cam->matrix, o, &payload, rgba, &depth);
+		/* compact_kernel_nerf (:1403-1426): dead rays with alpha > 0.001 reach shading; rays that are
+		 * still alive when the march loop ends never do. */
+		if (!payload.alive && rgba[3] > 0.001f) {
+			++n_hit;
+			shade_one(o, rgba, depth, payload.idx, frame_buffer, depth_buffer);
+		}
+	}
+	if (stats) {
+		stats->n_rays = (uint64_t)n_pixels;
+		stats->n_rays_alive_after_init = n_alive;
+		stats->n_rays_hit = n_hit;
+		stats->n_samples = n_samples;
+	}
+}
+
+void orc_trace_payloads(const orc_nerf_model* m, const float* cam_matrix, const orc_render_opts* o, uint32_t n, orc_payload* payloads, float* rgba, float* depth, orc_render_stats* stats) {
+	uint64_t n_alive = 0, n_hit = 0, n_samples = 0;
+#ifdef _OPENMP
+	if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : n_alive, n_hit, n_samples)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		if (!payloads[i].alive) continue;
+		++n_alive;
+		n_samples += orc_trace_ray(m, cam_matrix, o, &payloads[i], rgba + 4 * i, depth + i);
+		if (!payloads[i].alive && rgba[4 * i + 3] > 0.001f) ++n_hit;
+	}
+	if (stats) {
+		stats->n_rays = n;
+		stats->n_rays_alive_after_init = n_alive;
+		stats->n_rays_hit = n_hit;
+		stats->n_samples = n_samples;
+	}
+}
+
+/* ------------------------------------------------------------------ P1 accumulate + tonemap
+ * render_buffer.cu:228-262 (EColorSpace::Linear) and :529-561 (Identity tonemap curve, no DLSS). */
+void orc_accumulate(uint32_t n_pixels, const float* frame_buffer, float* accumulate_buffer, float sample_count) {
+	for (size_t i = 0; i < (size_t)n_pixels * 4; ++i) {
+		accumulate_buffer[i] = (accumulate_buffer[i] * sample_count + frame_buffer[i]) / (sample_count + 1.0f);
+	}
+}
+
+void orc_tonemap(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, float* rgba_out) {
+	/* colour space is Linear, so the sRGB background colour is linearised first */
+	float bg[4] = {orc_srgb_to_linear(background_rgba[0]), orc_srgb_to_linear(background_rgba[1]), orc_srgb_to_linear(background_rgba[2]), background_rgba[3]};
+	float scale = powf(2.0f, exposure);
+	for (size_t i = 0; i < (size_t)n_pixels; ++i) {
+		float c[4] = {accumulate_buffer[4 * i], accumulate_buffer[4 * i + 1], accumulate_buffer[4 * i + 2], accumulate_buffer[4 * i + 3]};
+		float weight = (1.0f - c[3]) * bg[3];
+		for (int k = 0; k < 3; ++k) c[k] += bg[k] * weight;
+		c[3] += weight;
+		for (int k = 0; k < 3; ++k) {
+			c[k] *= scale;
+			if (to_srgb) c[k] = orc_linear_to_srgb(c[k]);
+		}
+		for (int k = 0; k < 4; ++k) rgba_out[4 * i + k] = c[k];
+	}
+}

@@ -1,0 +1,115 @@
+"""Host-side scene description shared by the synthetic generator, the snapshot reader/writer and the
+ctypes binding of libngp_hip: grid layout, parameter counts, Morton helpers, camera conventions.
+
+Mirrors what Testbed::reset_network / load_nerf_post derive from a config + dataset
+(reference src/testbed.cu:3928-3977, src/testbed_nerf.cu:2720-2738, nerf_loader.h:101-120).
+"""
+import math
+
+import numpy as np
+
+NERF_GRIDSIZE = 128
+NERF_CASCADES = 8
+ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
+
+
+def base_network_config():
+    """configs/nerf/base.json (reference configs/nerf/base.json:23-58), render-relevant parts."""
+    return {
+        "encoding": {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 19, "base_resolution": 16},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1},
+        "dir_encoding": {"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4}, {"otype": "Identity"}]},
+        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }
+
+
+def per_level_scale(aabb_scale, n_levels, base_resolution, rule="fork", desired_resolution=2048.0):
+    """src/testbed.cu:3951-3966. The fork overwrites the value with one derived from
+    m_geometry.nerf...aabb_scale, which is 1 in Nerf mode ('fork' rule); upstream uses the dataset's."""
+    s = 1 if rule == "fork" else aabb_scale
+    if n_levels <= 1:
+        return 1.0
+    v = np.exp(np.log(np.float32(desired_resolution) * np.float32(s) / np.float32(base_resolution)) / np.float32(n_levels - 1))
+    return float(np.float32(v))
+
+
+def grid_layout(enc):
+    """tcnn GridEncoding level table: offsets (entries), resolutions, scales."""
+    n_levels = enc["n_levels"]
+    log2_pls = np.log2(np.float32(enc["per_level_scale"]))
+    offsets, resolutions, scales = [0], [], []
+    for l in range(n_levels):
+        scale = np.float32(np.exp2(np.float32(l) * log2_pls) * np.float32(enc["base_resolution"]) - np.float32(1.0))
+        res = int(math.ceil(float(scale))) + 1
+        n = min(res ** 3, 0xFFFFFFFF // 2)
+        n = (n + 7) // 8 * 8
+        n = min(n, 1 << enc["log2_hashmap_size"])
+        offsets.append(offsets[-1] + n)
+        resolutions.append(res)
+        scales.append(float(scale))
+    return offsets, resolutions, scales
+
+
+def mlp_n_params(n_in, width, n_hidden, n_out_padded):
+    return width * n_in + (n_hidden - 1) * width * width + n_out_padded * width
+
+
+def n_params(cfg):
+    enc = cfg["encoding"]
+    enc_dims = enc["n_levels"] * enc["n_features_per_level"]
+    dens_out = cfg["network"].get("n_output_dims", 16)
+    nd = mlp_n_params(enc_dims, cfg["network"]["n_neurons"], cfg["network"]["n_hidden_layers"], dens_out)
+    nr = mlp_n_params(dens_out + 16, cfg["rgb_network"]["n_neurons"], cfg["rgb_network"]["n_hidden_layers"], 16)
+    offsets, _, _ = grid_layout(enc)
+    return nd, nr, offsets[-1] * enc["n_features_per_level"]
+
+
+def _expand_bits(v):
+    v = v.astype(np.uint32)
+    v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+    v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+    v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+    v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+    return v
+
+
+def morton3d(x, y, z):
+    return _expand_bits(x) | (_expand_bits(y) << np.uint32(1)) | (_expand_bits(z) << np.uint32(2))
+
+
+def max_cascade_for(aabb_scale):
+    mc = 0
+    while (1 << mc) < aabb_scale:
+        mc += 1
+    return mc
+
+
+def nerf_matrix_to_ngp(m, scale=0.33, offset=(0.5, 0.5, 0.5)):
+    """nerf_loader.h:101-120: negate columns 1,2; t*scale+offset; cycle rows (x,y,z) <- (y,z,x).
+    m: (3,4) or (4,4) camera-to-world in the NeRF/Blender convention. Returns (3,4) float32."""
+    m = np.asarray(m, np.float32)[:3, :4].copy()
+    m[:, 1] *= -1.0
+    m[:, 2] *= -1.0
+    m[:, 3] = m[:, 3] * np.float32(scale) + np.asarray(offset, np.float32)
+    return m[[1, 2, 0], :].copy()
+
+
+def orbit_camera(azimuth_deg, elevation_deg=30.0, radius=4.03, scale=0.33, offset=(0.5, 0.5, 0.5)):
+    """SURVEY 8(d) synthetic camera: orbit pose looking at the origin (NeRF convention: camera looks down -z,
+    y up), converted with nerf_matrix_to_ngp."""
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    pos = np.array([radius * math.cos(el) * math.cos(az), radius * math.cos(el) * math.sin(az), radius * math.sin(el)], np.float64)
+    fwd = -pos / np.linalg.norm(pos)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    true_up = np.cross(right, fwd)
+    c2w = np.stack([right, true_up, -fwd, pos], axis=1)  # columns: x, y, z(back), t
+    return nerf_matrix_to_ngp(c2w.astype(np.float32), scale, offset)
+
+
+def focal_from_fov_x(width, fov_x_rad):
+    """fov_axis = 0: relative_focal_length = 0.5 / tan(fov/2); focal = rel * res[0] (src/testbed.cu:4474-4476)."""
+    rel = np.float32(0.5) / np.float32(math.tan(0.5 * fov_x_rad))
+    f = float(rel * np.float32(width))
+    return (f, f)
