@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of NeRF inference at 1920x1080 (BASELINE.json metric).
+
+A step is one frame (1 spp) of the fixed 1080p orbit camera over the Lego-shaped scene (configs[1]: HashGrid
+L8/F4/T19 + 64-wide MLPs; synthetic weights and occupancy, there is no pretrained snapshot in the reference mount).
+With N GPUs the frame's 8x8-pixel camera tiles are dealt round-robin to the ranks (one process per GPU, launched by
+torch.distributed.run) and one RCCL all_gather per frame returns rgba+depth to every rank: total work is fixed, so
+this is strong scaling. Inputs (model, camera) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = "surface-irradiance-estimation-from-neural-radiance-fields_amd"
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+FOV_X = 0.6911  # Blender Lego camera_angle_x
+AZIMUTHS = [0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_SAMPLE = 512.0  # 8 levels x 8 corners x 8 B of hash-grid gathers
+BYTES_PER_RAY = 80.0  # payload/rgba/depth once + frame-buffer scatter
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+def cpu_baseline(scene_dict, scene_mod):
+    """The oracle (kind "port": the reference has no CPU path, scripts/run.py:25 hard-imports the CUDA module) on a
+    bounded sample of the same workload: the same camera and model at 480x270 (1/16 of the pixels)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    out_dir = os.path.join(ROOT, "gpurun_out", "oracle_native")
+    os.makedirs(out_dir, exist_ok=True)
+    try:
+        lib = orc.build(native=True, out_dir=out_dir)
+    except Exception:
+        lib = None
+    o = orc.Oracle(lib)
+    sc = dict(scene_dict)
+    grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
+    sc["density_grid_bitfield"], _ = o.density_grid_to_bitfield(grid, sc["max_cascade"])
+    m = o.make_model(sc)
+    w, h = WIDTH // 4, HEIGHT // 4
+    cam = o.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X))
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _, _, st = o.render_nerf(m, cam, o.make_opts(n_threads=cores))
+    dt = time.perf_counter() - t0
+    o.release(m)
+    return {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"same model+camera at {w}x{h} (1/16 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the renderer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg("build").build()
+    native, synthetic, scene_mod, parallel = pkg("native"), pkg("synthetic"), pkg("scene"), pkg("parallel")
+    sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)  # identical on every rank (seeded)
+    ctx = native.Context(local_rank)
+    ctx.set_model(sc)  # replica per GPU; a broadcast is not needed because every rank generates the same bytes
+
+    w, h = args.width, args.height
+    focal = scene_mod.focal_from_fov_x(w, FOV_X)
+    cams = [native.make_camera(scene_mod.orbit_camera(az), w, h, focal) for az in AZIMUTHS]
+    opts = native.make_opts(shard_index=rank, shard_count=world)
+    rgbad = torch.zeros((h, w, 5), dtype=torch.float32, device=dev)  # not used for rendering; see below
+    rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+    stream = torch.cuda.Stream(dev)  # the stream every kernel, copy and collective of a step is enqueued on
+    torch.cuda.set_stream(stream)
+
+    def step(i):
+        ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            rgbad[..., :4] = rgba
+            rgbad[..., 4] = depth
+            return parallel.gather_frame(rgbad, w, h, rank, world)
+        return rgba
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    hist = ctx.render_history(min(args.steps, 256))
+    local = np.array([[s["n_rays"], s["n_rays_hit"], s["n_samples"], s["kernel_ms"], s["frame_ms"]] for s in hist], np.float64)
+    if world > 1:
+        tl = torch.tensor(local, dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(allr, tl)
+        per_rank = torch.stack(allr).cpu().numpy()
+    else:
+        per_rank = local[None]
+
+    if rank == 0:
+        n_rays = w * h
+        ms = dt / args.steps * 1e3
+        value = n_rays / (dt / args.steps) / 1e6
+        samples_per_frame = per_rank[:, :, 2].sum(0).mean()
+        hits_per_frame = per_rank[:, :, 1].sum(0).mean()
+        # dominant kernel: render_nerf_fused on rank 0 (one launch per step)
+        k_ms = float(per_rank[0, :, 3].mean())
+        k_rays = float(per_rank[0, :, 0].mean())
+        k_samples = float(per_rank[0, :, 2].mean())
+        algo_bytes = k_samples * BYTES_PER_SAMPLE + k_rays * BYTES_PER_RAY
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s @1080p NeRF inference (Lego snapshot); PSNR vs reference",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": "Lego-shaped synthetic scene (HashGrid L8 F4 T2^19 b=2.0, density MLP 32-64-16, rgb MLP 32-64-64-16, aabb_scale 1), "
+                            f"{w}x{h} pinhole camera fov_x 0.6911 rad, 8 orbit azimuths, 1 spp, render_mode Shade, min_transmittance 0.01",
+                "rays_per_step": n_rays,
+                "samples_per_hit_ray": round(samples_per_frame / max(hits_per_frame, 1.0), 2),
+                "hit_fraction": round(hits_per_frame / n_rays, 4),
+                "samples_per_step": int(samples_per_frame),
+                "tile_sharding": f"8x8 tiles round-robin over {world} rank(s)" + (", all_gather of rgba+depth per frame (RCCL)" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel": "render_nerf_fused",
+                "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "mfma_tflops": round(k_samples * 20480.0 / (k_ms * 1e-3) / 1e12, 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, scene_mod)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * libngp_hip.so -- C ABI of the MI355X-native NeRF volume renderer.
+ *
+ * The reference (fnysalehi/Surface-Irradiance-Estimation-from-Neural-Radiance-Fields) has no FFI seam:
+ * its public surface is the C++ class ngp::Testbed (include/neural-graphics-primitives/testbed.h)
+ * re-exported by pybind11 (src/python_api.cu). This header is the seam the build inserts UNDER that
+ * class: every entry point names the Testbed member (file:line in the reference) it replaces. Plain
+ * pointers and sizes only; no exceptions cross the boundary (0 = ok, otherwise ngp_last_error()).
+ *
+ * Threading: a context is not re-entrant -- one host thread per context. All inputs are copied during
+ * the call; no borrowed pointer survives a call.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_API __attribute__((visibility("default")))
+
+typedef struct ngp_ctx ngp_ctx;
+
+enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
+
+/* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
+enum ngp_render_mode { NGP_RENDER_SHADE = 0 };
+
+/* What Testbed::reset_network (src/testbed.cu:3844-4212) + load_nerf_post (src/testbed_nerf.cu:2652-2739)
+ * + the snapshot (src/testbed.cu:5285-5463) leave behind for rendering. */
+typedef struct ngp_model_desc {
+	/* tcnn HashGrid encoding */
+	uint32_t n_levels;
+	uint32_t n_features_per_level;
+	uint32_t log2_hashmap_size;
+	uint32_t base_resolution;
+	float per_level_scale; /* explicit: the fork derives it with aabb_scale = 1, src/testbed.cu:3959-3966 */
+	/* tcnn FullyFusedMLP density / rgb heads (nerf_network.h:81-101) */
+	uint32_t n_neurons;
+	uint32_t n_hidden_density;
+	uint32_t n_hidden_rgb;
+	uint32_t density_out_dims;
+	uint32_t rgb_activation;     /* ngp_activation */
+	uint32_t density_activation; /* ngp_activation */
+	/* Trainer::serialize "params_binary": density MLP, rgb MLP, grid (nerf_network.h:356-371), fp16 */
+	const uint16_t* params_fp16;
+	uint64_t n_params;
+	/* snapshot "density_grid_binary": (max_cascade+1) x 128^3 fp16, Morton order (src/testbed.cu:5339-5347) */
+	const uint16_t* density_grid_fp16;
+	uint64_t n_density_grid;
+	float aabb_min[3], aabb_max[3];               /* m_aabb */
+	float render_aabb_min[3], render_aabb_max[3]; /* m_render_aabb */
+	float render_aabb_to_local[9];                /* column-major mat3 */
+	uint32_t aabb_scale;                          /* dataset.aabb_scale -> max_cascade, src/testbed_nerf.cu:2729-2732 */
+	float cone_angle_constant;                    /* src/testbed_nerf.cu:2736 */
+	int32_t linear_colors;                        /* m_nerf.training.linear_colors */
+} ngp_model_desc;
+
+/* Arguments of Testbed::render_frame (testbed.h:561-575) that the NeRF path consumes. */
+typedef struct ngp_camera {
+	float matrix[12];       /* camera-to-world 4x3 column-major (m_camera) */
+	int32_t width, height;
+	float focal_length[2];  /* pixels: calc_focal_length, src/testbed.cu:4474-4476 */
+	float screen_center[2]; /* render_screen_center */
+	uint32_t spp_index;     /* render_buffer.spp() */
+	int32_t snap_to_pixel_centers;
+	float near_distance;    /* m_render_near_distance */
+} ngp_camera;
+
+typedef struct ngp_render_opts {
+	int32_t render_mode;      /* ngp_render_mode */
+	float min_transmittance;  /* m_nerf.render_min_transmittance */
+	float background[4];      /* m_background_color (sRGB, straight) */
+	float exposure;           /* m_exposure */
+	int32_t to_srgb;          /* !linear of Testbed::render (python_api.cu:124,189) */
+	int32_t spp;              /* samples accumulated by ngp_render */
+	/* camera-tile sharding across GPUs: this context renders 8x8-pixel tiles t with t % shard_count == shard_index */
+	uint32_t shard_index, shard_count;
+} ngp_render_opts;
+
+typedef struct ngp_render_stats {
+	uint64_t n_rays;
+	uint64_t n_rays_alive_after_init;
+	uint64_t n_rays_hit;
+	uint64_t n_samples;      /* network queries composited */
+	float kernel_ms;         /* duration of the fused march/encode/MLP/composite kernel, HIP events on its stream */
+	float frame_ms;          /* whole frame on the device (clear .. tonemap), HIP events */
+} ngp_render_stats;
+
+/* --- lifetime: Testbed::Testbed / ~Testbed (testbed.h:80-95) */
+NGP_API ngp_ctx* ngp_create(int device);
+NGP_API void ngp_destroy(ngp_ctx* ctx);
+NGP_API const char* ngp_last_error(const ngp_ctx* ctx);
+NGP_API const char* ngp_version(void);
+
+/* --- model: Testbed::reset_network + Trainer::deserialize (src/testbed.cu:3844,5428-5433) */
+NGP_API int ngp_set_model(ngp_ctx* ctx, const ngp_model_desc* desc);
+/* Testbed::load_snapshot(std::istream&, bool is_compressed) (src/testbed.cu:5477-5488): msgpack, optionally zlib (.ingp) */
+NGP_API int ngp_load_snapshot(ngp_ctx* ctx, const void* bytes, size_t n_bytes, int is_compressed);
+/* Testbed::load_snapshot(const fs::path&) (src/testbed.cu:5465-5475) */
+NGP_API int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path);
+/* Testbed::save_snapshot (src/testbed.cu:5219-5283), inference state only */
+NGP_API int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress);
+/* the model as currently loaded (pointers in the returned desc are NULL; sizes are valid) */
+NGP_API int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out);
+/* camera stored in the snapshot: m_camera, relative focal length, fov axis, screen center, zoom */
+NGP_API int ngp_get_snapshot_camera(const ngp_ctx* ctx, float* matrix12, float* relative_focal_length2, int32_t* fov_axis, float* screen_center2, float* zoom);
+
+/* --- data: Testbed::load_training_data (src/testbed.cu:125-152) -> ngp::load_nerf (src/nerf_loader.cu:273):
+ * camera metadata of a transforms.json (or a directory of them); images are not decoded (inference path). */
+NGP_API int ngp_load_training_data(ngp_ctx* ctx, const char* path);
+NGP_API int ngp_n_training_views(const ngp_ctx* ctx);
+/* per-view: ngp-space camera matrix (nerf_matrix_to_ngp applied), resolution, focal length (pixels), principal point */
+NGP_API int ngp_get_training_view(const ngp_ctx* ctx, int view, float* matrix12, int32_t* resolution2, float* focal_length2, float* principal_point2);
+NGP_API int ngp_get_dataset_info(const ngp_ctx* ctx, int32_t* aabb_scale, float* scale, float* offset3, int32_t* is_hdr);
+
+/* --- render: Testbed::render_frame (src/testbed.cu:4694-4721) = clear + render_nerf (src/testbed_nerf.cu:2328-2488)
+ * + accumulate/tonemap (src/render_buffer.cu:631-694) for opts->spp samples, then the copy that
+ * Testbed::render_to_cpu (src/python_api.cu:197-201) does. rgba_out: host, H*W*4 floats, premultiplied alpha.
+ * depth_out (nullable): host, H*W floats. */
+NGP_API int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out);
+/* Same frame, results left in device memory (d_rgba: W*H*4 floats, d_depth nullable: W*H floats) and enqueued on
+ * `stream` (a hipStream_t, NULL = default stream) without synchronising: for callers that keep the image on the GPU
+ * (RCCL gather of tiles, benchmarks). */
+NGP_API int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, void* d_rgba, void* d_depth, void* stream);
+/* counters + timings of the last ngp_render / ngp_render_device (synchronises the stream) */
+NGP_API int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out);
+/* the same for the last n calls (oldest first; the context keeps 256), read once after a batch of asynchronous
+ * ngp_render_device calls so that measuring does not serialise them */
+NGP_API int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out);
+
+/* --- stage entry points (what the reference launches as separate kernels; used by parity tests and tools)
+ * K5a tcnn GridEncoding::inference (call site nerf_network.h:113-118): host pos01 n x 3 -> host fp16 n x (L*F) */
+NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_fp16);
+/* K5 NerfNetwork::inference_mixed_precision (nerf_network.h:105-139): pos01/dir01 n x 3 -> fp16 n x 4 (rgb logits, density logit) */
+NGP_API int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16);
+/* K8/K9 update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:2863-2880): the bitfield in use, 8 x 128^3 / 8 bytes */
+NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean);
+/* K1+K2 init_rays_with_payload_kernel_nerf + advance_pos_nerf_kernel (src/testbed_nerf.cu:1428-1544,333-381):
+ * out: W*H NerfPayload records of 40 bytes (nerf_device.cuh:144-152) */
+NGP_API int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

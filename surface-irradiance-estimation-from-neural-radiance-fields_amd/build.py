@@ -1,0 +1,46 @@
+"""hipcc driver: compiles csrc/ into the in-tree libngp_hip.so (gfx950 only; cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libngp_hip.so")
+SOURCES = ["nerf_kernels.hip", "mesh_kernels.hip", "ngp_api.cpp", "ngp_mesh.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in os.listdir(CSRC):
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    inc = os.path.join(HERE, "..", "include", "ngp_hip.h")
+    return os.path.getmtime(inc) > t
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + srcs + ["-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,443 @@
+// Device-side building blocks of the NeRF inference path, written for CDNA4 (gfx950, wave64).
+//
+// Arithmetic contract (DESIGN.md "Numerics"): IEEE fp32, no FMA contraction (-ffp-contract=off), correctly
+// rounded division/sqrt; hash-grid features accumulate in fp16 exactly like tcnn's kernel_grid; MLP layers run on
+// v_mfma_f32_16x16x32_f16 (fp16 operands, fp32 accumulate) with activations rounded to fp16 between layers.
+// Each function cites the reference kernel/device function whose behaviour it reproduces.
+#pragma once
+
+#include "ngp_kernels.h"
+
+namespace ngp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct f3 {
+	float x, y, z;
+};
+
+#define NGP_DEV __device__ __forceinline__
+
+NGP_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+NGP_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NGP_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NGP_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+NGP_DEV f3 div3(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+NGP_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+NGP_DEV f3 adds3(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+NGP_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+NGP_DEV f3 normalize3(f3 a) {
+	float len = __builtin_sqrtf(dot3(a, a));
+	return mk3(a.x / len, a.y / len, a.z / len);
+}
+// column-major 3x3 times vector, accumulated column by column
+NGP_DEV f3 m3_mulv(const float* m, f3 v) {
+	f3 r = mk3(m[0] * v.x, m[1] * v.x, m[2] * v.x);
+	r = add3(r, mk3(m[3] * v.y, m[4] * v.y, m[5] * v.y));
+	r = add3(r, mk3(m[6] * v.z, m[7] * v.z, m[8] * v.z));
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Low-discrepancy sequences: random_val.cuh:274-336. Sobol dimension 0 has direction numbers 1<<(31-bit), i.e.
+// sobol(index, 0) is a plain bit reversal, which gfx950 does in one v_bfrev_b32.
+NGP_DEV uint32_t laine_karras_permutation(uint32_t x, uint32_t seed) {
+	x += seed;
+	x ^= x * 0x6c50b47cu;
+	x ^= x * 0xb82f1e52u;
+	x ^= x * 0xc7afe638u;
+	x ^= x * 0x8d22f6e6u;
+	return x;
+}
+NGP_DEV uint32_t nested_uniform_scramble_base2(uint32_t x, uint32_t seed) {
+	x = __builtin_bitreverse32(x);
+	x = laine_karras_permutation(x, seed);
+	return __builtin_bitreverse32(x);
+}
+NGP_DEV uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+NGP_DEV float ld_random_val_dim0(uint32_t index, uint32_t seed) {
+	index = nested_uniform_scramble_base2(index, seed);
+	uint32_t x = nested_uniform_scramble_base2(__builtin_bitreverse32(index), hash_combine(seed, 0u));
+	return (float)x * 2.3283064365386963e-10f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Exponential stepping: nerf_device.cuh:378-428
+NGP_DEV float stepsize() { return 1.73205080757f / (float)NERF_STEPS; }
+NGP_DEV float max_cone_stepsize() { return stepsize() * (float)(1u << (NERF_CASCADES - 1)) * (float)NERF_STEPS / (float)NERF_GRIDSIZE; }
+
+NGP_DEV float to_stepping_space(float t, float cone_angle) {
+	if (cone_angle <= 1e-5f) return t / stepsize();
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(stepsize()) - logf(log1p_c)) / log1p_c;
+	float b = (logf(max_cone_stepsize()) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c);
+	float bt = expf(b * log1p_c);
+	if (t <= at) return (t - at) / stepsize() + a;
+	else if (t <= bt) return logf(t) / log1p_c;
+	else return (t - bt) / max_cone_stepsize() + b;
+}
+NGP_DEV float from_stepping_space(float n, float cone_angle) {
+	if (cone_angle <= 1e-5f) return n * stepsize();
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(stepsize()) - logf(log1p_c)) / log1p_c;
+	float b = (logf(max_cone_stepsize()) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c);
+	float bt = expf(b * log1p_c);
+	if (n <= a) return (n - a) * stepsize() + at;
+	else if (n <= b) return expf(n * log1p_c);
+	else return (n - b) * max_cone_stepsize() + bt;
+}
+NGP_DEV float advance_n_steps(float t, float cone_angle, float n) { return from_stepping_space(to_stepping_space(t, cone_angle) + n, cone_angle); }
+NGP_DEV float calc_dt(float t, float cone_angle) { return advance_n_steps(t, cone_angle, 1.0f) - t; }
+NGP_DEV float warp_dt(float dt) { // nerf_device.cuh:306-309
+	float max_stepsize = stepsize() * (float)(1u << (NERF_CASCADES - 1));
+	return (dt - stepsize()) / (max_stepsize - stepsize());
+}
+NGP_DEV float unwarp_dt(float dt) { // nerf_device.cuh:311-314
+	float max_stepsize = stepsize() * (float)(1u << (NERF_CASCADES - 1));
+	return dt * (max_stepsize - stepsize()) + stepsize();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Occupancy grid: nerf_device.cuh:316-367,430-447; Morton code as tcnn's morton3D.
+NGP_DEV uint32_t expand_bits(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+NGP_DEV uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) { return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2); }
+NGP_DEV uint32_t morton3D_invert(uint32_t x) {
+	x = x & 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+
+NGP_DEV bool density_grid_occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
+	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
+	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
+	int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
+	int iy = (int)(pos.y * (float)NERF_GRIDSIZE);
+	int iz = (int)(pos.z * (float)NERF_GRIDSIZE);
+	if (ix < 0 || ix >= (int)NERF_GRIDSIZE || iy < 0 || iy >= (int)NERF_GRIDSIZE || iz < 0 || iz >= (int)NERF_GRIDSIZE) return false;
+	uint32_t idx = morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+	return (bitfield[idx / 8 + (NERF_GRID_N_CELLS / 8) * mip] & (1u << (idx % 8))) != 0;
+}
+
+NGP_DEV float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, float res) {
+	f3 p = scale3(adds3(pos, -0.5f), res);
+	float tx = (__builtin_floorf(p.x + 0.5f + 0.5f * __builtin_copysignf(1.0f, dir.x)) - p.x) * idir.x;
+	float ty = (__builtin_floorf(p.y + 0.5f + 0.5f * __builtin_copysignf(1.0f, dir.y)) - p.y) * idir.y;
+	float tz = (__builtin_floorf(p.z + 0.5f + 0.5f * __builtin_copysignf(1.0f, dir.z)) - p.z) * idir.z;
+	float t = fminf(fminf(tx, ty), tz);
+	return fmaxf(t / res, 0.0f);
+}
+NGP_DEV float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t mip) {
+	float res = __builtin_ldexpf((float)NERF_GRIDSIZE, -(int)mip);
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	t = to_stepping_space(t, cone_angle);
+	t_target = to_stepping_space(t_target, cone_angle);
+	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+}
+NGP_DEV uint32_t mip_from_pos(f3 pos, uint32_t max_cascade) {
+	int exponent;
+	float maxval = fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f));
+	(void)__builtin_frexpf(maxval, &exponent);
+	int v = exponent + 1;
+	v = v < 0 ? 0 : v;
+	v = v > (int)max_cascade ? (int)max_cascade : v;
+	return (uint32_t)v;
+}
+
+NGP_DEV bool raabb_contains(const ModelParams& M, f3 p) {
+	p = m3_mulv(M.r2l, p);
+	return p.x >= M.raabb_min[0] && p.x <= M.raabb_max[0] && p.y >= M.raabb_min[1] && p.y <= M.raabb_max[1] && p.z >= M.raabb_min[2] && p.z <= M.raabb_max[2];
+}
+
+// if_unoccupied_advance_to_next_occupied_voxel, nerf_device.cuh:461-494 (CAPPED: the 200-iteration variant :497-534)
+template <bool CAPPED>
+NGP_DEV float skip_empty_space(float t, const ModelParams& M, f3 o, f3 d, f3 idir) {
+	const float cone_angle = M.cone_angle;
+	uint32_t i = 1;
+	while (!CAPPED || i < 200) {
+		f3 pos = add3(o, scale3(d, t));
+		if (t >= MAX_DEPTH || !raabb_contains(M, pos)) return MAX_DEPTH;
+		uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
+		mip = mip > M.max_cascade ? M.max_cascade : mip; // clamp(mip, min_mip = 0, max_mip)
+		if (density_grid_occupied_at(pos, M.bitfield, mip)) return t;
+		while (mip < M.max_cascade && !density_grid_occupied_at(pos, M.bitfield, mip + 1)) ++mip;
+		t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+		++i;
+	}
+	return MAX_DEPTH;
+}
+
+// BoundingBox::ray_intersect, bounding_box.cuh:172-219 (entry distance only; FLT_MAX on a miss)
+NGP_DEV float aabb_ray_entry(const float* bmin, const float* bmax, f3 pos, f3 dir) {
+	const float FMAX = 3.402823466e+38f;
+	float tmin = (bmin[0] - pos.x) / dir.x;
+	float tmax = (bmax[0] - pos.x) / dir.x;
+	if (tmin > tmax) { float s = tmin; tmin = tmax; tmax = s; }
+	float tymin = (bmin[1] - pos.y) / dir.y;
+	float tymax = (bmax[1] - pos.y) / dir.y;
+	if (tymin > tymax) { float s = tymin; tymin = tymax; tymax = s; }
+	if (tmin > tymax || tymin > tmax) return FMAX;
+	if (tymin > tmin) tmin = tymin;
+	if (tymax < tmax) tmax = tymax;
+	float tzmin = (bmin[2] - pos.z) / dir.z;
+	float tzmax = (bmax[2] - pos.z) / dir.z;
+	if (tzmin > tzmax) { float s = tzmin; tzmin = tzmax; tzmax = s; }
+	if (tmin > tzmax || tzmin > tmax) return FMAX;
+	if (tzmin > tmin) tmin = tzmin;
+	return tmin;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1 + K2: init_rays_with_payload_kernel_nerf (testbed_nerf.cu:1428-1544, perspective branch of uv_to_ray,
+// common_device.cuh:416-483) followed by advance_pos_nerf (:333-362).
+struct RayState {
+	f3 o, d;
+	float t;
+	uint32_t idx;
+	bool alive;
+};
+
+NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
+	r.idx = x + (uint32_t)C.width * y;
+	float u = ((float)x + C.pixel_offset[0]) / (float)C.width;
+	float v = ((float)y + C.pixel_offset[1]) / (float)C.height;
+	f3 dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
+	dir = m3_mulv(C.m, dir);
+	f3 origin = mk3(C.m[9], C.m[10], C.m[11]);
+	origin = add3(origin, scale3(dir, C.near_distance));
+	r.o = origin;
+	r.d = mk3(0.f, 0.f, 0.f);
+	r.t = 0.f;
+	r.alive = false;
+	if (dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
+	dir = normalize3(dir);
+	float t = fmaxf(aabb_ray_entry(M.raabb_min, M.raabb_max, m3_mulv(M.r2l, origin), m3_mulv(M.r2l, dir)), 0.0f) + 1e-6f;
+	if (!raabb_contains(M, add3(origin, scale3(dir, t)))) return;
+	r.d = dir;
+	r.t = t;
+	r.alive = true;
+}
+
+NGP_DEV void advance_pos(const ModelParams& M, const CameraParams& C, RayState& r) {
+	if (!r.alive) return;
+	f3 idir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+	float t = advance_n_steps(r.t, M.cone_angle, ld_random_val_dim0(C.spp, r.idx * 786433u));
+	t = skip_empty_space<false>(t, M, r.o, r.d, idir);
+	if (t >= MAX_DEPTH) r.alive = false;
+	else r.t = t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5a: two levels of the multiresolution hash grid for one sample, landing directly in MFMA B-operand order.
+// tcnn kernel_grid semantics (pos = fma(scale, x, 0.5); 8 corners, bit d of the corner index selects +1 along
+// dimension d; result[f] += (half)(weight * (float)value[f]) accumulated in fp16).
+struct CornerSet {
+	uint32_t index[8];
+	float weight[8];
+};
+
+NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, CornerSet& cs) {
+	float fx = __builtin_fmaf(L.scale, x, 0.5f), fy = __builtin_fmaf(L.scale, y, 0.5f), fz = __builtin_fmaf(L.scale, z, 0.5f);
+	float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy), flz = __builtin_floorf(fz);
+	uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
+	float wx = fx - flx, wy = fy - fly, wz = fz - flz;
+	float wx0 = 1.0f - wx, wy0 = 1.0f - wy, wz0 = 1.0f - wz;
+	uint32_t ix[2], iy[2], iz[2];
+	if (L.hashed) {
+		ix[0] = gx;               ix[1] = gx + 1u;
+		iy[0] = gy * 2654435761u; iy[1] = (gy + 1u) * 2654435761u;
+		iz[0] = gz * 805459861u;  iz[1] = (gz + 1u) * 805459861u;
+	} else {
+		uint32_t r2 = L.res * L.res;
+		ix[0] = gx;         ix[1] = gx + 1u;
+		iy[0] = gy * L.res; iy[1] = (gy + 1u) * L.res;
+		iz[0] = gz * r2;    iz[1] = (gz + 1u) * r2;
+	}
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+		uint32_t idx = L.hashed ? (ix[bx] ^ iy[by] ^ iz[bz]) : (ix[bx] + iy[by] + iz[bz]);
+		idx = L.mask ? (idx & L.mask) : (idx % L.size);
+		cs.index[c] = L.offset + idx;
+		cs.weight[c] = ((bx ? wx : wx0) * (by ? wy : wy0)) * (bz ? wz : wz0);
+	}
+}
+
+NGP_DEV void accumulate_corner(uint2 v, float w, half_t* r) {
+	union { uint2 u; half_t h[4]; } cv;
+	cv.u = v;
+#pragma unroll
+	for (int f = 0; f < 4; ++f) {
+		float prod = w * (float)cv.h[f];
+		r[f] = r[f] + (half_t)prod;
+	}
+}
+
+// lane (h, c) of a 16-sample pass encodes levels h and h+4: B-fragment element j<4 is feature j of level h,
+// element j>=4 is feature j-4 of level h+4 (the K permutation n(s,h,j) = 32s + 16(j>>2) + 4h + (j&3) that the
+// host applied to every weight matrix, see ngp_api.cpp build_weight_fragments).
+NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const LevelInfo* lv, int h, float x, float y, float z) {
+	CornerSet c0, c1;
+	level_corners(lv[h], x, y, z, c0);
+	level_corners(lv[h + 4], x, y, z, c1);
+	uint2 v0[8], v1[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) v0[c] = grid[c0.index[c]];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) v1[c] = grid[c1.index[c]];
+	half_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+	for (int c = 0; c < 8; ++c) accumulate_corner(v0[c], c0.weight[c], r);
+#pragma unroll
+	for (int c = 0; c < 8; ++c) accumulate_corner(v1[c], c1.weight[c], r + 4);
+	half8 out;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) out[j] = r[j];
+	return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5c: tcnn SphericalHarmonics degree 4 -- the four coefficients 4h..4h+3 that lane group h feeds to the rgb head.
+NGP_DEV void sh4_quad(int h, float dx01, float dy01, float dz01, float* out4) {
+	float x = dx01 * 2.0f - 1.0f, y = dy01 * 2.0f - 1.0f, z = dz01 * 2.0f - 1.0f;
+	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	float o[16];
+	o[0] = 0.28209479177387814f;
+	o[1] = -0.48860251190291987f * y;
+	o[2] = 0.48860251190291987f * z;
+	o[3] = -0.48860251190291987f * x;
+	o[4] = 1.0925484305920792f * xy;
+	o[5] = -1.0925484305920792f * yz;
+	o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+	o[7] = -1.0925484305920792f * xz;
+	o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+	o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+	o[10] = 2.8906114426405538f * xy * z;
+	o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+	o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+	o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+	o[14] = 1.4453057213202769f * z * (x2 - y2);
+	o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		float a = h == 0 ? o[j] : o[4 + j];
+		float b = h == 2 ? o[8 + j] : o[12 + j];
+		out4[j] = h < 2 ? a : b;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5b/K5d: the two fully fused MLPs for 16 samples on one wave. Samples sit on the MFMA N axis (lane & 15),
+// neurons on the M axis, so every layer's fp32 accumulator tile D[neuron = 4h + r][sample = c] is, after ReLU
+// and a cvt to fp16, already the next layer's B operand -- no LDS transpose, no cross-lane traffic
+// (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").
+NGP_DEV half8 ld_frag(const uint4* s_w, int f, int lane) {
+	union { uint4 u; half8 h; } cv;
+	cv.u = s_w[f * 64 + lane];
+	return cv.h;
+}
+NGP_DEV floatx4 mfma16(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+NGP_DEV half8 relu_pack(floatx4 lo, floatx4 hi) {
+	half8 r;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		r[j] = (half_t)fmaxf(lo[j], 0.0f);
+		r[4 + j] = (half_t)fmaxf(hi[j], 0.0f);
+	}
+	return r;
+}
+
+struct MlpOut {
+	half_t rgb[3];  // valid in lanes with h == 0
+	half_t sigma;   // density logit, valid in lanes with h == 0
+};
+
+NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, float dx01, float dy01, float dz01) {
+	const int h = lane >> 4;
+	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+	// density head: 32 -> 64 (ReLU) -> 16
+	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
+	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
+	floatx4 d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
+	floatx4 d3 = mfma16(ld_frag(s_w, FRAG_D0 + 3, lane), enc, zero);
+	half8 b0 = relu_pack(d0, d1), b1 = relu_pack(d2, d3);
+	floatx4 dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
+	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
+	// rgb head input: [density out 4h..4h+3 | SH 4h..4h+3]
+	float sh[4];
+	sh4_quad(h, dx01, dy01, dz01, sh);
+	half8 rin;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		rin[j] = (half_t)dens[j];
+		rin[4 + j] = (half_t)sh[j];
+	}
+	MlpOut out;
+	out.sigma = rin[0];
+	// rgb head: 32 -> 64 (ReLU) -> 64 (ReLU) -> 16
+	d0 = mfma16(ld_frag(s_w, FRAG_R0 + 0, lane), rin, zero);
+	d1 = mfma16(ld_frag(s_w, FRAG_R0 + 1, lane), rin, zero);
+	d2 = mfma16(ld_frag(s_w, FRAG_R0 + 2, lane), rin, zero);
+	d3 = mfma16(ld_frag(s_w, FRAG_R0 + 3, lane), rin, zero);
+	b0 = relu_pack(d0, d1);
+	b1 = relu_pack(d2, d3);
+	d0 = mfma16(ld_frag(s_w, FRAG_R1 + 0, lane), b0, zero);
+	d0 = mfma16(ld_frag(s_w, FRAG_R1 + 1, lane), b1, d0);
+	d1 = mfma16(ld_frag(s_w, FRAG_R1 + 2, lane), b0, zero);
+	d1 = mfma16(ld_frag(s_w, FRAG_R1 + 3, lane), b1, d1);
+	d2 = mfma16(ld_frag(s_w, FRAG_R1 + 4, lane), b0, zero);
+	d2 = mfma16(ld_frag(s_w, FRAG_R1 + 5, lane), b1, d2);
+	d3 = mfma16(ld_frag(s_w, FRAG_R1 + 6, lane), b0, zero);
+	d3 = mfma16(ld_frag(s_w, FRAG_R1 + 7, lane), b1, d3);
+	half8 c0 = relu_pack(d0, d1), c1 = relu_pack(d2, d3);
+	floatx4 rgb = mfma16(ld_frag(s_w, FRAG_R2 + 0, lane), c0, zero);
+	rgb = mfma16(ld_frag(s_w, FRAG_R2 + 1, lane), c1, rgb);
+	out.rgb[0] = (half_t)rgb[0];
+	out.rgb[1] = (half_t)rgb[1];
+	out.rgb[2] = (half_t)rgb[2];
+	return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// activations, nerf_device.cuh:203-263
+NGP_DEV float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+NGP_DEV float network_to_rgb(float v, uint32_t act) {
+	switch (act) {
+		case 1: return v > 0.0f ? v : 0.0f;
+		case 2: return logistic(v);
+		case 3: return expf(fminf(fmaxf(v, -10.0f), 10.0f));
+		default: return v;
+	}
+}
+NGP_DEV float network_to_density(float v, uint32_t act) {
+	switch (act) {
+		case 1: return v > 0.0f ? v : 0.0f;
+		case 2: return logistic(v);
+		case 3: return expf(v);
+		default: return v;
+	}
+}
+NGP_DEV float srgb_to_linear(float s) { // common_device.cuh:34-40
+	return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f);
+}
+NGP_DEV float linear_to_srgb(float l) { // common_device.cuh:58-64
+	return l < 0.0031308f ? 12.92f * l : 1.055f * powf(l, 0.41666f) - 0.055f;
+}
+
+NGP_DEV uint32_t lanes_below(unsigned long long mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+} // namespace ngp

@@ -1,0 +1,395 @@
+// Kernels of the NeRF inference hot path for MI355X (gfx950).
+//
+// render_nerf_fused: ONE persistent launch per sample-per-pixel replaces the reference's per-iteration chain
+//   compact_kernel_nerf -> (D2H counter + stream sync) -> generate_next_nerf_network_inputs -> 4 tcnn launches +
+//   extract_density -> composite_kernel_nerf        (reference src/testbed_nerf.cu:2056-2138)
+// and the ray setup / shading kernels around it (:1878-1921, :2463). Rays never leave registers: no NerfPayload,
+// NerfCoordinate or network-output round trip through HBM; the only global traffic is hash-table gathers,
+// occupancy bits and one frame-buffer write per pixel.
+//
+// Work distribution: 8x8-pixel camera tiles are dealt from a global atomic queue (one atomic per 64 rays). Each
+// wave64 owns 64 ray slots; finished slots are refilled from the wave's current tile using a wave ballot +
+// prefix count (mbcnt) -- the wave64 counterpart of the reference's global-atomic compaction, with no host sync.
+// Every iteration the live slots are compacted (ds_permute) onto 16-sample MFMA passes: 4 lanes cooperate on one
+// sample's hash-grid levels (2 levels each) and the MLPs run with samples on the MFMA N axis (nerf_device.h).
+#include "nerf_device.h"
+
+namespace ngp {
+
+constexpr int BLOCK = 256;
+constexpr int REFILL_MIN = 8; // refill once at least this many of a wave's 64 ray slots are free
+
+struct Accum {
+	float r, g, b, a;
+	float depth;
+	float max_weight;
+};
+
+// shade_kernel_nerf (src/testbed_nerf.cu:1361-1401, Shade mode) / shade_kernel_nerf_geometry depth test
+// (src/testbed_geometry_training.cu:1843-1846) for one finished ray. compact_kernel_nerf (:1420) only forwards
+// rays with alpha > 0.001.
+NGP_DEV bool shade_ray(const FrameParams& F, uint32_t idx, const Accum& acc) {
+	if (!(acc.a > 0.001f)) return false;
+	if (F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
+	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
+	if (!F.linear_colors) {
+		r = srgb_to_linear(r);
+		g = srgb_to_linear(g);
+		b = srgb_to_linear(b);
+	}
+	float4 fb = F.frame_buffer[idx];
+	float k = 1.0f - a;
+	fb.x = r + fb.x * k;
+	fb.y = g + fb.y * k;
+	fb.z = b + fb.z * k;
+	fb.w = a + fb.w * k;
+	F.frame_buffer[idx] = fb;
+	if (a > 0.2f) F.depth_buffer[idx] = acc.depth;
+	return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
+	__shared__ uint4 s_w[N_FRAGS * 64];
+	__shared__ LevelInfo s_lv[N_LEVELS];
+	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63;
+	const int c = lane & 15;
+	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
+	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
+	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
+	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
+
+	// per-lane ray slot
+	RayState ray;
+	ray.alive = false;
+	ray.o = ray.d = mk3(0.f, 0.f, 0.f);
+	ray.t = 0.f;
+	ray.idx = 0;
+	f3 idir = mk3(0.f, 0.f, 0.f);
+	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	uint32_t step = 1;
+
+	// wave-uniform tile reservoir
+	uint32_t tile = 0, tile_next = 64;
+	bool exhausted = false;
+	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
+
+	for (;;) {
+		// ---- refill free slots from the tile queue (K1 + K2)
+		unsigned long long dead_mask = __ballot(!ray.alive);
+		int n_dead = __popcll(dead_mask);
+		if (!exhausted && n_dead >= REFILL_MIN) {
+			if (tile_next >= 64) {
+				uint32_t tq = 0;
+				if (lane == 0) tq = atomicAdd(F.queue, 1u);
+				tq = __builtin_amdgcn_readfirstlane(tq);
+				if (tq >= F.n_local_tiles) {
+					exhausted = true;
+				} else {
+					tile = F.shard_index + F.shard_count * tq;
+					tile_next = 0;
+				}
+			}
+			if (!exhausted) {
+				uint32_t slot = tile_next + lanes_below(dead_mask);
+				if (!ray.alive && slot < 64) {
+					uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
+					uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
+					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
+						init_ray(M, C, x, y, ray);
+						// src/testbed_nerf.cu:1490-1493
+						if (F.depth_buffer[ray.idx] < 0.01f) F.depth_buffer[ray.idx] = MAX_DEPTH;
+						advance_pos(M, C, ray);
+						if (ray.alive) {
+							idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+							acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+							step = 1;
+							++n_alive_init;
+						}
+					}
+				}
+				uint32_t adv = tile_next + (uint32_t)n_dead;
+				tile_next = adv > 64u ? 64u : adv;
+			}
+		}
+
+		// ---- K4: skip empty space, emit the next sample (generate_next_nerf_network_inputs, :430-477)
+		float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
+		if (ray.alive) {
+			float t = skip_empty_space<false>(ray.t, M, ray.o, ray.d, idir);
+			if (t >= MAX_DEPTH) {
+				ray.alive = false;
+				n_hit += shade_ray(F, ray.idx, acc) ? 1u : 0u;
+			} else {
+				float dt = calc_dt(t, M.cone_angle);
+				f3 w = div3(sub3(add3(ray.o, scale3(ray.d, t)), amin), adiag); // warp_position
+				wx = w.x; wy = w.y; wz = w.z;
+				wdt = warp_dt(dt);
+				ray.t = t + dt;
+			}
+		}
+		unsigned long long alive_mask = __ballot(ray.alive);
+		int n_alive = __popcll(alive_mask);
+		if (n_alive == 0) {
+			if (exhausted) break;
+			continue;
+		}
+
+		// ---- compact live slots onto MFMA sample slots: a bijection lane -> slot (live first)
+		uint32_t my_slot = ray.alive ? lanes_below(alive_mask) : (uint32_t)n_alive + lanes_below(~alive_mask);
+		int slot_owner = __builtin_amdgcn_ds_permute((int)(my_slot * 4u), lane); // lane k learns who owns slot k
+		float ddx = (ray.d.x + 1.0f) * 0.5f, ddy = (ray.d.y + 1.0f) * 0.5f, ddz = (ray.d.z + 1.0f) * 0.5f; // warp_direction
+
+		// ---- K5: network, 16 samples per pass
+		half_t o_r = 0, o_g = 0, o_b = 0, o_s = 0;
+		const int n_pass = (n_alive + 15) >> 4;
+		for (int p = 0; p < n_pass; ++p) {
+			int src = __shfl(slot_owner, 16 * p + c, 64);
+			float sx = __shfl(wx, src, 64), sy = __shfl(wy, src, 64), sz = __shfl(wz, src, 64);
+			float sdx = __shfl(ddx, src, 64), sdy = __shfl(ddy, src, 64), sdz = __shfl(ddz, src, 64);
+			half8 enc = encode_level_pair(M.grid, s_lv, lane >> 4, sx, sy, sz);
+			MlpOut mo = mlp_pass(s_w, lane, enc, sdx, sdy, sdz);
+			// results live in lanes 0..15 (h == 0); the owner of slot 16p+c pulls them from lane c
+			union { half_t h[2]; int i; } lo, hi;
+			lo.h[0] = mo.rgb[0]; lo.h[1] = mo.rgb[1];
+			hi.h[0] = mo.rgb[2]; hi.h[1] = mo.sigma;
+			int from = (int)(my_slot & 15u);
+			int rlo = __shfl(lo.i, from, 64), rhi = __shfl(hi.i, from, 64);
+			if ((int)(my_slot >> 4) == p) {
+				lo.i = rlo; hi.i = rhi;
+				o_r = lo.h[0]; o_g = lo.h[1]; o_b = hi.h[0]; o_s = hi.h[1];
+			}
+		}
+
+		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
+		if (ray.alive) {
+			++n_samples;
+			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
+			float T = 1.0f - acc.a;
+			float dt = unwarp_dt(wdt);
+			float alpha = 1.0f - expf(-network_to_density((float)o_s, M.density_act) * dt);
+			float weight = alpha * T;
+			acc.r += network_to_rgb((float)o_r, M.rgb_act) * weight;
+			acc.g += network_to_rgb((float)o_g, M.rgb_act) * weight;
+			acc.b += network_to_rgb((float)o_b, M.rgb_act) * weight;
+			acc.a += weight;
+			if (weight > acc.max_weight) {
+				acc.max_weight = weight;
+				acc.depth = dot3(cam_fwd, sub3(pos, cam_pos));
+			}
+			++step;
+			if (acc.a > (1.0f - F.min_transmittance)) {
+				acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
+				ray.alive = false;
+				n_hit += shade_ray(F, ray.idx, acc) ? 1u : 0u;
+			} else if (step >= MARCH_ITER) {
+				ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
+			}
+		}
+	}
+
+	// ---- counters (one atomic per wave and counter)
+	for (int off = 32; off > 0; off >>= 1) {
+		n_alive_init += __shfl_down(n_alive_init, off, 64);
+		n_hit += __shfl_down(n_hit, off, 64);
+		n_samples += __shfl_down(n_samples, off, 64);
+	}
+	if (lane == 0) {
+		atomicAdd(&F.counters[0], (unsigned long long)n_alive_init);
+		atomicAdd(&F.counters[1], (unsigned long long)n_hit);
+		atomicAdd(&F.counters[2], (unsigned long long)n_samples);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stage kernels (parity tests / tools): same device functions, one wave = 64 samples in 4 passes.
+__global__ __launch_bounds__(BLOCK) void grid_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {
+	__shared__ LevelInfo s_lv[N_LEVELS];
+	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, c = lane & 15, h = lane >> 4;
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	for (int p = 0; p < 4; ++p) {
+		uint32_t s = wave * 64u + 16u * p + c;
+		uint32_t sc = s < n ? s : n - 1;
+		half8 enc = encode_level_pair(M.grid, s_lv, h, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		if (s < n) {
+			union { half_t h; uint16_t u; } cv;
+			for (int j = 0; j < 8; ++j) {
+				cv.h = enc[j];
+				out[(size_t)s * 32 + 16 * (j >> 2) + 4 * h + (j & 3)] = cv.u;
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
+	__shared__ uint4 s_w[N_FRAGS * 64];
+	__shared__ LevelInfo s_lv[N_LEVELS];
+	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, c = lane & 15;
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	for (int p = 0; p < 4; ++p) {
+		uint32_t s = wave * 64u + 16u * p + c;
+		uint32_t sc = s < n ? s : n - 1;
+		half8 enc = encode_level_pair(M.grid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		MlpOut mo = mlp_pass(s_w, lane, enc, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]);
+		if (s < n && lane < 16) {
+			union { half_t h; uint16_t u; } cv;
+			cv.h = mo.rgb[0]; out[(size_t)s * 4 + 0] = cv.u;
+			cv.h = mo.rgb[1]; out[(size_t)s * 4 + 1] = cv.u;
+			cv.h = mo.rgb[2]; out[(size_t)s * 4 + 2] = cv.u;
+			cv.h = mo.sigma;  out[(size_t)s * 4 + 3] = cv.u;
+		}
+	}
+}
+
+__global__ void init_rays_kernel(const ModelParams M, const CameraParams C, NerfPayload* __restrict__ payloads) {
+	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x;
+	uint32_t y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= (uint32_t)C.width || y >= (uint32_t)C.height) return;
+	RayState r;
+	init_ray(M, C, x, y, r);
+	advance_pos(M, C, r);
+	NerfPayload p;
+	p.origin[0] = r.o.x; p.origin[1] = r.o.y; p.origin[2] = r.o.z;
+	p.dir[0] = r.d.x; p.dir[1] = r.d.y; p.dir[2] = r.d.z;
+	p.t = r.t;
+	p.max_weight = 0.f;
+	p.idx = r.alive || (r.d.x != 0.f || r.d.y != 0.f || r.d.z != 0.f) ? r.idx : 0u;
+	p.n_steps = 0;
+	p.alive = r.alive ? 1 : 0;
+	p.pad = 0;
+	payloads[x + (uint32_t)C.width * y] = p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K8/K9: update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:284-331, 2863-2877)
+__global__ void half_to_float_kernel(uint32_t n, const uint16_t* __restrict__ in, float* __restrict__ out) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	union { uint16_t u; half_t h; } cv;
+	cv.u = in[i];
+	out[i] = (float)cv.h;
+}
+
+// mean of fmaxf(v,0)/n over level 0; summed in double so that the (unspecified) reduction order cannot change the
+// rounded fp32 result.
+__global__ void density_mean_kernel(uint32_t n, const float* __restrict__ grid, double* __restrict__ partial) {
+	__shared__ double s[256];
+	double acc = 0.0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += (double)(fmaxf(grid[i], 0.0f) / (float)n);
+	s[threadIdx.x] = acc;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ void grid_to_bitfield_kernel(uint32_t n_elements, uint32_t n_nonzero_elements, const float* __restrict__ grid, uint8_t* __restrict__ bitfield, float mean) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	if (i >= n_nonzero_elements) { bitfield[i] = 0; return; }
+	float thresh = fminf(0.01f, mean); // NERF_MIN_OPTICAL_THICKNESS
+	uint8_t bits = 0;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? (uint8_t)(1u << j) : 0;
+	bitfield[i] = bits;
+}
+
+__global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	uint8_t bits = 0;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) bits |= prev_level[(size_t)i * 8 + j] > 0 ? (uint8_t)(1u << j) : 0;
+	uint32_t x = morton3D_invert(i >> 0) + NERF_GRIDSIZE / 8;
+	uint32_t y = morton3D_invert(i >> 1) + NERF_GRIDSIZE / 8;
+	uint32_t z = morton3D_invert(i >> 2) + NERF_GRIDSIZE / 8;
+	next_level[morton3D(x, y, z)] |= bits; // each thread owns a distinct output byte
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// P1: accumulate_kernel + tonemap_kernel (src/render_buffer.cu:228-262, 529-561), fused: colour space Linear,
+// tonemap curve Identity, no DLSS. rgba_out may alias nothing else.
+__global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __restrict__ frame_buffer, float4* __restrict__ accumulate_buffer,
+                                          float sample_count, float4 background, float exposure_scale, int to_srgb, float4* __restrict__ rgba_out) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_pixels) return;
+	float4 color = frame_buffer[i];
+	float4 tmp = sample_count > 0.f ? accumulate_buffer[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+	tmp.x = (tmp.x * sample_count + color.x) / (sample_count + 1.0f);
+	tmp.y = (tmp.y * sample_count + color.y) / (sample_count + 1.0f);
+	tmp.z = (tmp.z * sample_count + color.z) / (sample_count + 1.0f);
+	tmp.w = (tmp.w * sample_count + color.w) / (sample_count + 1.0f);
+	accumulate_buffer[i] = tmp;
+	if (!rgba_out) return;
+	float bgr = srgb_to_linear(background.x), bgg = srgb_to_linear(background.y), bgb = srgb_to_linear(background.z);
+	float weight = (1.0f - tmp.w) * background.w;
+	tmp.x += bgr * weight;
+	tmp.y += bgg * weight;
+	tmp.z += bgb * weight;
+	tmp.w += weight;
+	tmp.x *= exposure_scale;
+	tmp.y *= exposure_scale;
+	tmp.z *= exposure_scale;
+	if (to_srgb) {
+		tmp.x = linear_to_srgb(tmp.x);
+		tmp.y = linear_to_srgb(tmp.y);
+		tmp.z = linear_to_srgb(tmp.z);
+	}
+	rgba_out[i] = tmp;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers (called from ngp_api.cpp)
+void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream) {
+	hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+}
+void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream) {
+	uint32_t n_waves = (n + 63) / 64;
+	hipLaunchKernelGGL(grid_encode_kernel, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, out);
+}
+void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream) {
+	uint32_t n_waves = (n + 63) / 64;
+	hipLaunchKernelGGL(network_inference_kernel, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+}
+void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream) {
+	dim3 threads(16, 8, 1);
+	dim3 blocks((C.width + 15) / 16, (C.height + 7) / 8, 1);
+	hipLaunchKernelGGL(init_rays_kernel, blocks, threads, 0, stream, M, C, payloads);
+}
+void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_grid, uint32_t max_cascade, float* d_grid_f32, double* d_partial /*256*/,
+                                     uint8_t* d_bitfield, float* out_mean, hipStream_t stream) {
+	if (n_grid) hipLaunchKernelGGL(half_to_float_kernel, dim3((n_grid + 255) / 256), dim3(256), 0, stream, n_grid, d_grid_fp16, d_grid_f32);
+	hipLaunchKernelGGL(density_mean_kernel, dim3(256), dim3(256), 0, stream, NERF_GRID_N_CELLS, d_grid_f32, d_partial);
+	double partial[256];
+	(void)hipMemcpyAsync(partial, d_partial, sizeof(partial), hipMemcpyDeviceToHost, stream);
+	(void)hipStreamSynchronize(stream);
+	double sum = 0.0;
+	for (int i = 0; i < 256; ++i) sum += partial[i];
+	float mean = (float)sum;
+	*out_mean = mean;
+	const uint32_t n_elements = NERF_GRID_N_CELLS;
+	uint32_t n_bytes = n_elements / 8 * NERF_CASCADES;
+	hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3((n_bytes + 255) / 256), dim3(256), 0, stream, n_bytes, n_elements / 8 * (max_cascade + 1), d_grid_f32, d_bitfield, mean);
+	for (uint32_t level = 1; level < NERF_CASCADES; ++level) {
+		hipLaunchKernelGGL(bitfield_max_pool_kernel, dim3((n_elements / 64 + 255) / 256), dim3(256), 0, stream, n_elements / 64,
+		                   d_bitfield + (size_t)(level - 1) * (n_elements / 8), d_bitfield + (size_t)level * (n_elements / 8));
+	}
+}
+void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
+                               float exposure, int to_srgb, float4* rgba_out, hipStream_t stream) {
+	float4 bg = make_float4(background[0], background[1], background[2], background[3]);
+	hipLaunchKernelGGL(accumulate_tonemap_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, n_pixels, frame_buffer, accumulate_buffer, sample_count,
+	                   bg, powf(2.0f, exposure), to_srgb, rgba_out);
+}
+
+} // namespace ngp

@@ -1,0 +1,1154 @@
+// C ABI of libngp_hip (include/ngp_hip.h): model upload, snapshot / transforms.json I/O, frame rendering.
+// Host logic only; every device computation lives in nerf_kernels.hip. There is no CPU fallback: each entry point
+// that computes needs a HIP device and fails with an error otherwise.
+#include "ngp_host.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+
+using namespace ngp;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ helpers
+template <typename F>
+int guarded(ngp_ctx* ctx, F&& f) {
+	if (!ctx) return -1;
+	try {
+		NGP_HIP_CHECK(hipSetDevice(ctx->device));
+		f();
+		ctx->error.clear();
+		return 0;
+	} catch (const std::exception& e) {
+		ctx->error = e.what();
+		return -1;
+	}
+}
+
+std::string read_file(const std::string& path) {
+	std::ifstream f(path, std::ios::in | std::ios::binary);
+	if (!f) throw std::runtime_error("cannot open '" + path + "'");
+	std::stringstream ss;
+	ss << f.rdbuf();
+	return ss.str();
+}
+
+bool file_exists(const std::string& p) {
+	struct stat st;
+	return stat(p.c_str(), &st) == 0;
+}
+bool is_directory(const std::string& p) {
+	struct stat st;
+	return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+std::string parent_dir(const std::string& p) {
+	size_t k = p.find_last_of('/');
+	return k == std::string::npos ? std::string(".") : p.substr(0, k);
+}
+bool ends_with_ci(const std::string& s, const std::string& suffix) {
+	if (s.size() < suffix.size()) return false;
+	for (size_t i = 0; i < suffix.size(); ++i)
+		if (tolower(s[s.size() - suffix.size() + i]) != tolower(suffix[i])) return false;
+	return true;
+}
+
+uint16_t float_to_half(float f) { // round to nearest even, for "params_type": "float" snapshots
+	uint32_t x;
+	memcpy(&x, &f, 4);
+	uint32_t sign = (x >> 16) & 0x8000u;
+	int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+	uint32_t man = x & 0x7fffffu;
+	if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+	if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+	if (exp <= 0) {
+		if (exp < -10) return (uint16_t)sign;
+		man |= 0x800000u;
+		uint32_t shift = (uint32_t)(14 - exp);
+		uint32_t half_man = man >> shift;
+		uint32_t rem = man & ((1u << shift) - 1u);
+		uint32_t halfway = 1u << (shift - 1);
+		if (rem > halfway || (rem == halfway && (half_man & 1u))) ++half_man;
+		return (uint16_t)(sign | half_man);
+	}
+	uint32_t half = (uint32_t)(exp << 10) | (man >> 13);
+	uint32_t rem = man & 0x1fffu;
+	if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;
+	return (uint16_t)(sign | half);
+}
+
+std::string inflate_all(const void* data, size_t n) { // zlib or gzip container (zstr, src/testbed.cu:262-266)
+	z_stream zs;
+	memset(&zs, 0, sizeof(zs));
+	if (inflateInit2(&zs, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+	zs.next_in = (Bytef*)data;
+	zs.avail_in = (uInt)n;
+	std::string out;
+	std::vector<char> buf(1 << 20);
+	int rc;
+	do {
+		zs.next_out = (Bytef*)buf.data();
+		zs.avail_out = (uInt)buf.size();
+		rc = inflate(&zs, Z_NO_FLUSH);
+		if (rc != Z_OK && rc != Z_STREAM_END) {
+			inflateEnd(&zs);
+			throw std::runtime_error("inflate failed: corrupt .ingp stream");
+		}
+		out.append(buf.data(), buf.size() - zs.avail_out);
+	} while (rc != Z_STREAM_END);
+	inflateEnd(&zs);
+	return out;
+}
+
+std::string deflate_gzip(const std::string& in, int level) {
+	z_stream zs;
+	memset(&zs, 0, sizeof(zs));
+	if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+	zs.next_in = (Bytef*)in.data();
+	zs.avail_in = (uInt)in.size();
+	std::string out;
+	std::vector<char> buf(1 << 20);
+	int rc;
+	do {
+		zs.next_out = (Bytef*)buf.data();
+		zs.avail_out = (uInt)buf.size();
+		rc = deflate(&zs, Z_FINISH);
+		out.append(buf.data(), buf.size() - zs.avail_out);
+	} while (rc != Z_STREAM_END);
+	deflateEnd(&zs);
+	return out;
+}
+
+// ------------------------------------------------------------------------------------------------ sampling (host)
+// ld_random_pixel_offset (random_val.cuh:365-370) is a per-frame constant, so it is evaluated once on the host.
+// Sobol dimensions 0 and 1 need no table: dim 0 is a bit reversal, dim 1's direction numbers obey v[i] = v[i-1] ^ (v[i-1] >> 1).
+uint32_t reverse_bits32(uint32_t x) {
+	x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+	x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+	x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+	x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+	return (x >> 16) | (x << 16);
+}
+uint32_t lk_perm(uint32_t x, uint32_t seed) {
+	x += seed;
+	x ^= x * 0x6c50b47cu;
+	x ^= x * 0xb82f1e52u;
+	x ^= x * 0xc7afe638u;
+	x ^= x * 0x8d22f6e6u;
+	return x;
+}
+uint32_t nus2(uint32_t x, uint32_t seed) { return reverse_bits32(lk_perm(reverse_bits32(x), seed)); }
+uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+uint32_t sobol_dim(uint32_t index, int dim) {
+	if (dim == 0) return reverse_bits32(index);
+	uint32_t v = 0x80000000u, X = 0;
+	for (int bit = 0; bit < 32; ++bit) {
+		if ((index >> bit) & 1u) X ^= v;
+		v ^= v >> 1;
+	}
+	return X;
+}
+void ld_random_val_2d(uint32_t index, uint32_t seed, float* out) {
+	index = nus2(index, seed);
+	for (int i = 0; i < 2; ++i) out[i] = (float)nus2(sobol_dim(index, i), hash_combine(seed, (uint32_t)i)) * 2.3283064365386963e-10f;
+}
+void ld_random_pixel_offset(uint32_t spp, float* out) {
+	float a[2], b[2];
+	ld_random_val_2d(0, 0xdeadbeefu, a);
+	ld_random_val_2d(spp, 0xdeadbeefu, b);
+	for (int i = 0; i < 2; ++i) {
+		float v = (0.5f - a[i]) + b[i];
+		out[i] = v - floorf(v);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ model
+uint32_t next_multiple(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
+
+// tcnn GridEncoding level table
+void build_levels(const ngp_model_desc& d, LevelInfo* lv, uint32_t* total_entries) {
+	float log2_pls = log2f(d.per_level_scale);
+	uint32_t offset = 0;
+	for (uint32_t l = 0; l < d.n_levels; ++l) {
+		float scale = exp2f((float)l * log2_pls) * (float)d.base_resolution - 1.0f;
+		uint32_t res = (uint32_t)ceilf(scale) + 1u;
+		uint32_t max_params = 0xFFFFFFFFu / 2u;
+		uint32_t n = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+		n = next_multiple(n, 8u);
+		n = std::min(n, 1u << d.log2_hashmap_size);
+		// grid_index: strides accumulate while stride <= size; hashed iff the final stride exceeds the level size
+		uint32_t stride = 1;
+		for (int dim = 0; dim < 3 && stride <= n; ++dim) stride *= res;
+		lv[l].scale = scale;
+		lv[l].res = res;
+		lv[l].size = n;
+		lv[l].offset = offset;
+		lv[l].hashed = n < stride ? 1u : 0u;
+		lv[l].mask = (n & (n - 1)) == 0 ? n - 1 : 0u;
+		lv[l].pad0 = lv[l].pad1 = 0;
+		offset += n;
+	}
+	*total_entries = offset;
+}
+
+uint64_t mlp_n_params(uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out) {
+	return (uint64_t)width * n_in + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)n_out * width;
+}
+
+// MFMA A-operand fragments for v_mfma_f32_16x16x32_f16: fragment (tile m, k-step s) holds, in lane l = (h = l>>4,
+// row = l&15), element j: W[16m + row][n(s,h,j)], n(s,h,j) = 32s + 16(j>>2) + 4h + (j&3). The K permutation n() is
+// the order in which the previous layer's accumulator tiles (and the encoder's level pairs) already sit in the
+// B operand's registers, so no activation ever moves between lanes (nerf_device.h mlp_pass).
+void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t* W, int n_out, int n_in) {
+	int f = first_frag;
+	for (int m = 0; m < n_out / 16; ++m) {
+		for (int s = 0; s < n_in / 32; ++s, ++f) {
+			for (int l = 0; l < 64; ++l) {
+				int h = l >> 4, row = l & 15;
+				for (int j = 0; j < 8; ++j) {
+					int k = 32 * s + 16 * (j >> 2) + 4 * h + (j & 3);
+					frags[((size_t)f * 64 + l) * 8 + j] = W[(size_t)(16 * m + row) * n_in + k];
+				}
+			}
+		}
+	}
+}
+
+void free_model(ngp_ctx* ctx) {
+	if (ctx->d_params) (void)hipFree(ctx->d_params);
+	if (ctx->d_wfrags) (void)hipFree(ctx->d_wfrags);
+	if (ctx->d_bitfield) (void)hipFree(ctx->d_bitfield);
+	if (ctx->d_density_f16) (void)hipFree(ctx->d_density_f16);
+	if (ctx->d_density_f32) (void)hipFree(ctx->d_density_f32);
+	if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+	ctx->d_params = nullptr;
+	ctx->d_wfrags = nullptr;
+	ctx->d_bitfield = nullptr;
+	ctx->d_density_f16 = nullptr;
+	ctx->d_density_f32 = nullptr;
+	ctx->d_partial = nullptr;
+	ctx->model_loaded = false;
+}
+
+void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
+	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density != 1 ||
+	    d.n_hidden_rgb != 2 || d.density_out_dims != 16) {
+		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json "
+		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64x2 hidden)");
+	}
+	if (d.log2_hashmap_size > 28 || d.base_resolution == 0 || !(d.per_level_scale > 0.f)) throw std::runtime_error("invalid hash grid configuration");
+	if (d.aabb_scale == 0 || (d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error("NeRF dataset's `aabb_scale` must be a power of two"); // testbed_nerf.cu:2707
+	if (d.aabb_scale > (1u << (NERF_CASCADES - 1))) throw std::runtime_error("NeRF dataset must have `aabb_scale <= 128`"); // :2711-2718
+
+	ModelParams M{};
+	uint32_t total_entries = 0;
+	build_levels(d, M.levels, &total_entries);
+	const uint32_t enc_dims = d.n_levels * d.n_features_per_level;
+	const uint64_t nd = mlp_n_params(enc_dims, d.n_neurons, d.n_hidden_density, d.density_out_dims);
+	const uint64_t nr = mlp_n_params(d.density_out_dims + 16u, d.n_neurons, d.n_hidden_rgb, 16u);
+	const uint64_t ng = (uint64_t)total_entries * d.n_features_per_level;
+	if (d.n_params != nd + nr + ng || !d.params_fp16) {
+		throw std::runtime_error("parameter count mismatch: snapshot has " + std::to_string(d.n_params) + ", network needs " + std::to_string(nd + nr + ng));
+	}
+	uint32_t max_cascade = 0;
+	while ((1u << max_cascade) < d.aabb_scale) ++max_cascade; // testbed_nerf.cu:2729-2732
+	const uint64_t n_grid_expected = (uint64_t)NERF_GRID_N_CELLS * (max_cascade + 1);
+	if (d.n_density_grid != 0 && d.n_density_grid != n_grid_expected) throw std::runtime_error("Incompatible number of grid cascades."); // testbed.cu:5350
+
+	free_model(ctx);
+	ctx->params.assign(d.params_fp16, d.params_fp16 + d.n_params);
+	ctx->density_grid.assign(d.density_grid_fp16, d.density_grid_fp16 + d.n_density_grid);
+	ctx->desc = d;
+	ctx->desc.params_fp16 = nullptr;
+	ctx->desc.density_grid_fp16 = nullptr;
+	ctx->max_cascade = max_cascade;
+
+	// grid table
+	NGP_HIP_CHECK(hipMalloc(&ctx->d_params, ng * sizeof(uint16_t)));
+	NGP_HIP_CHECK(hipMemcpy(ctx->d_params, ctx->params.data() + nd + nr, ng * sizeof(uint16_t), hipMemcpyHostToDevice));
+	// weight fragments
+	std::vector<uint16_t> frags((size_t)N_FRAGS * 64 * 8);
+	const uint16_t* W = ctx->params.data();
+	emit_fragments(frags, FRAG_D0, W, 64, 32);
+	emit_fragments(frags, FRAG_D1, W + 64 * 32, 16, 64);
+	const uint16_t* R = W + nd;
+	emit_fragments(frags, FRAG_R0, R, 64, 32);
+	emit_fragments(frags, FRAG_R1, R + 64 * 32, 64, 64);
+	emit_fragments(frags, FRAG_R2, R + 64 * 32 + 64 * 64, 16, 64);
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
+	NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	// occupancy: fp16 grid -> fp32 -> bitfield + mips on the device (K8/K9)
+	const size_t bitfield_bytes = (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES;
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_bitfield, bitfield_bytes));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_f32, n_grid_expected * sizeof(float)));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_partial, 256 * sizeof(double)));
+	if (d.n_density_grid) {
+		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_f16, d.n_density_grid * sizeof(uint16_t)));
+		NGP_HIP_CHECK(hipMemcpy(ctx->d_density_f16, ctx->density_grid.data(), d.n_density_grid * sizeof(uint16_t), hipMemcpyHostToDevice));
+	} else {
+		// a snapshot whose grid was never populated renders as empty space (testbed.cu:5348-5351)
+		NGP_HIP_CHECK(hipMemset(ctx->d_density_f32, 0, n_grid_expected * sizeof(float)));
+	}
+	launch_density_grid_to_bitfield(ctx->d_density_f16, (uint32_t)d.n_density_grid, max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield,
+	                                &ctx->bitfield_mean, ctx->stream);
+	NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	NGP_HIP_CHECK(hipGetLastError());
+
+	M.grid = (const uint2*)ctx->d_params;
+	M.wfrags = ctx->d_wfrags;
+	M.bitfield = ctx->d_bitfield;
+	for (int i = 0; i < 3; ++i) {
+		M.aabb_min[i] = d.aabb_min[i];
+		M.aabb_diag[i] = d.aabb_max[i] - d.aabb_min[i];
+		M.raabb_min[i] = d.render_aabb_min[i];
+		M.raabb_max[i] = d.render_aabb_max[i];
+	}
+	for (int i = 0; i < 9; ++i) M.r2l[i] = d.render_aabb_to_local[i];
+	M.max_cascade = max_cascade;
+	M.cone_angle = d.cone_angle_constant;
+	M.rgb_act = d.rgb_activation;
+	M.density_act = d.density_activation;
+	ctx->M = M;
+	ctx->model_loaded = true;
+}
+
+// ------------------------------------------------------------------------------------------------ snapshot
+void read_vec(const mj::Value& v, float* out, size_t n) {
+	if (!v.is_array() || v.size() != n) throw std::runtime_error("snapshot: vector of unexpected size");
+	for (size_t i = 0; i < n; ++i) out[i] = (float)v.at(i).num();
+}
+// tcnn vec_json.h: a tmat<T,N,M> is an array of M rows with N entries each; storage is column-major
+void read_mat(const mj::Value& v, float* out, int n_cols, int n_rows) {
+	if (!v.is_array() || (int)v.size() != n_rows) throw std::runtime_error("snapshot: matrix of unexpected size");
+	for (int r = 0; r < n_rows; ++r) {
+		const mj::Value& row = v.at((size_t)r);
+		if (!row.is_array() || (int)row.size() != n_cols) throw std::runtime_error("snapshot: matrix of unexpected size");
+		for (int c = 0; c < n_cols; ++c) out[c * n_rows + r] = (float)row.at((size_t)c).num();
+	}
+}
+mj::Value write_vec(const float* v, size_t n) {
+	mj::Value a = mj::Value::make_array();
+	for (size_t i = 0; i < n; ++i) a.push(mj::Value::make_float(v[i]));
+	return a;
+}
+mj::Value write_mat(const float* m, int n_cols, int n_rows) {
+	mj::Value a = mj::Value::make_array();
+	for (int r = 0; r < n_rows; ++r) {
+		mj::Value row = mj::Value::make_array();
+		for (int c = 0; c < n_cols; ++c) row.push(mj::Value::make_float(m[c * n_rows + r]));
+		a.push(std::move(row));
+	}
+	return a;
+}
+
+void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-183
+	size_t n = (size_t)j.at("n_images").integer();
+	ds.views.assign(n, TrainingView{});
+	for (size_t i = 0; i < n; ++i) {
+		TrainingView& v = ds.views[i];
+		v.principal_point[0] = v.principal_point[1] = 0.5f;
+		v.focal_length[0] = v.focal_length[1] = 1000.f;
+		v.resolution[0] = v.resolution[1] = 0;
+		if (j.contains("principal_point")) read_vec(j.at("principal_point"), v.principal_point, 2);
+		if (j.contains("focal_length")) read_vec(j.at("focal_length"), v.focal_length, 2);
+		if (j.contains("image_resolution")) { float r[2]; read_vec(j.at("image_resolution"), r, 2); v.resolution[0] = (int)r[0]; v.resolution[1] = (int)r[1]; }
+		read_mat(j.at("xforms").at(i).at("start"), v.xform.data(), 4, 3);
+		if (j.contains("metadata")) {
+			const mj::Value& ji = j.at("metadata").at(i);
+			float r[2];
+			read_vec(ji.at("resolution"), r, 2);
+			v.resolution[0] = (int)r[0];
+			v.resolution[1] = (int)r[1];
+			read_vec(ji.at("focal_length"), v.focal_length, 2);
+			read_vec(ji.at("principal_point"), v.principal_point, 2);
+		}
+		if (j.contains("paths") && i < j.at("paths").size()) v.path = j.at("paths").at(i).str();
+	}
+	const mj::Value& ra = j.at("render_aabb");
+	read_vec(ra.at("min"), ds.render_aabb_min, 3);
+	read_vec(ra.at("max"), ds.render_aabb_max, 3);
+	ds.has_render_aabb = true;
+	if (j.contains("render_aabb_to_local")) read_mat(j.at("render_aabb_to_local"), ds.render_aabb_to_local, 3, 3);
+	read_vec(j.at("up"), ds.up, 3);
+	read_vec(j.at("offset"), ds.offset, 3);
+	ds.scale = (float)j.at("scale").num();
+	ds.aabb_scale = (int)j.at("aabb_scale").integer();
+	ds.from_mitsuba = j.at("from_mitsuba").boolean();
+	ds.is_hdr = j.value("is_hdr", false);
+	ds.n_extra_learnable_dims = (int)j.value("n_extra_learnable_dims", 0.0);
+}
+
+mj::Value dataset_to_json(const Dataset& ds) { // json_binding.h:94-119
+	mj::Value j = mj::Value::make_object();
+	j["n_images"] = mj::Value::make_uint(ds.views.size());
+	mj::Value paths = mj::Value::make_array(), metadata = mj::Value::make_array(), xforms = mj::Value::make_array();
+	for (auto& v : ds.views) {
+		paths.push(mj::Value::make_string(v.path));
+		mj::Value m = mj::Value::make_object();
+		m["focal_length"] = write_vec(v.focal_length, 2);
+		m["lens"] = mj::Value::make_object();
+		m["principal_point"] = write_vec(v.principal_point, 2);
+		float rs[4] = {0, 0, 0, 0};
+		m["rolling_shutter"] = write_vec(rs, 4);
+		mj::Value res = mj::Value::make_array();
+		res.push(mj::Value::make_int(v.resolution[0]));
+		res.push(mj::Value::make_int(v.resolution[1]));
+		m["resolution"] = res;
+		metadata.push(std::move(m));
+		mj::Value x = mj::Value::make_object();
+		x["start"] = write_mat(v.xform.data(), 4, 3);
+		x["end"] = write_mat(v.xform.data(), 4, 3);
+		xforms.push(std::move(x));
+	}
+	j["paths"] = paths;
+	j["metadata"] = metadata;
+	j["xforms"] = xforms;
+	mj::Value ra = mj::Value::make_object();
+	ra["min"] = write_vec(ds.render_aabb_min, 3);
+	ra["max"] = write_vec(ds.render_aabb_max, 3);
+	j["render_aabb"] = ra;
+	j["render_aabb_to_local"] = write_mat(ds.render_aabb_to_local, 3, 3);
+	j["up"] = write_vec(ds.up, 3);
+	j["offset"] = write_vec(ds.offset, 3);
+	mj::Value er = mj::Value::make_array();
+	er.push(mj::Value::make_int(0));
+	er.push(mj::Value::make_int(0));
+	j["envmap_resolution"] = er;
+	j["scale"] = mj::Value::make_float(ds.scale);
+	j["aabb_scale"] = mj::Value::make_int(ds.aabb_scale);
+	j["from_mitsuba"] = mj::Value::make_bool(ds.from_mitsuba);
+	j["is_hdr"] = mj::Value::make_bool(ds.is_hdr);
+	j["wants_importance_sampling"] = mj::Value::make_bool(true);
+	j["n_extra_learnable_dims"] = mj::Value::make_int(ds.n_extra_learnable_dims);
+	return j;
+}
+
+// Testbed::load_snapshot(nlohmann::json) (src/testbed.cu:5285-5463), Nerf mode, inference-relevant state
+void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
+	if (!root.contains("snapshot")) throw std::runtime_error("File does not contain a snapshot.");
+	const mj::Value& snap = root.at("snapshot");
+	if (snap.value("version", 0.0) < 1.0) throw std::runtime_error("Snapshot uses an old format and can not be loaded.");
+	std::string mode = snap.value("mode", snap.contains("nerf") ? "nerf" : "none");
+	for (auto& ch : mode) ch = (char)tolower(ch);
+	if (mode != "nerf") throw std::runtime_error("Only NeRF snapshots are supported by this renderer (snapshot mode: " + mode + ").");
+	if (snap.at("density_grid_size").integer() != (int64_t)NERF_GRIDSIZE) throw std::runtime_error("Incompatible grid size.");
+
+	ngp_model_desc d{};
+	const mj::Value& enc = root.at("encoding");
+	const mj::Value& net = root.at("network");
+	const mj::Value& rgb = root.at("rgb_network");
+	std::string otype = enc.value("otype", "OneBlob");
+	for (auto& ch : otype) ch = (char)tolower(ch);
+	if (otype.find("grid") == std::string::npos) throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid only)");
+	d.n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2.0);
+	d.n_levels = enc.contains("n_features") && enc.at("n_features").num() > 0 ? (uint32_t)enc.at("n_features").num() / d.n_features_per_level
+	                                                                           : (uint32_t)enc.value("n_levels", 16.0);
+	d.log2_hashmap_size = (uint32_t)enc.value("log2_hashmap_size", 15.0);
+	d.base_resolution = (uint32_t)enc.value("base_resolution", 0.0);
+	if (!d.base_resolution) d.base_resolution = 1u << (d.log2_hashmap_size / 3); // testbed.cu:3945-3949
+
+	const mj::Value& nerf = snap.at("nerf");
+	Dataset ds;
+	if (nerf.contains("dataset")) dataset_from_json(nerf.at("dataset"), ds);
+	if (nerf.contains("aabb_scale")) ds.aabb_scale = (int)nerf.at("aabb_scale").integer();
+	d.aabb_scale = (uint32_t)ds.aabb_scale;
+
+	d.per_level_scale = (float)enc.value("per_level_scale", 0.0);
+	if (!(d.per_level_scale > 0.0f) && d.n_levels > 1) {
+		// The fork derives it from m_geometry.nerf...aabb_scale, which is 1 in Nerf mode (testbed.cu:3959-3966).
+		d.per_level_scale = std::exp(std::log(2048.0f * 1.0f / (float)d.base_resolution) / (float)(d.n_levels - 1));
+	}
+	auto fully_fused = [](const mj::Value& n) {
+		std::string t = n.value("otype", "FullyFusedMLP");
+		for (auto& ch : t) ch = (char)tolower(ch);
+		return t == "fullyfusedmlp" || t == "megakernelmlp" || t == "cutlassmlp";
+	};
+	if (!fully_fused(net) || !fully_fused(rgb)) throw std::runtime_error("unsupported network otype");
+	d.n_neurons = (uint32_t)net.at("n_neurons").integer();
+	if ((uint32_t)rgb.at("n_neurons").integer() != d.n_neurons) throw std::runtime_error("density and rgb networks must have the same width");
+	d.n_hidden_density = (uint32_t)net.at("n_hidden_layers").integer();
+	d.n_hidden_rgb = (uint32_t)rgb.at("n_hidden_layers").integer();
+	d.density_out_dims = (uint32_t)net.value("n_output_dims", 16.0);
+	d.rgb_activation = ds.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC; // testbed_nerf.cu:2653
+	d.density_activation = NGP_ACT_EXPONENTIAL;                           // nerf.h:151-152
+
+	// m_aabb / m_render_aabb: load_nerf_post (testbed_nerf.cu:2720-2727), then the snapshot's own values (testbed.cu:5309,5422-5423)
+	float half = 0.5f * (float)std::min<int>(1 << (NERF_CASCADES - 1), ds.aabb_scale);
+	for (int i = 0; i < 3; ++i) {
+		d.aabb_min[i] = 0.5f - half;
+		d.aabb_max[i] = 0.5f + half;
+		d.render_aabb_min[i] = d.aabb_min[i];
+		d.render_aabb_max[i] = d.aabb_max[i];
+	}
+	for (int i = 0; i < 9; ++i) d.render_aabb_to_local[i] = ds.render_aabb_to_local[i];
+	if (snap.contains("aabb")) {
+		read_vec(snap.at("aabb").at("min"), d.aabb_min, 3);
+		read_vec(snap.at("aabb").at("max"), d.aabb_max, 3);
+	}
+	if (snap.contains("render_aabb")) {
+		read_vec(snap.at("render_aabb").at("min"), d.render_aabb_min, 3);
+		read_vec(snap.at("render_aabb").at("max"), d.render_aabb_max, 3);
+	}
+	if (snap.contains("render_aabb_to_local")) read_mat(snap.at("render_aabb_to_local"), d.render_aabb_to_local, 3, 3);
+	d.cone_angle_constant = ds.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f); // testbed_nerf.cu:2736
+	d.linear_colors = 0;
+
+	// Trainer::deserialize: params_binary (__half or float)
+	const mj::Value& pb = snap.at("params_binary");
+	if (pb.type != mj::Value::Binary) throw std::runtime_error("snapshot: params_binary is not binary");
+	std::string ptype = snap.value("params_type", "__half");
+	std::vector<uint16_t> params;
+	if (ptype == "float") {
+		size_t n = pb.s.size() / 4;
+		params.resize(n);
+		const float* src = (const float*)pb.s.data();
+		for (size_t i = 0; i < n; ++i) params[i] = float_to_half(src[i]);
+	} else {
+		params.resize(pb.s.size() / 2);
+		memcpy(params.data(), pb.s.data(), params.size() * 2);
+	}
+	if (snap.contains("n_params") && (uint64_t)snap.at("n_params").integer() != params.size()) throw std::runtime_error("snapshot: n_params does not match params_binary");
+	d.params_fp16 = params.data();
+	d.n_params = params.size();
+	const mj::Value& gb = snap.at("density_grid_binary");
+	if (gb.type != mj::Value::Binary) throw std::runtime_error("snapshot: density_grid_binary is not binary");
+	d.density_grid_fp16 = (const uint16_t*)gb.s.data();
+	d.n_density_grid = gb.s.size() / 2;
+
+	set_model_impl(ctx, d);
+
+	ctx->dataset = ds;
+	ctx->has_snapshot_camera = false;
+	if (snap.contains("camera")) {
+		const mj::Value& cam = snap.at("camera");
+		if (cam.contains("matrix")) {
+			read_mat(cam.at("matrix"), ctx->snap_camera, 4, 3);
+			ctx->has_snapshot_camera = true;
+		}
+		ctx->snap_fov_axis = (int32_t)cam.value("fov_axis", 1.0);
+		if (cam.contains("relative_focal_length")) read_vec(cam.at("relative_focal_length"), ctx->snap_relative_focal_length, 2);
+		if (cam.contains("screen_center")) read_vec(cam.at("screen_center"), ctx->snap_screen_center, 2);
+		ctx->snap_zoom = (float)cam.value("zoom", 1.0);
+	}
+	// keep the network config (without the heavy binaries) for save_snapshot
+	mj::Value cfg = mj::Value::make_object();
+	for (auto& kv : root.obj)
+		if (kv.first != "snapshot") cfg.set(kv.first, kv.second);
+	ctx->config = std::move(cfg);
+}
+
+// ------------------------------------------------------------------------------------------------ transforms.json
+// SI::natural::compare (dependencies/NaturalSort): digit runs compare by value
+bool natural_less(const std::string& a, const std::string& b) {
+	size_t i = 0, j = 0;
+	while (i < a.size() && j < b.size()) {
+		if (isdigit((unsigned char)a[i]) && isdigit((unsigned char)b[j])) {
+			size_t i0 = i, j0 = j;
+			while (i0 < a.size() && a[i0] == '0') ++i0;
+			while (j0 < b.size() && b[j0] == '0') ++j0;
+			size_t i1 = i0, j1 = j0;
+			while (i1 < a.size() && isdigit((unsigned char)a[i1])) ++i1;
+			while (j1 < b.size() && isdigit((unsigned char)b[j1])) ++j1;
+			if (i1 - i0 != j1 - j0) return (i1 - i0) < (j1 - j0);
+			int c = a.compare(i0, i1 - i0, b, j0, j1 - j0);
+			if (c != 0) return c < 0;
+			i = i1;
+			j = j1;
+		} else {
+			if (a[i] != b[j]) return a[i] < b[j];
+			++i;
+			++j;
+		}
+	}
+	return a.size() - i < b.size() - j;
+}
+
+float fov_to_focal_length(int resolution, float degrees) { return 0.5f * (float)resolution / tanf(0.5f * degrees * 3.14159265358979323846f / 180.0f); }
+
+bool read_focal_length(const mj::Value& json, float* fl, const int* res) { // nerf_loader.cu:243-271
+	auto read = [&](int resolution, const std::string& axis) -> float {
+		if (json.contains(axis + "_fov")) return fov_to_focal_length(resolution, (float)json.at(axis + "_fov").num());
+		if (json.contains("fl_" + axis)) return (float)json.at("fl_" + axis).num();
+		if (json.contains("camera_angle_" + axis)) return fov_to_focal_length(resolution, (float)json.at("camera_angle_" + axis).num() * 180 / 3.14159265358979323846f);
+		return 0.0f;
+	};
+	float x_fl = read(res[0], "x"), y_fl = read(res[1], "y");
+	if (x_fl != 0) {
+		fl[0] = fl[1] = x_fl;
+		if (y_fl != 0) fl[1] = y_fl;
+	} else if (y_fl != 0) {
+		fl[0] = fl[1] = y_fl;
+	} else {
+		return false;
+	}
+	return true;
+}
+
+// NerfDataset::nerf_matrix_to_ngp (nerf_loader.h:101-120); m column-major 4x3 in place
+void nerf_matrix_to_ngp(const Dataset& ds, float* m) {
+	for (int r = 0; r < 3; ++r) {
+		m[3 + r] *= -1.f;
+		m[6 + r] *= -1.f;
+		m[9 + r] = m[9 + r] * ds.scale + ds.offset[r];
+	}
+	if (ds.from_mitsuba) {
+		for (int r = 0; r < 3; ++r) { m[0 + r] *= -1.f; m[6 + r] *= -1.f; }
+	} else {
+		for (int c = 0; c < 4; ++c) { // cycle rows xyz <- yzx
+			float t = m[c * 3 + 0];
+			m[c * 3 + 0] = m[c * 3 + 1];
+			m[c * 3 + 1] = m[c * 3 + 2];
+			m[c * 3 + 2] = t;
+		}
+	}
+}
+
+// ngp::load_nerf (src/nerf_loader.cu:273-743), camera metadata only: images are not decoded on the inference path,
+// so per-view resolution comes from the json's "w"/"h".
+void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
+	std::vector<std::string> json_paths;
+	if (is_directory(path)) {
+		DIR* dir = opendir(path.c_str());
+		if (!dir) throw std::runtime_error("cannot open directory '" + path + "'");
+		while (dirent* e = readdir(dir)) {
+			std::string name = e->d_name;
+			if (ends_with_ci(name, ".json")) json_paths.push_back(path + "/" + name);
+		}
+		closedir(dir);
+		std::sort(json_paths.begin(), json_paths.end());
+	} else if (ends_with_ci(path, ".json")) {
+		json_paths.push_back(path);
+	} else {
+		throw std::runtime_error("NeRF data path must either be a json file or a directory containing json files.");
+	}
+	if (json_paths.empty()) throw std::runtime_error("Cannot load NeRF data from an empty set of paths.");
+
+	Dataset ds;
+	ds.scale = 0.33f; // NERF_SCALE, nerf_loader.h:29
+	ds.offset[0] = ds.offset[1] = ds.offset[2] = 0.5f;
+	for (const std::string& jp : json_paths) {
+		mj::Value json = mj::parse_json(read_file(jp));
+		if (!json.contains("frames") || !json.at("frames").is_array()) continue;
+		const std::string base = parent_dir(jp);
+		std::vector<mj::Value> frames = json.at("frames").arr;
+		std::stable_sort(frames.begin(), frames.end(), [](const mj::Value& a, const mj::Value& b) { return natural_less(a.at("file_path").str(), b.at("file_path").str()); });
+		if (json.contains("n_frames")) frames.resize(std::min(frames.size(), (size_t)json.at("n_frames").integer()));
+		auto resolve = [&](const std::string& local) {
+			std::string p = (!local.empty() && local[0] == '/') ? local : base + "/" + local;
+			if (p.find_last_of('.') == std::string::npos || p.find_last_of('.') < p.find_last_of('/')) {
+				for (const char* ext : {"png", "jpg", "jpeg", "bmp", "gif", "tga", "pic", "pnm", "psd", "exr"})
+					if (file_exists(p + "." + ext)) return p + "." + ext;
+			}
+			return p;
+		};
+		if (!frames.empty() && frames[0].contains("sharpness")) { // blurry / missing frames are dropped, nerf_loader.cu:364-388
+			float thresh = (float)json.value("sharpness_discard_threshold", 0.0);
+			std::vector<mj::Value> kept;
+			for (int i = 0; i < (int)frames.size(); ++i) {
+				float mean = 0.f;
+				int s = std::max(0, i - 3), e = std::min(i + 3, (int)frames.size() - 1);
+				for (int j = s; j < e; ++j) mean += (float)frames[j].value("sharpness", 1.0);
+				mean /= (float)(e - s);
+				if (file_exists(resolve(frames[i].at("file_path").str())) && (float)frames[i].value("sharpness", 1.0) > thresh * mean) kept.push_back(frames[i]);
+			}
+			frames.swap(kept);
+		}
+		if (json.contains("normal_mts_args")) ds.from_mitsuba = true;
+		if (ds.from_mitsuba) { ds.scale = 0.66f; ds.offset[0] = ds.offset[1] = ds.offset[2] = 0.25f * ds.scale; }
+		if (json.contains("render_aabb")) {
+			read_vec(json.at("render_aabb").at(0), ds.render_aabb_min, 3);
+			read_vec(json.at("render_aabb").at(1), ds.render_aabb_max, 3);
+			ds.has_render_aabb = true;
+		}
+		if (json.contains("scale")) ds.scale = (float)json.at("scale").num();
+		if (json.contains("n_extra_learnable_dims")) ds.n_extra_learnable_dims = (int)json.at("n_extra_learnable_dims").integer();
+		if (json.contains("aabb_scale")) ds.aabb_scale = (int)json.at("aabb_scale").integer();
+		if (json.contains("offset")) {
+			const mj::Value& o = json.at("offset");
+			if (o.is_array()) read_vec(o, ds.offset, 3);
+			else ds.offset[0] = ds.offset[1] = ds.offset[2] = (float)o.num();
+		}
+		if (json.contains("aabb")) { // nerf_loader.cu:503-509
+			const mj::Value& a = json.at("aabb");
+			float lo[3], hi[3];
+			read_vec(a.at(0), lo, 3);
+			read_vec(a.at(1), hi, 3);
+			float len = std::max(0.000001f, std::max(std::max(std::abs(hi[0] - lo[0]), std::abs(hi[1] - lo[1])), std::abs(hi[2] - lo[2])));
+			ds.scale = 1.f / len;
+			for (int i = 0; i < 3; ++i) ds.offset[i] = ((hi[i] + lo[i]) * 0.5f) * -ds.scale + 0.5f;
+		}
+		if (json.contains("up")) {
+			ds.up[0] = (float)json.at("up").at(1).num();
+			ds.up[1] = (float)json.at("up").at(2).num();
+			ds.up[2] = (float)json.at("up").at(0).num();
+		}
+		float pp[2] = {0.5f, 0.5f};
+		auto read_pp = [](const mj::Value& j, float* pp) {
+			if (j.contains("cx")) pp[0] = (float)j.at("cx").num() / (float)j.at("w").num();
+			if (j.contains("cy")) pp[1] = (float)j.at("cy").num() / (float)j.at("h").num();
+		};
+		read_pp(json, pp);
+		for (const mj::Value& frame : frames) {
+			TrainingView v;
+			v.path = frame.at("file_path").str();
+			std::replace(v.path.begin(), v.path.end(), '\\', '/');
+			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
+			v.resolution[1] = (int)(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
+			if (v.resolution[0] <= 0 || v.resolution[1] <= 0) throw std::runtime_error("transforms.json must provide 'w' and 'h' (images are not decoded on the inference path)");
+			v.focal_length[0] = v.focal_length[1] = 1000.f;
+			bool got = read_focal_length(json, v.focal_length, v.resolution);
+			got |= read_focal_length(frame, v.focal_length, v.resolution);
+			if (!got) throw std::runtime_error("Couldn't read fov.");
+			const mj::Value& mat = frame.contains("transform_matrix_start") ? frame.at("transform_matrix_start") : frame.at("transform_matrix");
+			for (int m = 0; m < 3; ++m)
+				for (int n = 0; n < 4; ++n) v.xform[(size_t)n * 3 + m] = (float)mat.at((size_t)m).at((size_t)n).num();
+			v.principal_point[0] = pp[0];
+			v.principal_point[1] = pp[1];
+			read_pp(frame, v.principal_point);
+			nerf_matrix_to_ngp(ds, v.xform.data());
+			ds.views.push_back(std::move(v));
+		}
+	}
+	ctx->dataset = std::move(ds);
+	ctx->data_path = path;
+}
+
+// ------------------------------------------------------------------------------------------------ frame
+void ensure_frame_buffers(ngp_ctx* ctx, size_t n_pixels) {
+	if (!ctx->d_sync) {
+		NGP_HIP_CHECK(hipMalloc(&ctx->d_sync, 64 + 32 * ngp_ctx::HISTORY));
+		for (int i = 0; i < ngp_ctx::HISTORY; ++i) {
+			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_frame0[i]));
+			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_frame1[i]));
+			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_kern0[i]));
+			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_kern1[i]));
+		}
+	}
+	if (n_pixels <= ctx->n_pixels_alloc) return;
+	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+	if (ctx->d_depth) (void)hipFree(ctx->d_depth);
+	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+	if (ctx->d_rgba) (void)hipFree(ctx->d_rgba);
+	ctx->n_pixels_alloc = 0;
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_frame, n_pixels * sizeof(float4)));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_depth, n_pixels * sizeof(float)));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_accum, n_pixels * sizeof(float4)));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_rgba, n_pixels * sizeof(float4)));
+	ctx->n_pixels_alloc = n_pixels;
+}
+
+CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
+	CameraParams C{};
+	memcpy(C.m, cam.matrix, sizeof(C.m));
+	C.width = cam.width;
+	C.height = cam.height;
+	C.focal[0] = cam.focal_length[0];
+	C.focal[1] = cam.focal_length[1];
+	C.screen_center[0] = cam.screen_center[0];
+	C.screen_center[1] = cam.screen_center[1];
+	C.spp = spp_index;
+	C.near_distance = cam.near_distance;
+	ld_random_pixel_offset(cam.snap_to_pixel_centers ? 0u : spp_index, C.pixel_offset);
+	return C;
+}
+
+// Testbed::render_frame (src/testbed.cu:4694-4721) for opts->spp samples; the final image lands in d_rgba_out.
+void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba_out, float* d_depth_out, hipStream_t stream) {
+	if (!ctx->model_loaded) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
+	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
+	if (opts.render_mode != NGP_RENDER_SHADE) throw std::runtime_error("only render_mode Shade is implemented");
+	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
+	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
+	const size_t n_pixels = (size_t)cam.width * cam.height;
+	ensure_frame_buffers(ctx, n_pixels);
+	const int spp = opts.spp > 0 ? opts.spp : 1;
+
+	FrameParams F{};
+	F.frame_buffer = ctx->d_frame;
+	F.depth_buffer = d_depth_out ? d_depth_out : ctx->d_depth;
+	F.queue = (uint32_t*)ctx->d_sync;
+	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
+	F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
+	F.tiles_x = (uint32_t)(cam.width + 7) / 8;
+	F.tiles_y = (uint32_t)(cam.height + 7) / 8;
+	const uint32_t n_tiles = F.tiles_x * F.tiles_y;
+	F.shard_index = opts.shard_index;
+	F.shard_count = shard_count;
+	F.n_local_tiles = n_tiles > opts.shard_index ? (n_tiles - opts.shard_index + shard_count - 1) / shard_count : 0;
+	F.min_transmittance = opts.min_transmittance;
+	F.linear_colors = ctx->desc.linear_colors;
+	F.depth_test = 0;
+
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
+	NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
+	for (int s = 0; s < spp; ++s) {
+		CameraParams C = make_camera_params(cam, cam.spp_index + (uint32_t)s);
+		// CudaRenderBufferView::clear (src/render_buffer.cu:603-607)
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_frame, 0, n_pixels * sizeof(float4), stream));
+		NGP_HIP_CHECK(hipMemsetAsync(F.depth_buffer, 0, n_pixels * sizeof(float), stream));
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
+		const bool last = s == spp - 1;
+		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
+		// persistent grid: 4 workgroups of 4 waves per CU; surplus waves find the queue empty and exit
+		int n_blocks = ctx->n_cus * 4;
+		const int needed = (int)((F.n_local_tiles + 3) / 4);
+		if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
+		launch_render_nerf(ctx->M, C, F, n_blocks, stream);
+		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
+		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, last ? d_rgba_out : nullptr, stream);
+	}
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame1[slot], stream));
+	NGP_HIP_CHECK(hipGetLastError());
+	ctx->last_stream = stream;
+	ctx->hist_n_rays[slot] = (uint64_t)F.n_local_tiles * 64u * (uint64_t)spp;
+	++ctx->n_calls;
+}
+
+} // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+const char* ngp_version(void) { return "ngp_hip 0.1 (gfx950)"; }
+
+ngp_ctx* ngp_create(int device) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+	if (hipSetDevice(device) != hipSuccess) return nullptr;
+	ngp_ctx* ctx = new ngp_ctx();
+	ctx->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+	if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+		delete ctx;
+		return nullptr;
+	}
+	return ctx;
+}
+
+void ngp_destroy(ngp_ctx* ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
+	free_model(ctx);
+	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+	if (ctx->d_depth) (void)hipFree(ctx->d_depth);
+	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+	if (ctx->d_rgba) (void)hipFree(ctx->d_rgba);
+	if (ctx->d_sync) (void)hipFree(ctx->d_sync);
+	for (int i = 0; i < ngp_ctx::HISTORY; ++i) {
+		if (ctx->ev_frame0[i]) (void)hipEventDestroy(ctx->ev_frame0[i]);
+		if (ctx->ev_frame1[i]) (void)hipEventDestroy(ctx->ev_frame1[i]);
+		if (ctx->ev_kern0[i]) (void)hipEventDestroy(ctx->ev_kern0[i]);
+		if (ctx->ev_kern1[i]) (void)hipEventDestroy(ctx->ev_kern1[i]);
+	}
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+const char* ngp_last_error(const ngp_ctx* ctx) { return ctx ? ctx->error.c_str() : "no HIP device / invalid context"; }
+
+int ngp_set_model(ngp_ctx* ctx, const ngp_model_desc* desc) {
+	return guarded(ctx, [&] {
+		if (!desc) throw std::runtime_error("null model descriptor");
+		set_model_impl(ctx, *desc);
+		ctx->config = mj::Value();
+	});
+}
+
+int ngp_load_snapshot(ngp_ctx* ctx, const void* bytes, size_t n_bytes, int is_compressed) {
+	return guarded(ctx, [&] {
+		if (!bytes || !n_bytes) throw std::runtime_error("empty snapshot");
+		if (is_compressed) {
+			std::string raw = inflate_all(bytes, n_bytes);
+			load_snapshot_value(ctx, mj::MsgpackReader((const uint8_t*)raw.data(), raw.size()).parse());
+		} else {
+			load_snapshot_value(ctx, mj::MsgpackReader((const uint8_t*)bytes, n_bytes).parse());
+		}
+	});
+}
+
+int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path) {
+	return guarded(ctx, [&] {
+		if (!path) throw std::runtime_error("null path");
+		std::string p = path;
+		std::string data = read_file(p);
+		bool compressed = ends_with_ci(p, ".ingp"); // testbed.cu:262-266
+		if (!compressed && !ends_with_ci(p, ".msgpack")) throw std::runtime_error("snapshot must be a .msgpack or .ingp file");
+		if (compressed) data = inflate_all(data.data(), data.size());
+		load_snapshot_value(ctx, mj::MsgpackReader((const uint8_t*)data.data(), data.size()).parse());
+	});
+}
+
+int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
+	return guarded(ctx, [&] {
+		if (!ctx->model_loaded) throw std::runtime_error("no model to save");
+		if (!path) throw std::runtime_error("null path");
+		const ngp_model_desc& d = ctx->desc;
+		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
+		if (!root.contains("encoding")) {
+			mj::Value e = mj::Value::make_object();
+			e["otype"] = mj::Value::make_string("HashGrid");
+			e["n_levels"] = mj::Value::make_uint(d.n_levels);
+			e["n_features_per_level"] = mj::Value::make_uint(d.n_features_per_level);
+			e["log2_hashmap_size"] = mj::Value::make_uint(d.log2_hashmap_size);
+			e["base_resolution"] = mj::Value::make_uint(d.base_resolution);
+			root["encoding"] = e;
+			auto mlp = [&](uint32_t hidden) {
+				mj::Value n = mj::Value::make_object();
+				n["otype"] = mj::Value::make_string("FullyFusedMLP");
+				n["activation"] = mj::Value::make_string("ReLU");
+				n["output_activation"] = mj::Value::make_string("None");
+				n["n_neurons"] = mj::Value::make_uint(d.n_neurons);
+				n["n_hidden_layers"] = mj::Value::make_uint(hidden);
+				return n;
+			};
+			root["network"] = mlp(d.n_hidden_density);
+			root["rgb_network"] = mlp(d.n_hidden_rgb);
+			mj::Value de = mj::Value::make_object();
+			de["otype"] = mj::Value::make_string("Composite");
+			mj::Value nested = mj::Value::make_array();
+			mj::Value sh = mj::Value::make_object();
+			sh["n_dims_to_encode"] = mj::Value::make_uint(3);
+			sh["otype"] = mj::Value::make_string("SphericalHarmonics");
+			sh["degree"] = mj::Value::make_uint(4);
+			nested.push(sh);
+			mj::Value id = mj::Value::make_object();
+			id["otype"] = mj::Value::make_string("Identity");
+			nested.push(id);
+			de["nested"] = nested;
+			root["dir_encoding"] = de;
+		}
+		root["encoding"]["per_level_scale"] = mj::Value::make_float(d.per_level_scale);
+		mj::Value snap = mj::Value::make_object();
+		snap["n_params"] = mj::Value::make_uint(ctx->params.size());
+		snap["params_type"] = mj::Value::make_string("__half");
+		snap["params_binary"] = mj::Value::make_binary(ctx->params.data(), ctx->params.size() * 2);
+		snap["version"] = mj::Value::make_uint(1);
+		snap["mode"] = mj::Value::make_string("nerf");
+		snap["density_grid_size"] = mj::Value::make_uint(NERF_GRIDSIZE);
+		snap["density_grid_binary"] = mj::Value::make_binary(ctx->density_grid.data(), ctx->density_grid.size() * 2);
+		mj::Value nerf = mj::Value::make_object();
+		nerf["aabb_scale"] = mj::Value::make_uint(d.aabb_scale);
+		mj::Value rgbc = mj::Value::make_object();
+		rgbc["rays_per_batch"] = mj::Value::make_uint(4096);
+		rgbc["measured_batch_size"] = mj::Value::make_uint(0);
+		rgbc["measured_batch_size_before_compaction"] = mj::Value::make_uint(0);
+		nerf["rgb"] = rgbc;
+		Dataset ds = ctx->dataset;
+		ds.aabb_scale = (int)d.aabb_scale;
+		if (!ds.has_render_aabb) {
+			for (int i = 0; i < 3; ++i) { ds.render_aabb_min[i] = d.render_aabb_min[i]; ds.render_aabb_max[i] = d.render_aabb_max[i]; }
+		}
+		nerf["dataset"] = dataset_to_json(ds);
+		snap["nerf"] = nerf;
+		snap["training_step"] = mj::Value::make_uint(0);
+		snap["loss"] = mj::Value::make_float(0.0);
+		mj::Value aabb = mj::Value::make_object();
+		aabb["min"] = write_vec(d.aabb_min, 3);
+		aabb["max"] = write_vec(d.aabb_max, 3);
+		snap["aabb"] = aabb;
+		mj::Value raabb = mj::Value::make_object();
+		raabb["min"] = write_vec(d.render_aabb_min, 3);
+		raabb["max"] = write_vec(d.render_aabb_max, 3);
+		snap["render_aabb"] = raabb;
+		snap["render_aabb_to_local"] = write_mat(d.render_aabb_to_local, 3, 3);
+		snap["up_dir"] = write_vec(ctx->dataset.up, 3);
+		if (ctx->has_snapshot_camera) {
+			mj::Value cam = mj::Value::make_object();
+			cam["matrix"] = write_mat(ctx->snap_camera, 4, 3);
+			cam["fov_axis"] = mj::Value::make_int(ctx->snap_fov_axis);
+			cam["relative_focal_length"] = write_vec(ctx->snap_relative_focal_length, 2);
+			cam["screen_center"] = write_vec(ctx->snap_screen_center, 2);
+			cam["zoom"] = mj::Value::make_float(ctx->snap_zoom);
+			snap["camera"] = cam;
+		}
+		root["snapshot"] = snap;
+		mj::MsgpackWriter w;
+		w.write(root);
+		std::string p = path;
+		std::ofstream f(p, std::ios::out | std::ios::binary);
+		if (!f) throw std::runtime_error("cannot write '" + p + "'");
+		if (ends_with_ci(p, ".ingp")) {
+			std::string z = deflate_gzip(w.out, compress ? Z_DEFAULT_COMPRESSION : Z_NO_COMPRESSION);
+			f.write(z.data(), (std::streamsize)z.size());
+		} else {
+			f.write(w.out.data(), (std::streamsize)w.out.size());
+		}
+	});
+}
+
+int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out) {
+	if (!ctx || !out || !ctx->model_loaded) return -1;
+	*out = ctx->desc;
+	out->n_params = ctx->params.size();
+	out->n_density_grid = ctx->density_grid.size();
+	return 0;
+}
+
+int ngp_get_snapshot_camera(const ngp_ctx* ctx, float* matrix12, float* rfl2, int32_t* fov_axis, float* sc2, float* zoom) {
+	if (!ctx || !ctx->has_snapshot_camera) return -1;
+	if (matrix12) memcpy(matrix12, ctx->snap_camera, sizeof(float) * 12);
+	if (rfl2) memcpy(rfl2, ctx->snap_relative_focal_length, sizeof(float) * 2);
+	if (fov_axis) *fov_axis = ctx->snap_fov_axis;
+	if (sc2) memcpy(sc2, ctx->snap_screen_center, sizeof(float) * 2);
+	if (zoom) *zoom = ctx->snap_zoom;
+	return 0;
+}
+
+int ngp_load_training_data(ngp_ctx* ctx, const char* path) {
+	if (!ctx) return -1;
+	try { // needs no device
+		if (!path) throw std::runtime_error("null path");
+		load_training_data_impl(ctx, path);
+		ctx->error.clear();
+		return 0;
+	} catch (const std::exception& e) {
+		ctx->error = e.what();
+		return -1;
+	}
+}
+
+int ngp_n_training_views(const ngp_ctx* ctx) { return ctx ? (int)ctx->dataset.views.size() : -1; }
+
+int ngp_get_training_view(const ngp_ctx* ctx, int view, float* matrix12, int32_t* res2, float* fl2, float* pp2) {
+	if (!ctx || view < 0 || view >= (int)ctx->dataset.views.size()) return -1;
+	const TrainingView& v = ctx->dataset.views[(size_t)view];
+	if (matrix12) memcpy(matrix12, v.xform.data(), sizeof(float) * 12);
+	if (res2) { res2[0] = v.resolution[0]; res2[1] = v.resolution[1]; }
+	if (fl2) { fl2[0] = v.focal_length[0]; fl2[1] = v.focal_length[1]; }
+	if (pp2) { pp2[0] = v.principal_point[0]; pp2[1] = v.principal_point[1]; }
+	return 0;
+}
+
+int ngp_get_dataset_info(const ngp_ctx* ctx, int32_t* aabb_scale, float* scale, float* offset3, int32_t* is_hdr) {
+	if (!ctx) return -1;
+	if (aabb_scale) *aabb_scale = ctx->dataset.aabb_scale;
+	if (scale) *scale = ctx->dataset.scale;
+	if (offset3) memcpy(offset3, ctx->dataset.offset, sizeof(float) * 3);
+	if (is_hdr) *is_hdr = ctx->dataset.is_hdr ? 1 : 0;
+	return 0;
+}
+
+int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, void* d_rgba, void* d_depth, void* stream) {
+	return guarded(ctx, [&] {
+		if (!cam || !opts || !d_rgba) throw std::runtime_error("null argument");
+		render_frames(ctx, *cam, *opts, (float4*)d_rgba, (float*)d_depth, stream ? (hipStream_t)stream : ctx->stream);
+	});
+}
+
+int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out) {
+	return guarded(ctx, [&] {
+		if (!cam || !opts || !rgba_out) throw std::runtime_error("null argument");
+		const size_t n_pixels = (size_t)cam->width * cam->height;
+		ensure_frame_buffers(ctx, n_pixels);
+		render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
+		NGP_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_rgba, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+		if (depth_out) NGP_HIP_CHECK(hipMemcpyAsync(depth_out, ctx->d_depth, n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	});
+}
+
+static void read_history_slot(ngp_ctx* ctx, uint64_t call, ngp_render_stats* out) {
+	const int slot = (int)(call % ngp_ctx::HISTORY);
+	unsigned long long c[3];
+	NGP_HIP_CHECK(hipMemcpy(c, (char*)ctx->d_sync + 64 + 32 * slot, sizeof(c), hipMemcpyDeviceToHost));
+	out->n_rays = ctx->hist_n_rays[slot];
+	out->n_rays_alive_after_init = c[0];
+	out->n_rays_hit = c[1];
+	out->n_samples = c[2];
+	NGP_HIP_CHECK(hipEventElapsedTime(&out->kernel_ms, ctx->ev_kern0[slot], ctx->ev_kern1[slot]));
+	NGP_HIP_CHECK(hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0[slot], ctx->ev_frame1[slot]));
+}
+
+int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
+	return guarded(ctx, [&] {
+		if (!out) throw std::runtime_error("null argument");
+		if (!ctx->n_calls) throw std::runtime_error("nothing rendered yet");
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+		read_history_slot(ctx, ctx->n_calls - 1, out);
+	});
+}
+
+int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out) {
+	return guarded(ctx, [&] {
+		if (!out || n <= 0) throw std::runtime_error("invalid argument");
+		if ((uint64_t)n > ctx->n_calls || n > ngp_ctx::HISTORY) throw std::runtime_error("history holds fewer render calls than requested");
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+		for (int i = 0; i < n; ++i) read_history_slot(ctx, ctx->n_calls - (uint64_t)n + (uint64_t)i, &out[i]);
+	});
+}
+
+int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_fp16) {
+	return guarded(ctx, [&] {
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (n == 0) return;
+		if (!pos01 || !out_fp16) throw std::runtime_error("null argument");
+		float* d_pos = nullptr;
+		uint16_t* d_out = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_pos, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 32 * sizeof(uint16_t)));
+		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		launch_grid_encode(ctx->M, n, d_pos, d_out, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * 32 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+		(void)hipFree(d_pos);
+		(void)hipFree(d_out);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16) {
+	return guarded(ctx, [&] {
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (n == 0) return;
+		if (!pos01 || !dir01 || !out_fp16) throw std::runtime_error("null argument");
+		float *d_pos = nullptr, *d_dir = nullptr;
+		uint16_t* d_out = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_pos, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_dir, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 4 * sizeof(uint16_t)));
+		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		NGP_HIP_CHECK(hipMemcpy(d_dir, dir01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		launch_network_inference(ctx->M, n, d_pos, d_dir, d_out, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+		(void)hipFree(d_pos);
+		(void)hipFree(d_dir);
+		(void)hipFree(d_out);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
+	return guarded(ctx, [&] {
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (out) NGP_HIP_CHECK(hipMemcpy(out, ctx->d_bitfield, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, hipMemcpyDeviceToHost));
+		if (out_mean) *out_mean = ctx->bitfield_mean;
+	});
+}
+
+int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out) {
+	return guarded(ctx, [&] {
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (!cam || !payloads_out) throw std::runtime_error("null argument");
+		const size_t n = (size_t)cam->width * cam->height;
+		NerfPayload* d_p = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_p, n * sizeof(NerfPayload)));
+		CameraParams C = make_camera_params(*cam, cam->spp_index);
+		launch_init_rays(ctx->M, C, d_p, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipMemcpy(payloads_out, d_p, n * sizeof(NerfPayload), hipMemcpyDeviceToHost));
+		(void)hipFree(d_p);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+} // extern "C"

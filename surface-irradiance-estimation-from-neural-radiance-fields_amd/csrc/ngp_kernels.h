@@ -1,0 +1,82 @@
+// Host/device shared declarations for libngp_hip's kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ngp {
+
+constexpr uint32_t NERF_GRIDSIZE = 128;
+constexpr uint32_t NERF_GRID_N_CELLS = NERF_GRIDSIZE * NERF_GRIDSIZE * NERF_GRIDSIZE;
+constexpr uint32_t NERF_CASCADES = 8;
+constexpr uint32_t NERF_STEPS = 1024;
+constexpr float MAX_DEPTH = 16384.0f;
+constexpr uint32_t MARCH_ITER = 10000; // reference src/testbed_nerf.cu:46
+
+// The fused kernel is specialised for the configs/nerf/base.json architecture:
+// 8 levels x 4 features -> 32, density 32->64->16, rgb 32->64->64->16, all on 16x16x32 f16 MFMA tiles.
+constexpr int N_LEVELS = 8;
+constexpr int N_FEATURES = 4;
+constexpr int MLP_WIDTH = 64;
+// MFMA A-operand fragments (weights): density L1 (4), density out (2), rgb L1 (4), rgb L2 (8), rgb out (2)
+constexpr int FRAG_D0 = 0, FRAG_D1 = 4, FRAG_R0 = 6, FRAG_R1 = 10, FRAG_R2 = 18, N_FRAGS = 20;
+
+struct LevelInfo {
+	float scale;
+	uint32_t res;
+	uint32_t size;   // entries in this level
+	uint32_t offset; // first entry
+	uint32_t hashed; // 1: spatial hash, 0: dense x + y*res + z*res^2
+	uint32_t mask;   // size-1 if size is a power of two, else 0
+	uint32_t pad0, pad1;
+};
+
+struct NerfPayload { // nerf_device.cuh:144-152
+	float origin[3];
+	float dir[3];
+	float t;
+	float max_weight;
+	uint32_t idx;
+	uint16_t n_steps;
+	uint8_t alive;
+	uint8_t pad;
+};
+static_assert(sizeof(NerfPayload) == 40, "NerfPayload layout");
+
+struct ModelParams {
+	const uint2* grid;       // fp16 x4 per entry
+	const uint4* wfrags;     // [N_FRAGS][64] x 8 fp16, MFMA A fragments in lane order
+	const uint8_t* bitfield; // 8 x 128^3 bits
+	LevelInfo levels[N_LEVELS];
+	float aabb_min[3], aabb_diag[3];
+	float raabb_min[3], raabb_max[3];
+	float r2l[9]; // render_aabb_to_local, column-major
+	uint32_t max_cascade;
+	float cone_angle;
+	uint32_t rgb_act, density_act;
+};
+
+struct CameraParams {
+	float m[12]; // column-major 4x3
+	int32_t width, height;
+	float focal[2];
+	float screen_center[2];
+	float pixel_offset[2]; // ld_random_pixel_offset(snap ? 0 : spp), per-frame constant
+	uint32_t spp;
+	float near_distance;
+};
+
+struct FrameParams {
+	float4* frame_buffer;
+	float* depth_buffer;
+	uint32_t* queue;               // [0]: next local tile
+	unsigned long long* counters;  // [0] alive after init, [1] hit, [2] samples
+	uint32_t tiles_x, tiles_y;
+	uint32_t n_local_tiles;
+	uint32_t shard_index, shard_count;
+	float min_transmittance;
+	int32_t linear_colors;
+	int32_t depth_test;
+};
+
+} // namespace ngp

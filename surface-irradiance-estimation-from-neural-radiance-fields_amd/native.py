@@ -1,0 +1,276 @@
+"""ctypes binding of libngp_hip.so -- the C ABI declared in include/ngp_hip.h.
+
+This is the only way Python reaches the renderer: there is no CPU fallback. Loading fails loudly when the
+library has not been built (run the package's build.py / __graft_entry__.build()), and every compute call
+fails loudly when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libngp_hip.so")
+
+HEADER_PATH = os.path.join(HERE, "..", "include", "ngp_hip.h")
+
+
+def header_exports():
+    """Every entry point include/ngp_hip.h declares (NGP_API ... name(...))."""
+    import re
+
+    with open(HEADER_PATH) as f:
+        return re.findall(r"NGP_API\s+[\w\s\*]+?\b(ngp_\w+)\s*\(", f.read())
+
+
+EXPORTS = header_exports()
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32), ("n_features_per_level", C.c_uint32), ("log2_hashmap_size", C.c_uint32), ("base_resolution", C.c_uint32),
+        ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_uint32), ("n_hidden_density", C.c_uint32), ("n_hidden_rgb", C.c_uint32), ("density_out_dims", C.c_uint32),
+        ("rgb_activation", C.c_uint32), ("density_activation", C.c_uint32),
+        ("params_fp16", C.c_void_p), ("n_params", C.c_uint64),
+        ("density_grid_fp16", C.c_void_p), ("n_density_grid", C.c_uint64),
+        ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+        ("render_aabb_min", C.c_float * 3), ("render_aabb_max", C.c_float * 3),
+        ("render_aabb_to_local", C.c_float * 9),
+        ("aabb_scale", C.c_uint32), ("cone_angle_constant", C.c_float), ("linear_colors", C.c_int32),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("matrix", C.c_float * 12), ("width", C.c_int32), ("height", C.c_int32), ("focal_length", C.c_float * 2),
+        ("screen_center", C.c_float * 2), ("spp_index", C.c_uint32), ("snap_to_pixel_centers", C.c_int32), ("near_distance", C.c_float),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("render_mode", C.c_int32), ("min_transmittance", C.c_float), ("background", C.c_float * 4), ("exposure", C.c_float),
+        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+    ]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_uint64), ("n_rays_alive_after_init", C.c_uint64), ("n_rays_hit", C.c_uint64), ("n_samples", C.c_uint64),
+        ("kernel_ms", C.c_float), ("frame_ms", C.c_float),
+    ]
+
+
+PAYLOAD_DTYPE = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"), ("max_weight", "<f4"), ("idx", "<u4"),
+                          ("n_steps", "<u2"), ("alive", "u1"), ("pad", "u1")])
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py or the package's build.py). "
+                           "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.c_int
+    L.ngp_create.argtypes = [ip]; L.ngp_create.restype = vp
+    L.ngp_destroy.argtypes = [vp]; L.ngp_destroy.restype = None
+    L.ngp_last_error.argtypes = [vp]; L.ngp_last_error.restype = C.c_char_p
+    L.ngp_version.restype = C.c_char_p
+    L.ngp_set_model.argtypes = [vp, C.POINTER(ModelDesc)]
+    L.ngp_load_snapshot.argtypes = [vp, vp, C.c_size_t, ip]
+    L.ngp_load_snapshot_file.argtypes = [vp, C.c_char_p]
+    L.ngp_save_snapshot_file.argtypes = [vp, C.c_char_p, ip]
+    L.ngp_get_model.argtypes = [vp, C.POINTER(ModelDesc)]
+    L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
+    L.ngp_n_training_views.argtypes = [vp]
+    L.ngp_get_training_view.argtypes = [vp, ip, vp, vp, vp, vp]
+    L.ngp_get_dataset_info.argtypes = [vp, vp, vp, vp, vp]
+    L.ngp_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp]
+    L.ngp_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp, vp]
+    L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
+    L.ngp_get_render_history.argtypes = [vp, ip, C.POINTER(RenderStats)]
+    L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
+    L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.ngp_get_density_bitfield.argtypes = [vp, vp, vp]
+    L.ngp_init_rays.argtypes = [vp, C.POINTER(Camera), vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0):
+    cam = Camera()
+    mat = np.asarray(matrix_3x4, np.float32)
+    assert mat.shape == (3, 4)
+    for c in range(4):
+        for r in range(3):
+            cam.matrix[c * 3 + r] = mat[r, c]
+    cam.width, cam.height = int(width), int(height)
+    cam.focal_length[0], cam.focal_length[1] = focal_length
+    cam.screen_center[0], cam.screen_center[1] = screen_center
+    cam.spp_index = spp_index
+    cam.snap_to_pixel_centers = 1 if snap else 0
+    cam.near_distance = near
+    return cam
+
+
+def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1):
+    o = RenderOpts()
+    o.render_mode = 0
+    o.min_transmittance = min_transmittance
+    for i in range(4):
+        o.background[i] = background[i]
+    o.exposure = exposure
+    o.to_srgb = int(to_srgb)
+    o.spp = spp
+    o.shard_index, o.shard_count = shard_index, shard_count
+    return o
+
+
+class Context:
+    """One ngp_ctx. Errors from the C ABI become RuntimeError (like the reference's exceptions through pybind11)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = self.L.ngp_create(device)
+        if not self.h:
+            raise RuntimeError("ngp_create failed: no HIP device available (libngp_hip has no CPU fallback)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ngp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.ngp_last_error(self.h).decode())
+
+    # ---------------------------------------------------------------- model
+    def set_model(self, scene):
+        d = ModelDesc()
+        enc = scene["encoding"]
+        d.n_levels, d.n_features_per_level = enc["n_levels"], enc["n_features_per_level"]
+        d.log2_hashmap_size, d.base_resolution = enc["log2_hashmap_size"], enc["base_resolution"]
+        d.per_level_scale = enc["per_level_scale"]
+        d.n_neurons = scene["network"]["n_neurons"]
+        d.n_hidden_density = scene["network"]["n_hidden_layers"]
+        d.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]
+        d.density_out_dims = scene["network"].get("n_output_dims", 16)
+        d.rgb_activation = scene.get("rgb_activation", 2)
+        d.density_activation = scene.get("density_activation", 3)
+        params = np.ascontiguousarray(scene["params"], np.uint16)
+        grid = np.ascontiguousarray(np.asarray(scene["density_grid"]).astype(np.float16)).view(np.uint16)
+        d.params_fp16, d.n_params = params.ctypes.data, params.size
+        d.density_grid_fp16, d.n_density_grid = grid.ctypes.data, grid.size
+        for i in range(3):
+            d.aabb_min[i], d.aabb_max[i] = scene["aabb"][0][i], scene["aabb"][1][i]
+            d.render_aabb_min[i], d.render_aabb_max[i] = scene["render_aabb"][0][i], scene["render_aabb"][1][i]
+        r2l = np.asarray(scene.get("render_aabb_to_local", np.eye(3)), np.float32)
+        for c in range(3):
+            for r in range(3):
+                d.render_aabb_to_local[c * 3 + r] = r2l[r, c]
+        d.aabb_scale = scene["aabb_scale"]
+        d.cone_angle_constant = scene["cone_angle_constant"]
+        d.linear_colors = int(scene.get("linear_colors", False))
+        self._check(self.L.ngp_set_model(self.h, C.byref(d)))
+
+    def load_snapshot_bytes(self, data, compressed=False):
+        buf = np.frombuffer(data, np.uint8)
+        self._check(self.L.ngp_load_snapshot(self.h, _p(buf), buf.size, int(compressed)))
+
+    def load_snapshot_file(self, path):
+        self._check(self.L.ngp_load_snapshot_file(self.h, os.fsencode(path)))
+
+    def save_snapshot_file(self, path, compress=True):
+        self._check(self.L.ngp_save_snapshot_file(self.h, os.fsencode(path), int(compress)))
+
+    def get_model(self):
+        d = ModelDesc()
+        self._check(self.L.ngp_get_model(self.h, C.byref(d)))
+        return d
+
+    def snapshot_camera(self):
+        m = np.zeros(12, np.float32); rfl = np.zeros(2, np.float32); sc = np.zeros(2, np.float32)
+        ax = C.c_int32(0); zoom = C.c_float(0)
+        if self.L.ngp_get_snapshot_camera(self.h, _p(m), _p(rfl), C.addressof(ax), _p(sc), C.addressof(zoom)) != 0:
+            return None
+        return {"matrix": m.reshape(4, 3).T.copy(), "relative_focal_length": rfl, "fov_axis": ax.value, "screen_center": sc, "zoom": zoom.value}
+
+    # ---------------------------------------------------------------- data
+    def load_training_data(self, path):
+        self._check(self.L.ngp_load_training_data(self.h, os.fsencode(path)))
+
+    def n_training_views(self):
+        return self.L.ngp_n_training_views(self.h)
+
+    def training_view(self, i):
+        m = np.zeros(12, np.float32); res = np.zeros(2, np.int32); fl = np.zeros(2, np.float32); pp = np.zeros(2, np.float32)
+        if self.L.ngp_get_training_view(self.h, i, _p(m), _p(res), _p(fl), _p(pp)) != 0:
+            raise IndexError(i)
+        return {"matrix": m.reshape(4, 3).T.copy(), "resolution": res, "focal_length": fl, "principal_point": pp}
+
+    def dataset_info(self):
+        a = C.c_int32(0); s = C.c_float(0); off = np.zeros(3, np.float32); hdr = C.c_int32(0)
+        self._check(self.L.ngp_get_dataset_info(self.h, C.addressof(a), C.addressof(s), _p(off), C.addressof(hdr)))
+        return {"aabb_scale": a.value, "scale": s.value, "offset": off, "is_hdr": bool(hdr.value)}
+
+    # ---------------------------------------------------------------- render
+    def render(self, cam, opts=None, want_depth=False):
+        opts = opts or make_opts()
+        rgba = np.zeros((cam.height, cam.width, 4), np.float32)
+        depth = np.zeros((cam.height, cam.width), np.float32) if want_depth else None
+        self._check(self.L.ngp_render(self.h, C.byref(cam), C.byref(opts), _p(rgba), _p(depth) if want_depth else None))
+        return (rgba, depth) if want_depth else rgba
+
+    def render_device(self, cam, opts, d_rgba_ptr, d_depth_ptr=None, stream=None):
+        self._check(self.L.ngp_render_device(self.h, C.byref(cam), C.byref(opts), d_rgba_ptr, d_depth_ptr, stream))
+
+    def render_stats(self):
+        st = RenderStats()
+        self._check(self.L.ngp_get_render_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in RenderStats._fields_}
+
+    def render_history(self, n):
+        arr = (RenderStats * n)()
+        self._check(self.L.ngp_get_render_history(self.h, n, arr))
+        return [{k: getattr(st, k) for k, _ in RenderStats._fields_} for st in arr]
+
+    # ---------------------------------------------------------------- stages
+    def grid_encode(self, pos01):
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        out = np.zeros((pos01.shape[0], 32), np.uint16)
+        self._check(self.L.ngp_grid_encode(self.h, pos01.shape[0], _p(pos01), _p(out)))
+        return out.view(np.float16)
+
+    def network(self, pos01, dir01):
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        dir01 = np.ascontiguousarray(dir01, np.float32)
+        out = np.zeros((pos01.shape[0], 4), np.uint16)
+        self._check(self.L.ngp_network_inference(self.h, pos01.shape[0], _p(pos01), _p(dir01), _p(out)))
+        return out.view(np.float16)
+
+    def density_bitfield(self):
+        bf = np.zeros(128 ** 3 // 8 * 8, np.uint8)
+        mean = C.c_float(0)
+        self._check(self.L.ngp_get_density_bitfield(self.h, _p(bf), C.addressof(mean)))
+        return bf, mean.value
+
+    def init_rays(self, cam):
+        pl = np.zeros(cam.width * cam.height, PAYLOAD_DTYPE)
+        self._check(self.L.ngp_init_rays(self.h, C.byref(cam), _p(pl)))
+        return pl

@@ -1,0 +1,71 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "surface-irradiance-estimation-from-neural-radiance-fields_amd"
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+
+    return orc.Oracle()
+
+
+@pytest.fixture(scope="session")
+def native():
+    """ctypes binding of libngp_hip.so (built on demand; fails loudly if hipcc is missing)."""
+    pkg("build").build()
+    return pkg("native")
+
+
+@pytest.fixture(scope="session")
+def scene_mod():
+    return pkg("scene")
+
+
+def _with_bitfield(oracle, sc):
+    grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)  # what a snapshot stores
+    bf, mean = oracle.density_grid_to_bitfield(grid, sc["max_cascade"])
+    sc["density_grid_bitfield"] = bf
+    sc["density_grid_mean"] = mean
+    return sc
+
+
+@pytest.fixture(scope="session")
+def scene_unit(oracle):
+    """aabb_scale 1 (Lego-shaped: cone angle 0, one cascade), small hash table so that fixtures stay light."""
+    return _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=15))
+
+
+@pytest.fixture(scope="session")
+def scene_big(oracle):
+    """aabb_scale 4 (fox-shaped: exponential stepping, 3 cascades), upstream per_level_scale rule."""
+    return _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=4, seed=99, log2_hashmap_size=16, pls_rule="upstream"))
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(native):
+    ctx = native.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def psnr(a, b):
+    mse = float(((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2).mean())
+    return 99.0 if mse == 0 else -10.0 * np.log10(mse)
