@@ -53,7 +53,8 @@ def cpu_baseline(scene_dict, scene_mod):
     m = o.make_model(sc)
     w, h = WIDTH // 4, HEIGHT // 4
     cam = o.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X))
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("NGP_BENCH_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
     t0 = time.perf_counter()
     _, _, st = o.render_nerf(m, cam, o.make_opts(n_threads=cores))
     dt = time.perf_counter() - t0
