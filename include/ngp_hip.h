@@ -90,7 +90,8 @@ typedef struct ngp_render_stats {
 	float frame_ms;          /* whole frame on the device (clear .. tonemap), HIP events */
 } ngp_render_stats;
 
-/* --- lifetime: Testbed::Testbed / ~Testbed (testbed.h:80-95) */
+/* --- lifetime: Testbed::Testbed / ~Testbed (testbed.h:80-95). device = HIP device ordinal; -1 creates a host-only
+ * context that can read/validate/write the file formats but cannot render (there is no CPU renderer). NULL on failure. */
 NGP_API ngp_ctx* ngp_create(int device);
 NGP_API void ngp_destroy(ngp_ctx* ctx);
 NGP_API const char* ngp_last_error(const ngp_ctx* ctx);

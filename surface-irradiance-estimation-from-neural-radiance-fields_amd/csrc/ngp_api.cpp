@@ -23,7 +23,7 @@ template <typename F>
 int guarded(ngp_ctx* ctx, F&& f) {
 	if (!ctx) return -1;
 	try {
-		NGP_HIP_CHECK(hipSetDevice(ctx->device));
+		if (ctx->device >= 0) NGP_HIP_CHECK(hipSetDevice(ctx->device));
 		f();
 		ctx->error.clear();
 		return 0;
@@ -269,6 +269,8 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	ctx->desc.params_fp16 = nullptr;
 	ctx->desc.density_grid_fp16 = nullptr;
 	ctx->max_cascade = max_cascade;
+	ctx->have_desc = true;
+	if (ctx->device < 0) return; // host-only context: the model is parsed and validated, nothing can be rendered
 
 	// grid table
 	NGP_HIP_CHECK(hipMalloc(&ctx->d_params, ng * sizeof(uint16_t)));
@@ -761,6 +763,7 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 
 // Testbed::render_frame (src/testbed.cu:4694-4721) for opts->spp samples; the final image lands in d_rgba_out.
 void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba_out, float* d_depth_out, hipStream_t stream) {
+	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 	if (!ctx->model_loaded) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
 	if (opts.render_mode != NGP_RENDER_SHADE) throw std::runtime_error("only render_mode Shade is implemented");
@@ -819,6 +822,11 @@ extern "C" {
 const char* ngp_version(void) { return "ngp_hip 0.1 (gfx950)"; }
 
 ngp_ctx* ngp_create(int device) {
+	if (device == -1) { // host-only context: file formats and validation, no rendering (there is no CPU renderer)
+		ngp_ctx* ctx = new ngp_ctx();
+		ctx->device = -1;
+		return ctx;
+	}
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
 	if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -835,6 +843,7 @@ ngp_ctx* ngp_create(int device) {
 
 void ngp_destroy(ngp_ctx* ctx) {
 	if (!ctx) return;
+	if (ctx->device < 0) { delete ctx; return; }
 	(void)hipSetDevice(ctx->device);
 	if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
 	free_model(ctx);
@@ -889,7 +898,7 @@ int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path) {
 
 int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 	return guarded(ctx, [&] {
-		if (!ctx->model_loaded) throw std::runtime_error("no model to save");
+		if (!ctx->have_desc) throw std::runtime_error("no model to save");
 		if (!path) throw std::runtime_error("null path");
 		const ngp_model_desc& d = ctx->desc;
 		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
@@ -986,7 +995,7 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 }
 
 int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out) {
-	if (!ctx || !out || !ctx->model_loaded) return -1;
+	if (!ctx || !out || !ctx->have_desc) return -1;
 	*out = ctx->desc;
 	out->n_params = ctx->params.size();
 	out->n_density_grid = ctx->density_grid.size();
@@ -1047,6 +1056,7 @@ int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts
 int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out) {
 	return guarded(ctx, [&] {
 		if (!cam || !opts || !rgba_out) throw std::runtime_error("null argument");
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 		const size_t n_pixels = (size_t)cam->width * cam->height;
 		ensure_frame_buffers(ctx, n_pixels);
 		render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
@@ -1088,6 +1098,7 @@ int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out) {
 
 int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_fp16) {
 	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (n == 0) return;
 		if (!pos01 || !out_fp16) throw std::runtime_error("null argument");
@@ -1107,6 +1118,7 @@ int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_
 
 int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16) {
 	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (n == 0) return;
 		if (!pos01 || !dir01 || !out_fp16) throw std::runtime_error("null argument");
@@ -1129,6 +1141,7 @@ int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const fl
 
 int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (out) NGP_HIP_CHECK(hipMemcpy(out, ctx->d_bitfield, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, hipMemcpyDeviceToHost));
 		if (out_mean) *out_mean = ctx->bitfield_mean;
@@ -1137,6 +1150,7 @@ int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 
 int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out) {
 	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (!cam || !payloads_out) throw std::runtime_error("null argument");
 		const size_t n = (size_t)cam->width * cam->height;

@@ -61,7 +61,8 @@ struct ngp_ctx {
 	hipStream_t stream = nullptr;
 
 	// ---- model
-	bool model_loaded = false;
+	bool model_loaded = false; // uploaded to the device
+	bool have_desc = false;    // parsed + validated on the host
 	ngp_model_desc desc{};
 	std::vector<uint16_t> params;
 	std::vector<uint16_t> density_grid;

@@ -63,6 +63,6 @@ def gather_frame(local_img, width, height, rank, world_size, group=None):
         return local_img
     n_slots = slots_per_rank(width, height, world_size)
     packed = pack_tiles(local_img, width, height, rank, world_size, n_slots).contiguous()
-    out = packed.new_empty((world_size,) + tuple(packed.shape))
+    out = packed.new_empty((world_size * n_slots,) + tuple(packed.shape[1:]))  # concatenated along dim 0
     dist.all_gather_into_tensor(out, packed, group=group)
-    return unpack_tiles(out, width, height, world_size)
+    return unpack_tiles(out.view((world_size, n_slots) + tuple(packed.shape[1:])), width, height, world_size)

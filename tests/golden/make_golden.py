@@ -1,0 +1,72 @@
+"""Generates tests/golden/nerf_unit_v1.npz: inputs and expected outputs of the CPU oracle for a small seeded scene.
+
+The reference ships no golden vectors, cannot be built here (CUDA + absent tiny-cuda-nn) and has no CPU path, so
+these vectors come from the build's own oracle (PARITY UNPINNED, see oracle/orc_common.h). They pin the oracle
+against regressions and platform drift, and give the GPU tests a committed target that does not depend on the
+oracle being rebuilt. Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+PKG = "surface-irradiance-estimation-from-neural-radiance-fields_amd"
+
+SEED, LOG2_T = 4321, 14
+W, H, AZ = 48, 27, 45.0
+
+
+def build_inputs():
+    synthetic = importlib.import_module(PKG + ".synthetic")
+    scene = importlib.import_module(PKG + ".scene")
+    sc = synthetic.make_scene(aabb_scale=1, seed=SEED, log2_hashmap_size=LOG2_T)
+    rng = np.random.default_rng(77)
+    pos = rng.uniform(0, 1, (256, 3)).astype(np.float32)
+    pos[:4] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.75, 1.0]]
+    d = rng.normal(size=(256, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dir01 = ((d + 1) * 0.5).astype(np.float32)
+    cam_matrix = scene.orbit_camera(AZ)
+    focal = scene.focal_from_fov_x(W, 0.6911)
+    return sc, pos, dir01, cam_matrix, focal
+
+
+def main():
+    import oracle as orc
+
+    o = orc.Oracle()
+    sc, pos, dir01, cam_matrix, focal = build_inputs()
+    grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
+    bf, mean = o.density_grid_to_bitfield(grid, sc["max_cascade"])
+    sc["density_grid_bitfield"] = bf
+    m = o.make_model(sc)
+    cam = o.make_camera(cam_matrix, W, H, focal)
+    fb, db, st = o.render_nerf(m, cam, o.make_opts(n_threads=1))
+    out = dict(
+        params_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(sc["params"]).tobytes()).digest(), np.uint8),
+        density_grid_sha256=np.frombuffer(hashlib.sha256(np.asarray(sc["density_grid"], np.float16).tobytes()).digest(), np.uint8),
+        bitfield_sha256=np.frombuffer(hashlib.sha256(bf.tobytes()).digest(), np.uint8),
+        bitfield_mean=np.float32(mean),
+        pos=pos, dir01=dir01,
+        enc=o.grid_encode(m, pos).view(np.uint16),
+        sh=o.sh4(dir01).view(np.uint16),
+        net=o.network(m, pos, dir01).view(np.uint16),
+        cam_matrix=cam_matrix.astype(np.float32), focal=np.asarray(focal, np.float32),
+        payloads=o.init_rays(m, cam).view(np.uint8),
+        frame=fb.astype(np.float32), depth=db.astype(np.float32),
+        stats=np.array([st["n_rays"], st["n_rays_alive_after_init"], st["n_rays_hit"], st["n_samples"]], np.int64),
+        ld_vals=np.array([o.ld_random_val(i, s) for i in range(8) for s in (0, 786433, 0xdeadbeef)], np.float32),
+        pixel_offsets=np.stack([o.pixel_offset(s) for s in range(6)]),
+    )
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nerf_unit_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", st)
+
+
+if __name__ == "__main__":
+    main()

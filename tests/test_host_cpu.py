@@ -1,0 +1,245 @@
+"""CPU tests of the host side: the C ABI exports everything include/ngp_hip.h declares, file formats
+(transforms.json, msgpack / .ingp snapshots) parse and round-trip without a GPU, errors are reported, and the
+N > 1 tile-sharding path works over gloo with world_size 2."""
+import ctypes as C
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+REF = "/root/reference"
+
+
+def test_library_exports_every_declared_symbol(native):
+    L = native.load_library()
+    names = native.header_exports()
+    assert len(names) >= 20 and "ngp_render" in names and "ngp_load_snapshot" in names and "ngp_load_training_data" in names
+    for n in names:
+        assert hasattr(L, n), f"libngp_hip.so does not export {n}"
+    assert b"gfx950" in L.ngp_version()
+
+
+def test_no_cpu_fallback(native):
+    ctx = native.Context(-1)  # host-only: formats yes, rendering no
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        ctx.render(native.make_camera(np.eye(3, 4, dtype=np.float32), 8, 8, (8.0, 8.0)))
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        ctx.grid_encode(np.zeros((4, 3), np.float32))
+    ctx.close()
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            native.Context(0)
+    # the product never touches the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, pkg("native").__name__.split(".")[0])):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "orc_" not in txt, f
+
+
+def _write_transforms(tmp_path, **extra):
+    frames = []
+    for i, name in enumerate(["r_10", "r_2", "r_1"]):  # deliberately not in natural order
+        m = np.eye(4)
+        m[:3, 3] = [i + 1.0, 2.0 * i, -1.0]
+        frames.append({"file_path": f"./train/{name}", "transform_matrix": m.tolist()})
+    d = {"camera_angle_x": 0.6911, "w": 800, "h": 600, "aabb_scale": 2, "frames": frames}
+    d.update(extra)
+    p = tmp_path / "transforms.json"
+    p.write_text("// a comment, accepted like nlohmann's ignore_comments\n" + json.dumps(d))
+    return str(p)
+
+
+def test_transforms_json(tmp_path, native, scene_mod):
+    ctx = native.Context(-1)
+    ctx.load_training_data(_write_transforms(tmp_path))
+    assert ctx.n_training_views() == 3
+    info = ctx.dataset_info()
+    assert info["aabb_scale"] == 2 and abs(info["scale"] - 0.33) < 1e-7 and np.allclose(info["offset"], 0.5)
+    # natural sort: r_1, r_2, r_10 -> translations x = 3, 2, 1
+    xs = []
+    for i in range(3):
+        v = ctx.training_view(i)
+        assert v["resolution"].tolist() == [800, 600]
+        f = 0.5 * 800 / np.tan(0.5 * 0.6911)
+        assert np.allclose(v["focal_length"], f, rtol=1e-5)
+        xs.append(v["matrix"])
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = [3.0, 4.0, -1.0]
+    assert np.allclose(xs[0], scene_mod.nerf_matrix_to_ngp(m), atol=1e-6)
+    # per-json overrides: scale/offset/fl_x/cx
+    ctx.load_training_data(_write_transforms(tmp_path, scale=0.5, offset=[0.1, 0.2, 0.3], fl_x=1000.0, cx=200.0, cy=150.0))
+    info = ctx.dataset_info()
+    assert abs(info["scale"] - 0.5) < 1e-7 and np.allclose(info["offset"], [0.1, 0.2, 0.3])
+    v = ctx.training_view(2)
+    assert np.allclose(v["focal_length"], 1000.0) and np.allclose(v["principal_point"], [0.25, 0.25])
+    with pytest.raises(RuntimeError, match="json file or a directory"):
+        ctx.load_training_data(str(tmp_path / "nope.txt"))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        ctx.load_training_data(str(tmp_path / "missing.json"))
+    (tmp_path / "bad.json").write_text("{\"frames\": [")
+    with pytest.raises(RuntimeError, match="json parse error"):
+        ctx.load_training_data(str(tmp_path / "bad.json"))
+    ctx.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference mount not present (GPU box)")
+def test_reference_datasets_load(native):
+    """The reference's own data files (SURVEY 8c 'usable inputs'): fox keeps the 50 frames whose images exist."""
+    ctx = native.Context(-1)
+    ctx.load_training_data(os.path.join(REF, "data/nerf/fox"))
+    assert ctx.n_training_views() == 50
+    assert ctx.dataset_info()["aabb_scale"] == 4
+    v = ctx.training_view(0)
+    assert v["resolution"].tolist() == [1080, 1920] and abs(v["focal_length"][0] - 1375.52) < 1e-2
+    assert np.allclose(v["principal_point"], [554.558 / 1080, 965.268 / 1920], atol=1e-6)
+    ctx.load_training_data(os.path.join(REF, "data/test3/images/transforms_train.json"))
+    assert ctx.n_training_views() == 150
+    info = ctx.dataset_info()
+    assert info["aabb_scale"] == 1 and np.allclose(info["offset"], [0.5, 0.5, 0.0])
+    ctx.close()
+
+
+def test_snapshot_formats_roundtrip(tmp_path, native):
+    import msgpack
+
+    sc = pkg("synthetic").make_scene(aabb_scale=2, seed=5, log2_hashmap_size=12, pls_rule="upstream")
+    ctx = native.Context(-1)
+    ctx.set_model(sc)
+    for name in ("s.msgpack", "s.ingp"):
+        p = str(tmp_path / name)
+        ctx.save_snapshot_file(p)
+        raw = open(p, "rb").read()
+        if name.endswith(".ingp"):
+            raw = gzip.decompress(raw)  # zstr writes a gzip container
+        root = msgpack.unpackb(raw, raw=False)
+        snap = root["snapshot"]
+        assert snap["version"] == 1 and snap["mode"] == "nerf" and snap["density_grid_size"] == 128
+        assert snap["n_params"] == sc["params"].size and snap["params_type"] == "__half"
+        assert np.array_equal(np.frombuffer(snap["params_binary"], np.uint16), sc["params"])
+        assert np.array_equal(np.frombuffer(snap["density_grid_binary"], np.float16), np.asarray(sc["density_grid"], np.float16))
+        assert snap["nerf"]["aabb_scale"] == 2 and root["encoding"]["n_levels"] == 8
+        assert abs(root["encoding"]["per_level_scale"] - sc["encoding"]["per_level_scale"]) < 1e-7
+        ctx2 = native.Context(-1)
+        ctx2.load_snapshot_file(p)
+        d = ctx2.get_model()
+        assert d.n_params == sc["params"].size and d.aabb_scale == 2 and d.n_density_grid == 2 * 128 ** 3
+        assert abs(d.cone_angle_constant - 1 / 256) < 1e-9 and list(d.aabb_min) == [-0.5] * 3 and list(d.aabb_max) == [1.5] * 3
+        ctx2.close()
+    # a snapshot written by another msgpack encoder (python) with float32 params loads too
+    root["snapshot"]["params_type"] = "float"
+    root["snapshot"]["params_binary"] = sc["params"].view(np.float16).astype(np.float32).tobytes()
+    blob = msgpack.packb(root, use_bin_type=True)
+    ctx3 = native.Context(-1)
+    ctx3.load_snapshot_bytes(blob)
+    assert ctx3.get_model().n_params == sc["params"].size
+    # error paths (Testbed::load_snapshot throws, src/testbed.cu:5285-5352)
+    bad = dict(root)
+    bad["snapshot"] = dict(root["snapshot"], version=0)
+    with pytest.raises(RuntimeError, match="old format"):
+        ctx3.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    bad["snapshot"] = dict(root["snapshot"], density_grid_size=64)
+    with pytest.raises(RuntimeError, match="Incompatible grid size"):
+        ctx3.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    bad["snapshot"] = dict(root["snapshot"], density_grid_binary=b"\0" * 100)
+    with pytest.raises(RuntimeError, match="grid cascades"):
+        ctx3.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    bad["snapshot"] = dict(root["snapshot"], params_binary=b"\0" * 64)
+    with pytest.raises(RuntimeError, match="parameter count mismatch|n_params"):
+        ctx3.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    with pytest.raises(RuntimeError, match="does not contain a snapshot"):
+        ctx3.load_snapshot_bytes(msgpack.packb({"encoding": {}}, use_bin_type=True))
+    with pytest.raises(RuntimeError, match="truncated|msgpack"):
+        ctx3.load_snapshot_bytes(blob[: len(blob) // 2])
+    with pytest.raises(RuntimeError, match="inflate|corrupt"):
+        ctx3.load_snapshot_bytes(b"not a gzip stream", compressed=True)
+    ctx3.close()
+    ctx.close()
+
+
+def test_model_validation(native):
+    sc = pkg("synthetic").make_scene(aabb_scale=1, seed=5, log2_hashmap_size=12)
+    ctx = native.Context(-1)
+    for key, val, msg in (("aabb_scale", 3, "power of two"), ("aabb_scale", 256, "aabb_scale <= 128")):
+        bad = dict(sc)
+        bad[key] = val
+        with pytest.raises(RuntimeError, match=msg):
+            ctx.set_model(bad)
+    bad = dict(sc)
+    bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=3)
+    with pytest.raises(RuntimeError, match="unsupported network architecture"):
+        ctx.set_model(bad)
+    ctx.close()
+
+
+def test_scene_conventions(scene_mod):
+    # nerf_matrix_to_ngp (nerf_loader.h:101-120) on the identity pose
+    m = scene_mod.nerf_matrix_to_ngp(np.eye(4, dtype=np.float32))
+    assert np.allclose(m, [[0, -1, 0, 0.5], [0, 0, -1, 0.5], [1, 0, 0, 0.5]])
+    cam = scene_mod.orbit_camera(45.0)
+    R = cam[:, :3]
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-5)
+    to_centre = np.array([0.5, 0.5, 0.5]) - cam[:, 3]
+    assert np.allclose(to_centre / np.linalg.norm(to_centre), R[:, 2], atol=1e-5)  # +z looks at the scene centre
+    assert abs(np.linalg.norm(to_centre) - 4.03 * 0.33) < 1e-4
+    assert scene_mod.per_level_scale(16, 8, 16, "fork") == 2.0
+    assert abs(scene_mod.per_level_scale(16, 8, 16, "upstream") - 2.9720) < 1e-3
+    assert abs(scene_mod.per_level_scale(4, 8, 16, "upstream") - 2.4380) < 1e-3
+    off, res, _ = scene_mod.grid_layout(dict(scene_mod.base_network_config()["encoding"], per_level_scale=2.0))
+    assert res == [16, 32, 64, 128, 256, 512, 1024, 2048] and off[-1] == 2920448  # 23.36 MB of fp16x4
+
+
+def _gloo_worker(rank, world, port, w, h, q):
+    import torch
+    import torch.distributed as dist
+
+    par = pkg("parallel")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    full = torch.rand((h, w, 5), generator=g)
+    # a rank "renders" only its own tiles (what ngp_render_device does with shard_index/shard_count)
+    mine = torch.zeros_like(full)
+    tx, ty = par.tile_grid(w, h)
+    for t in par.local_tiles(w, h, rank, world).tolist():
+        y0, x0 = (t // tx) * 8, (t % tx) * 8
+        mine[y0:y0 + 8, x0:x0 + 8] = full[y0:y0 + 8, x0:x0 + 8]
+    out = par.gather_frame(mine, w, h, rank, world)
+    q.put((rank, bool(torch.equal(out, full))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (101, 67)])
+def test_tile_sharding_gather_gloo_world2(w, h):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + w) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, w, h, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
+def test_tile_pack_unpack_roundtrip():
+    import torch
+
+    par = pkg("parallel")
+    for (w, h, world) in ((1920, 1080, 8), (37, 21, 3), (8, 8, 2)):
+        img = torch.rand((h, w, 5))
+        n = par.slots_per_rank(w, h, world)
+        packed = torch.stack([par.pack_tiles(img, w, h, r, world, n) for r in range(world)])
+        assert torch.equal(par.unpack_tiles(packed, w, h, world), img)
+        assert sum(par.local_tiles(w, h, r, world).numel() for r in range(world)) == par.tile_grid(w, h)[0] * par.tile_grid(w, h)[1]

@@ -1,0 +1,271 @@
+"""CPU tests of the oracle: committed golden vectors, fp16 emulation, and an independent numpy restatement of the
+hash-grid / SH / MLP arithmetic (the oracle is PARITY UNPINNED by the reference, so it is pinned here against a
+second, differently written implementation and against size-independent properties)."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "nerf_unit_v1.npz"))
+
+
+@pytest.fixture(scope="module")
+def golden_inputs(oracle):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    sc, pos, dir01, cam_matrix, focal = mg.build_inputs()
+    grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
+    sc["density_grid_bitfield"], sc["density_grid_mean"] = oracle.density_grid_to_bitfield(grid, sc["max_cascade"])
+    return sc, pos, dir01, cam_matrix, focal, mg
+
+
+def test_fixture_inputs_are_reproducible(golden, golden_inputs):
+    sc = golden_inputs[0]
+    sha = hashlib.sha256(np.ascontiguousarray(sc["params"]).tobytes()).digest()
+    assert np.array_equal(np.frombuffer(sha, np.uint8), golden["params_sha256"]), "seeded parameter stream changed (numpy version?)"
+    sha = hashlib.sha256(np.asarray(sc["density_grid"], np.float16).tobytes()).digest()
+    assert np.array_equal(np.frombuffer(sha, np.uint8), golden["density_grid_sha256"])
+
+
+def test_oracle_matches_golden_vectors(oracle, golden, golden_inputs):
+    sc, pos, dir01, cam_matrix, focal, mg = golden_inputs
+    assert np.array_equal(pos, golden["pos"]) and np.array_equal(dir01, golden["dir01"])
+    sha = hashlib.sha256(sc["density_grid_bitfield"].tobytes()).digest()
+    assert np.array_equal(np.frombuffer(sha, np.uint8), golden["bitfield_sha256"])
+    assert np.float32(sc["density_grid_mean"]) == golden["bitfield_mean"]
+    m = oracle.make_model(sc)
+    assert np.array_equal(oracle.grid_encode(m, pos).view(np.uint16), golden["enc"])
+    assert np.array_equal(oracle.sh4(dir01).view(np.uint16), golden["sh"])
+    assert np.array_equal(oracle.network(m, pos, dir01).view(np.uint16), golden["net"])
+    cam = oracle.make_camera(cam_matrix, mg.W, mg.H, focal)
+    assert np.array_equal(oracle.init_rays(m, cam).view(np.uint8), golden["payloads"])
+    fb, db, st = oracle.render_nerf(m, cam)
+    assert np.array_equal(fb, golden["frame"]) and np.array_equal(db, golden["depth"])
+    assert [st["n_rays"], st["n_rays_alive_after_init"], st["n_rays_hit"], st["n_samples"]] == golden["stats"].tolist()
+    vals = np.array([oracle.ld_random_val(i, s) for i in range(8) for s in (0, 786433, 0xdeadbeef)], np.float32)
+    assert np.array_equal(vals, golden["ld_vals"])
+    assert np.array_equal(np.stack([oracle.pixel_offset(s) for s in range(6)]), golden["pixel_offsets"])
+    oracle.release(m)
+
+
+def test_fp16_emulation_matches_ieee(oracle):
+    import ctypes as C
+
+    # the emulation lives in a header; exercise it through the SH encoder's float->half and the grid's half->float
+    lib = oracle.lib
+    # 1) every binary16 value survives half->float->half: build a 1-level dense grid holding all 65536 patterns
+    # (done implicitly by test_grid_encode_against_numpy); here: float->half rounding on random floats vs numpy
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.normal(scale=s, size=4000) for s in (1e-7, 1e-4, 1.0, 100.0, 3e4)]).astype(np.float32)
+    x = np.concatenate([x, np.float32([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e9, 5.96e-8, 2.98e-8, 2.9802325e-8, 6.1e-5, np.inf, -np.inf])])
+    # orc_sh4: out[3] = -0.4886..*x with dir01 -> use the dedicated rounding path instead: SH coefficient 2 is 0.4886*z
+    # simpler and exact: coefficient 0 is a constant, so test conversion through the pixel path is not possible;
+    # use the exported tonemap? No -- call the static inline via a tiny shim compiled on the fly.
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent('''
+        #include "orc_common.h"
+        void conv(int n, const float* in, unsigned short* out) { for (int i = 0; i < n; ++i) out[i] = orc_float_to_half(in[i]); }
+        void back(int n, const unsigned short* in, float* out) { for (int i = 0; i < n; ++i) out[i] = orc_half_to_float(in[i]); }
+        void add(int n, const unsigned short* a, const unsigned short* b, unsigned short* out) { for (int i = 0; i < n; ++i) out[i] = orc_half_add(a[i], b[i]); }
+    ''')
+    with tempfile.TemporaryDirectory() as td:
+        cpath = os.path.join(td, "shim.c")
+        open(cpath, "w").write(src)
+        so = os.path.join(td, "shim.so")
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-I", os.path.join(os.path.dirname(HERE), "oracle"), cpath, "-o", so, "-lm"], check=True)
+        shim = C.CDLL(so)
+        out = np.zeros(x.size, np.uint16)
+        shim.conv(x.size, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        with np.errstate(over="ignore"):
+            ref = x.astype(np.float16).view(np.uint16)
+        assert np.array_equal(out, ref)
+        allh = np.arange(65536, dtype=np.uint16)
+        f = np.zeros(65536, np.float32)
+        shim.back(65536, allh.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+        reff = allh.view(np.float16).astype(np.float32)
+        assert np.array_equal(f.view(np.uint32)[~np.isnan(reff)], reff.view(np.uint32)[~np.isnan(reff)])
+        a = rng.integers(0, 0x7c00, 200000).astype(np.uint16) | (rng.integers(0, 2, 200000).astype(np.uint16) << 15)
+        b = rng.integers(0, 0x7c00, 200000).astype(np.uint16) | (rng.integers(0, 2, 200000).astype(np.uint16) << 15)
+        s = np.zeros(200000, np.uint16)
+        shim.add(200000, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+        with np.errstate(over="ignore"):
+            refs = (a.view(np.float16).astype(np.float64) + b.view(np.float16).astype(np.float64)).astype(np.float16)
+        assert np.array_equal(s.view(np.float16).astype(np.float32), refs.astype(np.float32))
+
+
+def _grid_encode_numpy(sc, scene_mod, pos, scales=None):
+    """Independent restatement of tcnn's kernel_grid with numpy float16 arithmetic."""
+    enc = sc["encoding"]
+    F = enc["n_features_per_level"]
+    offsets, resolutions, py_scales = scene_mod.grid_layout(enc)
+    scales = py_scales if scales is None else scales
+    nd, nr, ng = scene_mod.n_params(sc)
+    table = sc["params"][nd + nr:].view(np.float16)
+    out = np.zeros((pos.shape[0], enc["n_levels"] * F), np.float16)
+    for l in range(enc["n_levels"]):
+        size = offsets[l + 1] - offsets[l]
+        lvl = table[offsets[l] * F:offsets[l + 1] * F].reshape(size, F)
+        p = (np.float64(np.float32(scales[l])) * pos.astype(np.float64) + 0.5).astype(np.float32)  # fmaf: single rounding
+        fl = np.floor(p)
+        w = (p - fl).astype(np.float32)
+        g = fl.astype(np.int64).astype(np.uint32)
+        res = np.uint32(resolutions[l])
+        acc = np.zeros((pos.shape[0], F), np.float16)
+        for c in range(8):
+            wt = np.ones(pos.shape[0], np.float32)
+            gl = []
+            for d in range(3):
+                if c & (1 << d):
+                    wt = (wt * w[:, d]).astype(np.float32)
+                    gl.append(g[:, d] + np.uint32(1))
+                else:
+                    wt = (wt * (np.float32(1) - w[:, d])).astype(np.float32)
+                    gl.append(g[:, d])
+            if res.astype(np.uint64) ** 3 <= size:
+                idx = gl[0] + gl[1] * res + gl[2] * res * res
+            else:
+                idx = gl[0] ^ (gl[1] * np.uint32(2654435761)) ^ (gl[2] * np.uint32(805459861))
+            idx = idx % np.uint32(size)
+            prod = (wt[:, None] * lvl[idx].astype(np.float32)).astype(np.float32).astype(np.float16)
+            acc = (acc.astype(np.float64) + prod.astype(np.float64)).astype(np.float16)
+        out[:, l * F:(l + 1) * F] = acc
+    return out
+
+
+@pytest.mark.parametrize("which", ["unit", "big"])
+def test_grid_encode_against_numpy(which, oracle, scene_mod, scene_unit, scene_big):
+    sc = scene_unit if which == "unit" else scene_big
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(9)
+    pos = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    pos[:3] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5]]
+    # the per-level scale exp2f(l * log2f(b)) * N_min - 1 is evaluated by the C library (glibc here, as in the HIP
+    # build's host code); numpy's float32 exp2/log2 can differ by an ulp, so the restatement takes the scales as data
+    off, res, scl = oracle.grid_layout(m)
+    with np.errstate(over="ignore"):
+        ref = _grid_encode_numpy(sc, scene_mod, pos, scl)
+    got = oracle.grid_encode(m, pos)
+    assert np.array_equal(got.astype(np.float32), ref.astype(np.float32))
+    # layout agrees with the host-side table used for sizing
+    o2, r2, s2 = scene_mod.grid_layout(sc["encoding"])
+    assert off.tolist() == o2 and res.tolist() == r2 and np.allclose(scl, s2, rtol=1e-6)
+    oracle.release(m)
+
+
+def test_network_against_numpy_float64(oracle, scene_mod, scene_unit):
+    sc = scene_unit
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(10)
+    pos = rng.uniform(0.2, 0.8, (512, 3)).astype(np.float32)
+    d = rng.normal(size=(512, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dir01 = ((d + 1) * 0.5).astype(np.float32)
+    enc = oracle.grid_encode(m, pos).astype(np.float64)
+    sh = oracle.sh4(dir01).astype(np.float64)
+    p = sc["params"].view(np.float16).astype(np.float64)
+    W0, W1 = p[:2048].reshape(64, 32), p[2048:3072].reshape(16, 64)
+    R0, R1, R2 = p[3072:5120].reshape(64, 32), p[5120:9216].reshape(64, 64), p[9216:10240].reshape(16, 64)
+
+    def h(x):
+        return x.astype(np.float32).astype(np.float16).astype(np.float64)
+
+    dens = h(h(np.maximum(enc @ W0.T, 0)) @ W1.T)
+    rin = np.concatenate([dens, sh], axis=1)
+    rgb = h(h(np.maximum(h(np.maximum(rin @ R0.T, 0)) @ R1.T, 0)) @ R2.T)
+    ref = np.concatenate([rgb[:, :3], dens[:, :1]], axis=1)
+    got = oracle.network(m, pos, dir01).astype(np.float64)
+    assert np.array_equal(got, ref)
+    # real spherical harmonics: band energies of a unit vector are rotation invariant, sum_m Y_lm^2 = (2l+1)/(4 pi)
+    shf = oracle.sh4(dir01).astype(np.float64)
+    for l, (a, b) in enumerate(((0, 1), (1, 4), (4, 9), (9, 16))):
+        assert np.allclose((shf[:, a:b] ** 2).sum(1), (2 * l + 1) / (4 * np.pi), rtol=4e-3)
+    oracle.release(m)
+
+
+def test_sampling_sequences(oracle):
+    # Owen-scrambled Sobol: values in [0,1], deterministic, and (0,2)-stratified: any 2^k consecutive indices hit
+    # every dyadic interval of length 2^-k once
+    for seed in (0, 786433 * 5, 0xdeadbeef):
+        v = np.array([oracle.ld_random_val(i, seed) for i in range(64)])
+        assert (v >= 0).all() and (v <= 1).all()
+        for k in (3, 4, 5, 6):
+            assert sorted(np.minimum((v[: 1 << k] * (1 << k)).astype(int), (1 << k) - 1).tolist()) == list(range(1 << k))
+    off = oracle.pixel_offset(0)
+    assert np.allclose(off, 0.5, atol=1e-6)  # sample 0 / snap_to_pixel_centers is the pixel centre
+    assert not np.allclose(oracle.pixel_offset(1), 0.5)
+
+
+def test_bitfield_properties(oracle, scene_mod, scene_big):
+    sc = scene_big
+    grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
+    bf = sc["density_grid_bitfield"]
+    n = 128 ** 3
+    assert bf.size == n // 8 * 8
+    bits = np.unpackbits(bf, bitorder="little").reshape(8, n)
+    thresh = min(0.01, sc["density_grid_mean"])
+    # level 0 is the thresholded grid
+    assert np.array_equal(bits[0], (grid[:n] > thresh).astype(np.uint8))
+    # max-pool: a set cell at level k implies its parent cell at level k+1 is set (parent = centred half)
+    idx = np.arange(128, dtype=np.uint32)
+    X, Y, Z = np.meshgrid(idx, idx, idx, indexing="ij")
+    mort = scene_mod.morton3d(X.ravel(), Y.ravel(), Z.ravel())
+    parent = scene_mod.morton3d(X.ravel() // 2 + 32, Y.ravel() // 2 + 32, Z.ravel() // 2 + 32)
+    for k in range(7):
+        child_set = bits[k][mort] == 1
+        assert bits[k + 1][parent][child_set].all()
+    assert bits[7].any()
+    # an empty grid gives an empty bitfield
+    bf0, mean0 = oracle.density_grid_to_bitfield(np.zeros(n, np.float32), 0)
+    assert mean0 == 0.0 and not bf0.any()
+
+
+def test_render_properties(oracle, scene_mod, scene_unit):
+    sc = dict(scene_unit)
+    m = oracle.make_model(sc)
+    w, h = 40, 24
+    cam = oracle.make_camera(scene_mod.orbit_camera(45.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+    fb, db, st = oracle.render_nerf(m, cam)
+    assert st["n_rays_hit"] > 0
+    a = fb[..., 3]
+    assert (a >= 0).all() and (a <= 1.0 + 1e-6).all()
+    assert ((a > 0.989) | (a < 0.99)).all()
+    # alpha == 1 exactly where the ray terminated early (rgba /= a); premultiplied colours never exceed alpha
+    assert (fb[..., :3].max(-1) <= a + 1e-5).all()
+    assert np.array_equal(db[a == 0], np.full((a == 0).sum(), 16384.0, np.float32))
+    # stricter transmittance threshold -> at least as many samples
+    fb2, _, st2 = oracle.render_nerf(m, cam, oracle.make_opts(min_transmittance=1e-4))
+    assert st2["n_samples"] > st["n_samples"] and st2["n_rays_hit"] == st["n_rays_hit"]
+    # threads do not change the result
+    fb3, db3, _ = oracle.render_nerf(m, cam, oracle.make_opts(n_threads=1))
+    assert np.array_equal(fb, fb3) and np.array_equal(db, db3)
+    # empty occupancy -> nothing is rendered
+    sc["density_grid_bitfield"] = np.zeros_like(sc["density_grid_bitfield"])
+    m2 = oracle.make_model(sc)
+    fb4, _, st4 = oracle.render_nerf(m2, cam)
+    assert st4["n_samples"] == 0 and not fb4.any()
+    oracle.release(m)
+    oracle.release(m2)
+
+
+def test_post_pass(oracle):
+    rng = np.random.default_rng(2)
+    fb = rng.uniform(0, 1, (50, 4)).astype(np.float32)
+    acc = oracle.accumulate(fb, np.zeros_like(fb), 0)
+    assert np.array_equal(acc, fb)
+    acc2 = oracle.accumulate(np.zeros_like(fb), acc, 1)
+    assert np.allclose(acc2, fb / 2)
+    out = oracle.tonemap(acc, (1.0, 1.0, 1.0, 1.0), 0.0, False)
+    assert np.allclose(out[:, 3], 1.0) and np.allclose(out[:, :3], fb[:, :3] + (1 - fb[:, 3:4]), atol=1e-6)
+    srgb = oracle.tonemap(acc, (0, 0, 0, 0), 1.0, True)
+    lin = oracle.tonemap(acc, (0, 0, 0, 0), 1.0, False)
+    back = np.array([[oracle.lib.orc_srgb_to_linear(float(v)) for v in row[:3]] for row in srgb])
+    assert np.allclose(back, lin[:, :3], rtol=2e-3, atol=1e-4)  # the reference's 0.41666 exponent is not the exact inverse
+    assert np.allclose(lin[:, :3], acc[:, :3] * 2.0)
