@@ -29,6 +29,9 @@ enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, 
 /* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
 enum ngp_render_mode { NGP_RENDER_SHADE = 0 };
 
+/* ETestbedMode subset (common.h:35-43): Nerf, and the fork's Geometry mode (meshes + NeRF, depth composited) */
+enum ngp_testbed_mode { NGP_MODE_NERF = 0, NGP_MODE_GEOMETRY = 1 };
+
 /* What Testbed::reset_network (src/testbed.cu:3844-4212) + load_nerf_post (src/testbed_nerf.cu:2652-2739)
  * + the snapshot (src/testbed.cu:5285-5463) leave behind for rendering. */
 typedef struct ngp_model_desc {
@@ -79,7 +82,15 @@ typedef struct ngp_render_opts {
 	int32_t spp;              /* samples accumulated by ngp_render */
 	/* camera-tile sharding across GPUs: this context renders 8x8-pixel tiles t with t % shard_count == shard_index */
 	uint32_t shard_index, shard_count;
+	int32_t testbed_mode;     /* ngp_testbed_mode: Geometry = render_geometry_mesh then render_geometry_nerf (src/testbed.cu:4833-4889) */
 } ngp_render_opts;
+
+/* BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir (testbed.h:875-876) used by shade_kernel_mesh_geometry */
+typedef struct ngp_geometry_opts {
+	float sun_dir[3], up_dir[3];
+	float metallic, subsurface, specular, roughness, sheen, clearcoat, clearcoat_gloss;
+	float basecolor[3], ambientcolor[3];
+} ngp_geometry_opts;
 
 typedef struct ngp_render_stats {
 	uint64_t n_rays;
@@ -143,6 +154,25 @@ NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean
 /* K1+K2 init_rays_with_payload_kernel_nerf + advance_pos_nerf_kernel (src/testbed_nerf.cu:1428-1544,333-381):
  * out: W*H NerfPayload records of 40 bytes (nerf_device.cuh:144-152) */
 NGP_API int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out);
+
+
+/* --- geometry mode: Testbed::load_scene / load_mesh (src/testbed_geometry_training.cu:3101-3210, 2786-2866)
+ * load_scene: {"geometry":[{"center":[x,y,z],"path":..., "type":"Mesh"|"Nerf"}]}; Mesh -> load_mesh (.obj/.stl),
+ * Nerf -> load_snapshot. Relative paths resolve against the json's directory. */
+NGP_API int ngp_load_scene(ngp_ctx* ctx, const char* json_path);
+/* load_mesh on triangles already in memory: vertices = n_tris*9 floats in file space; normalised into the unit cube
+ * around `center`, BVH4 (8 triangles per leaf) built on the host, uploaded. Rebuilds the scene AABB. */
+NGP_API int ngp_add_mesh(ngp_ctx* ctx, const float* vertices, uint32_t n_tris, const float* center3);
+NGP_API int ngp_load_mesh_file(ngp_ctx* ctx, const char* path, const float* center3);
+NGP_API int ngp_clear_meshes(ngp_ctx* ctx);
+NGP_API int ngp_n_meshes(const ngp_ctx* ctx);
+/* per mesh: triangle / node counts and the mesh AABB; mesh = -1: the scene AABB (root inflated by 4) */
+NGP_API int ngp_get_mesh_info(const ngp_ctx* ctx, int mesh, uint32_t* n_tris, uint32_t* n_nodes, float* aabb6);
+/* the built BVH: nodes (n_nodes x 32 B: bb.min, bb.max, left_idx, right_idx) and reordered triangles (n_tris x 36 B) */
+NGP_API int ngp_get_mesh_bvh(const ngp_ctx* ctx, int mesh, void* nodes_out, void* triangles_out);
+NGP_API int ngp_set_geometry_opts(ngp_ctx* ctx, const ngp_geometry_opts* opts);
+/* M2 mesh_raytrace_kernel (src/geometry_bvh.cu:646-676): host positions / directions n x 3, updated in place */
+NGP_API int ngp_trace_mesh_rays(ngp_ctx* ctx, uint32_t n, float* positions, float* directions);
 
 #ifdef __cplusplus
 }

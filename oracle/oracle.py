@@ -85,6 +85,15 @@ class RenderStats(C.Structure):
     ]
 
 
+class MeshOpts(C.Structure):
+    _fields_ = [
+        ("sun_dir", C.c_float * 3), ("up_dir", C.c_float * 3),
+        ("metallic", C.c_float), ("subsurface", C.c_float), ("specular", C.c_float), ("roughness", C.c_float),
+        ("sheen", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
+        ("basecolor", C.c_float * 3), ("ambientcolor", C.c_float * 3),
+    ]
+
+
 PAYLOAD_DTYPE = np.dtype(
     [("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"), ("max_weight", "<f4"), ("idx", "<u4"),
      ("n_steps", "<u2"), ("alive", "u1"), ("pad", "u1")]
@@ -288,6 +297,56 @@ class Oracle:
         self.lib.orc_tonemap(acc.size // 4, _ptr(acc), _ptr(bg), float(exposure), int(to_srgb), _ptr(out))
         return out
 
-    # ------------------------------------------------------------------ mesh (orc_mesh.c); bound lazily
+    # ------------------------------------------------------------------ mesh (orc_mesh.c)
     def _bind_mesh(self):
-        pass
+        L = self.lib
+        L.orc_mesh_scene_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
+        L.orc_mesh_scene_create.restype = C.c_void_p
+        L.orc_mesh_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_mesh_scene_aabb.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_mesh_scene_n_nodes.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_mesh_scene_n_nodes.restype = C.c_uint32
+        L.orc_trace_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_render_mesh.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(MeshOpts), C.c_void_p, C.c_void_p]
+
+    def mesh_scene(self, meshes):
+        """meshes: list of (vertices float32 (n_tris, 3, 3) in file space, center (3,))."""
+        n = len(meshes)
+        verts = [np.ascontiguousarray(v, np.float32).reshape(-1) for v, _ in meshes]
+        ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in verts])
+        ntris = np.array([v.size // 9 for v in verts], np.uint32)
+        centers = np.ascontiguousarray(np.array([c for _, c in meshes], np.float32))
+        h = self.lib.orc_mesh_scene_create(n, ptrs, _ptr(ntris), _ptr(centers))
+        return h
+
+    def mesh_scene_aabb(self, h):
+        out = np.zeros(6, np.float32)
+        self.lib.orc_mesh_scene_aabb(h, _ptr(out))
+        return out[:3].copy(), out[3:].copy()
+
+    def mesh_scene_destroy(self, h):
+        self.lib.orc_mesh_scene_destroy(h)
+
+    def trace_mesh(self, h, positions, directions):
+        p = np.ascontiguousarray(positions, np.float32).copy()
+        d = np.ascontiguousarray(directions, np.float32).copy()
+        self.lib.orc_trace_mesh(h, p.shape[0], _ptr(p), _ptr(d))
+        return p, d
+
+    @staticmethod
+    def make_mesh_opts(sun_dir=(1.0, 1.0, 1.0), up_dir=(0.0, 1.0, 0.0), metallic=0.0, subsurface=0.0, specular=1.0, roughness=0.5, sheen=0.0,
+                       clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0)):
+        o = MeshOpts()
+        for i in range(3):
+            o.sun_dir[i], o.up_dir[i], o.basecolor[i], o.ambientcolor[i] = sun_dir[i], up_dir[i], basecolor[i], ambientcolor[i]
+        o.metallic, o.subsurface, o.specular, o.roughness = metallic, subsurface, specular, roughness
+        o.sheen, o.clearcoat, o.clearcoat_gloss = sheen, clearcoat, clearcoat_gloss
+        return o
+
+    def render_mesh(self, h, cam, opts=None):
+        opts = opts or self.make_mesh_opts()
+        n = cam.width * cam.height
+        fb = np.zeros((n, 4), np.float32)
+        db = np.zeros(n, np.float32)
+        self.lib.orc_render_mesh(h, C.byref(cam), C.byref(opts), _ptr(fb), _ptr(db))
+        return fb.reshape(cam.height, cam.width, 4), db.reshape(cam.height, cam.width)

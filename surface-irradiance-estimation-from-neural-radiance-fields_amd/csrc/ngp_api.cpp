@@ -18,48 +18,6 @@ using namespace ngp;
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------ helpers
-template <typename F>
-int guarded(ngp_ctx* ctx, F&& f) {
-	if (!ctx) return -1;
-	try {
-		if (ctx->device >= 0) NGP_HIP_CHECK(hipSetDevice(ctx->device));
-		f();
-		ctx->error.clear();
-		return 0;
-	} catch (const std::exception& e) {
-		ctx->error = e.what();
-		return -1;
-	}
-}
-
-std::string read_file(const std::string& path) {
-	std::ifstream f(path, std::ios::in | std::ios::binary);
-	if (!f) throw std::runtime_error("cannot open '" + path + "'");
-	std::stringstream ss;
-	ss << f.rdbuf();
-	return ss.str();
-}
-
-bool file_exists(const std::string& p) {
-	struct stat st;
-	return stat(p.c_str(), &st) == 0;
-}
-bool is_directory(const std::string& p) {
-	struct stat st;
-	return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
-}
-std::string parent_dir(const std::string& p) {
-	size_t k = p.find_last_of('/');
-	return k == std::string::npos ? std::string(".") : p.substr(0, k);
-}
-bool ends_with_ci(const std::string& s, const std::string& suffix) {
-	if (s.size() < suffix.size()) return false;
-	for (size_t i = 0; i < suffix.size(); ++i)
-		if (tolower(s[s.size() - suffix.size() + i]) != tolower(suffix[i])) return false;
-	return true;
-}
-
 uint16_t float_to_half(float f) { // round to nearest even, for "params_type": "float" snapshots
 	uint32_t x;
 	memcpy(&x, &f, 4);
@@ -764,7 +722,7 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 // Testbed::render_frame (src/testbed.cu:4694-4721) for opts->spp samples; the final image lands in d_rgba_out.
 void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba_out, float* d_depth_out, hipStream_t stream) {
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
-	if (!ctx->model_loaded) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
+	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
 	if (opts.render_mode != NGP_RENDER_SHADE) throw std::runtime_error("only render_mode Shade is implemented");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
@@ -787,7 +745,15 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.n_local_tiles = n_tiles > opts.shard_index ? (n_tiles - opts.shard_index + shard_count - 1) / shard_count : 0;
 	F.min_transmittance = opts.min_transmittance;
 	F.linear_colors = ctx->desc.linear_colors;
-	F.depth_test = 0;
+	const bool geometry = opts.testbed_mode == NGP_MODE_GEOMETRY;
+	const bool have_meshes = geometry && !ctx->meshes.empty();
+	F.depth_test = geometry ? 1 : 0; // shade_kernel_nerf_geometry
+	ModelParams M = ctx->M;
+	if (have_meshes) { // load_scene sets m_render_aabb to the inflated mesh bb (testbed_geometry_training.cu:3185-3189)
+		for (int i = 0; i < 3; ++i) { M.raabb_min[i] = ctx->mesh_scene.scene_min[i]; M.raabb_max[i] = ctx->mesh_scene.scene_max[i]; }
+		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		memcpy(M.r2l, ident, sizeof(ident));
+	}
 
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 	NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
@@ -798,12 +764,13 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		NGP_HIP_CHECK(hipMemsetAsync(F.depth_buffer, 0, n_pixels * sizeof(float), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
 		const bool last = s == spp - 1;
+		if (have_meshes) launch_render_mesh(ctx->mesh_scene, ctx->shade, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, stream);
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
 		// persistent grid: 4 workgroups of 4 waves per CU; surplus waves find the queue empty and exit
 		int n_blocks = ctx->n_cus * 4;
 		const int needed = (int)((F.n_local_tiles + 3) / 4);
 		if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-		launch_render_nerf(ctx->M, C, F, n_blocks, stream);
+		if (ctx->model_loaded) launch_render_nerf(M, C, F, n_blocks, stream);
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, last ? d_rgba_out : nullptr, stream);
 	}
@@ -815,6 +782,16 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 }
 
 } // namespace
+
+namespace ngp {
+void load_snapshot_path(ngp_ctx* ctx, const std::string& p) {
+	std::string data = read_file(p);
+	bool compressed = ends_with_ci(p, ".ingp"); // testbed.cu:262-266
+	if (!compressed && !ends_with_ci(p, ".msgpack")) throw std::runtime_error("snapshot must be a .msgpack or .ingp file");
+	if (compressed) data = inflate_all(data.data(), data.size());
+	load_snapshot_value(ctx, mj::MsgpackReader((const uint8_t*)data.data(), data.size()).parse());
+}
+} // namespace ngp
 
 // ================================================================================================== C ABI
 extern "C" {
@@ -847,6 +824,11 @@ void ngp_destroy(ngp_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
 	free_model(ctx);
+	for (auto& m : ctx->meshes) {
+		if (m.d_tris) (void)hipFree(m.d_tris);
+		if (m.d_nodes) (void)hipFree(m.d_nodes);
+	}
+	if (ctx->d_meshrefs) (void)hipFree(ctx->d_meshrefs);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->d_depth) (void)hipFree(ctx->d_depth);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -887,12 +869,7 @@ int ngp_load_snapshot(ngp_ctx* ctx, const void* bytes, size_t n_bytes, int is_co
 int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path) {
 	return guarded(ctx, [&] {
 		if (!path) throw std::runtime_error("null path");
-		std::string p = path;
-		std::string data = read_file(p);
-		bool compressed = ends_with_ci(p, ".ingp"); // testbed.cu:262-266
-		if (!compressed && !ends_with_ci(p, ".msgpack")) throw std::runtime_error("snapshot must be a .msgpack or .ingp file");
-		if (compressed) data = inflate_all(data.data(), data.size());
-		load_snapshot_value(ctx, mj::MsgpackReader((const uint8_t*)data.data(), data.size()).parse());
+		ngp::load_snapshot_path(ctx, path);
 	});
 }
 

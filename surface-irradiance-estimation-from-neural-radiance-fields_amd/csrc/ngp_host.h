@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,6 +32,19 @@ void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_gri
                                      uint8_t* d_bitfield, float* out_mean, hipStream_t stream);
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
                                float exposure, int to_srgb, float4* rgba_out, hipStream_t stream);
+
+void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
+                        uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
+void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream);
+
+struct HostMesh { // MeshData (mesh.h:18-24) after load_mesh
+	std::vector<Triangle> tris;        // reordered by the BVH build
+	std::vector<TriangleBvhNode> nodes;
+	float bmin[3], bmax[3];
+	float center[3];
+	Triangle* d_tris = nullptr;
+	TriangleBvhNode* d_nodes = nullptr;
+};
 
 // NerfDataset subset (nerf_loader.h:60-170): what rendering and the harness read
 struct TrainingView {
@@ -87,6 +103,12 @@ struct ngp_ctx {
 	ngp::Dataset dataset;
 	std::string data_path;
 
+	// ---- geometry mode
+	std::vector<ngp::HostMesh> meshes;
+	ngp::MeshRef* d_meshrefs = nullptr;
+	ngp::MeshSceneParams mesh_scene{};
+	ngp::MeshShadeParams shade{{0.57735026f, 0.57735026f, 0.57735026f}, {0.f, 1.f, 0.f}, 0.f, 0.f, 1.f, 0.5f, 0.f, 0.f, 0.f, {0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}};
+
 	// ---- frame
 	size_t n_pixels_alloc = 0;
 	float4* d_frame = nullptr;
@@ -101,3 +123,50 @@ struct ngp_ctx {
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
 	hipStream_t last_stream = nullptr;
 };
+
+namespace ngp {
+// ------------------------------------------------------------------------------------------------ helpers
+template <typename F>
+inline int guarded(ngp_ctx* ctx, F&& f) {
+	if (!ctx) return -1;
+	try {
+		if (ctx->device >= 0) NGP_HIP_CHECK(hipSetDevice(ctx->device));
+		f();
+		ctx->error.clear();
+		return 0;
+	} catch (const std::exception& e) {
+		ctx->error = e.what();
+		return -1;
+	}
+}
+
+inline std::string read_file(const std::string& path) {
+	std::ifstream f(path, std::ios::in | std::ios::binary);
+	if (!f) throw std::runtime_error("cannot open '" + path + "'");
+	std::stringstream ss;
+	ss << f.rdbuf();
+	return ss.str();
+}
+
+inline bool file_exists(const std::string& p) {
+	struct stat st;
+	return stat(p.c_str(), &st) == 0;
+}
+inline bool is_directory(const std::string& p) {
+	struct stat st;
+	return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+inline std::string parent_dir(const std::string& p) {
+	size_t k = p.find_last_of('/');
+	return k == std::string::npos ? std::string(".") : p.substr(0, k);
+}
+inline bool ends_with_ci(const std::string& s, const std::string& suffix) {
+	if (s.size() < suffix.size()) return false;
+	for (size_t i = 0; i < suffix.size(); ++i)
+		if (tolower(s[s.size() - suffix.size() + i]) != tolower(suffix[i])) return false;
+	return true;
+}
+
+
+void load_snapshot_path(ngp_ctx* ctx, const std::string& path);
+} // namespace ngp

@@ -79,4 +79,30 @@ struct FrameParams {
 	int32_t depth_test;
 };
 
+// ---- geometry mode (meshes)
+struct Triangle { // triangle.cuh:163 -- 36 B
+	float a[3], b[3], c[3];
+};
+struct TriangleBvhNode { // triangle_bvh.cuh:28-32 -- 32 B
+	float bmin[3], bmax[3];
+	int left_idx; // negative: leaf, triangles [-left_idx-1, -right_idx-1)
+	int right_idx;
+};
+struct MeshRef {
+	const TriangleBvhNode* nodes;
+	const Triangle* tris;
+	float bmin[3], bmax[3];
+	uint32_t n_tris, n_nodes;
+};
+struct MeshSceneParams {
+	const MeshRef* meshes;
+	uint32_t n_meshes;
+	float scene_min[3], scene_max[3]; // root bb inflated by 4 (load_scene, testbed_geometry_training.cu:3185-3189)
+};
+struct MeshShadeParams { // BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir
+	float sun_dir[3], up_dir[3];
+	float metallic, subsurface, specular, roughness, sheen, clearcoat, clearcoat_gloss;
+	float basecolor[3], ambientcolor[3];
+};
+
 } // namespace ngp

@@ -1,0 +1,358 @@
+// Geometry mode, host side of the C ABI: Testbed::load_scene / load_mesh (reference
+// src/testbed_geometry_training.cu:2751-2866, 3101-3210), the BVH4 build (src/triangle_bvh.cu:425-508) and the
+// .obj reader that replaces the vendored tinyobjloader wrapper (src/tinyobj_loader_wrapper.cu).
+#include "ngp_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stack>
+
+using namespace ngp;
+
+namespace {
+
+struct V3 {
+	float x, y, z;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 vmin(V3 a, V3 b) { return {std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
+inline V3 ld(const float* p) { return {p[0], p[1], p[2]}; }
+inline void st(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+inline V3 centroid(const Triangle& t) { return (ld(t.a) + ld(t.b) + ld(t.c)) / 3.0f; }           // triangle.cuh:149-151
+inline float centroid(const Triangle& t, int axis) { return (t.a[axis] + t.b[axis] + t.c[axis]) / 3; } // triangle.cuh:153-155
+
+void bounds(const Triangle* begin, const Triangle* end, float* bmin, float* bmax) { // BoundingBox(Triangle*, Triangle*)
+	V3 lo = ld(begin->a), hi = lo;
+	for (const Triangle* it = begin; it != end; ++it) {
+		lo = vmin(lo, vmin(ld(it->a), vmin(ld(it->b), ld(it->c))));
+		hi = vmax(hi, vmax(ld(it->a), vmax(ld(it->b), ld(it->c))));
+	}
+	st(bmin, lo);
+	st(bmax, hi);
+}
+
+// TriangleBvhWithBranchingFactor<4>::build (src/triangle_bvh.cu:425-508)
+void build_bvh4(std::vector<Triangle>& triangles, uint32_t n_primitives_per_leaf, std::vector<TriangleBvhNode>& nodes) {
+	constexpr int BF = 4;
+	nodes.clear();
+	nodes.emplace_back();
+	bounds(triangles.data(), triangles.data() + triangles.size(), nodes.front().bmin, nodes.front().bmax);
+	nodes.front().left_idx = nodes.front().right_idx = 0;
+	struct BuildNode {
+		int node_idx;
+		std::vector<Triangle>::iterator begin, end;
+	};
+	std::stack<BuildNode> build_stack;
+	build_stack.push({0, triangles.begin(), triangles.end()});
+	while (!build_stack.empty()) {
+		BuildNode curr = build_stack.top();
+		build_stack.pop();
+		std::array<BuildNode, BF> children;
+		children[0].begin = curr.begin;
+		children[0].end = curr.end;
+		int n_children = 1;
+		while (n_children < BF) {
+			for (int i = n_children - 1; i >= 0; --i) {
+				BuildNode child = children[i];
+				const float count = (float)std::distance(child.begin, child.end);
+				V3 mean{0.f, 0.f, 0.f};
+				for (auto it = child.begin; it != child.end; ++it) mean = mean + centroid(*it);
+				mean = mean / count;
+				V3 var{0.f, 0.f, 0.f};
+				for (auto it = child.begin; it != child.end; ++it) {
+					V3 diff = centroid(*it) - mean;
+					var = var + diff * diff;
+				}
+				var = var / count;
+				float max_val = std::max(std::max(var.x, var.y), var.z);
+				int axis = var.x == max_val ? 0 : (var.y == max_val ? 1 : 2);
+				auto m = child.begin + std::distance(child.begin, child.end) / 2;
+				std::nth_element(child.begin, m, child.end, [&](const Triangle& t1, const Triangle& t2) { return centroid(t1, axis) < centroid(t2, axis); });
+				children[i * 2].begin = child.begin;
+				children[i * 2 + 1].end = child.end;
+				children[i * 2].end = children[i * 2 + 1].begin = m;
+			}
+			n_children *= 2;
+		}
+		nodes[curr.node_idx].left_idx = (int)nodes.size();
+		for (int i = 0; i < BF; ++i) {
+			BuildNode& child = children[i];
+			child.node_idx = (int)nodes.size();
+			nodes.emplace_back();
+			TriangleBvhNode& nd = nodes.back();
+			if (child.begin != child.end) {
+				bounds(&*child.begin, &*child.begin + std::distance(child.begin, child.end), nd.bmin, nd.bmax);
+			} else { // the reference asserts this away; an empty child is an empty leaf
+				for (int k = 0; k < 3; ++k) { nd.bmin[k] = std::numeric_limits<float>::infinity(); nd.bmax[k] = -std::numeric_limits<float>::infinity(); }
+			}
+			if (std::distance(child.begin, child.end) <= (std::ptrdiff_t)n_primitives_per_leaf) {
+				nd.left_idx = -(int)std::distance(triangles.begin(), child.begin) - 1;
+				nd.right_idx = -(int)std::distance(triangles.begin(), child.end) - 1;
+			} else {
+				nd.left_idx = nd.right_idx = 0;
+				build_stack.push(child);
+			}
+		}
+		nodes[curr.node_idx].right_idx = (int)nodes.size();
+	}
+}
+
+void free_mesh_device(HostMesh& m) {
+	if (m.d_tris) (void)hipFree(m.d_tris);
+	if (m.d_nodes) (void)hipFree(m.d_nodes);
+	m.d_tris = nullptr;
+	m.d_nodes = nullptr;
+}
+
+// after any change of the mesh list: scene AABB (load_scene :3183-3189) and the device-side MeshRef table
+void rebuild_scene(ngp_ctx* ctx) {
+	if (ctx->d_meshrefs) {
+		(void)hipFree(ctx->d_meshrefs);
+		ctx->d_meshrefs = nullptr;
+	}
+	ctx->mesh_scene = MeshSceneParams{};
+	if (ctx->meshes.empty()) return;
+	V3 lo = ld(ctx->meshes[0].bmin), hi = ld(ctx->meshes[0].bmax);
+	for (auto& m : ctx->meshes) {
+		lo = vmin(lo, ld(m.bmin));
+		hi = vmax(hi, ld(m.bmax));
+	}
+	st(ctx->mesh_scene.scene_min, {lo.x - 4.0f, lo.y - 4.0f, lo.z - 4.0f});
+	st(ctx->mesh_scene.scene_max, {hi.x + 4.0f, hi.y + 4.0f, hi.z + 4.0f});
+	ctx->mesh_scene.n_meshes = (uint32_t)ctx->meshes.size();
+	if (ctx->device < 0) return;
+	std::vector<MeshRef> refs(ctx->meshes.size());
+	for (size_t i = 0; i < refs.size(); ++i) {
+		HostMesh& m = ctx->meshes[i];
+		if (!m.d_tris) {
+			NGP_HIP_CHECK(hipMalloc((void**)&m.d_tris, m.tris.size() * sizeof(Triangle)));
+			NGP_HIP_CHECK(hipMemcpy(m.d_tris, m.tris.data(), m.tris.size() * sizeof(Triangle), hipMemcpyHostToDevice));
+			NGP_HIP_CHECK(hipMalloc((void**)&m.d_nodes, m.nodes.size() * sizeof(TriangleBvhNode)));
+			NGP_HIP_CHECK(hipMemcpy(m.d_nodes, m.nodes.data(), m.nodes.size() * sizeof(TriangleBvhNode), hipMemcpyHostToDevice));
+		}
+		refs[i].nodes = m.d_nodes;
+		refs[i].tris = m.d_tris;
+		memcpy(refs[i].bmin, m.bmin, sizeof(m.bmin));
+		memcpy(refs[i].bmax, m.bmax, sizeof(m.bmax));
+		refs[i].n_tris = (uint32_t)m.tris.size();
+		refs[i].n_nodes = (uint32_t)m.nodes.size();
+	}
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_meshrefs, refs.size() * sizeof(MeshRef)));
+	NGP_HIP_CHECK(hipMemcpy(ctx->d_meshrefs, refs.data(), refs.size() * sizeof(MeshRef), hipMemcpyHostToDevice));
+	ctx->mesh_scene.meshes = ctx->d_meshrefs;
+}
+
+// Testbed::load_mesh (:2786-2866): normalise into the unit cube around `center`, build the BVH
+void add_mesh_impl(ngp_ctx* ctx, const float* vertices, uint32_t n_tris, const float* center3) {
+	if (!vertices || n_tris == 0) throw std::runtime_error("mesh has no triangles");
+	const size_t n_vertices = (size_t)n_tris * 3;
+	const float inf = std::numeric_limits<float>::infinity();
+	V3 lo{inf, inf, inf}, hi{-inf, -inf, -inf};
+	for (size_t i = 0; i < n_vertices; ++i) {
+		lo = vmin(lo, ld(vertices + 3 * i));
+		hi = vmax(hi, ld(vertices + 3 * i));
+	}
+	const float inflation = 0.005f;
+	V3 d0 = hi - lo;
+	float amount = std::sqrt((d0.x * d0.x + d0.y * d0.y) + d0.z * d0.z) * inflation;
+	lo = {lo.x - amount, lo.y - amount, lo.z - amount};
+	hi = {hi.x + amount, hi.y + amount, hi.z + amount};
+	V3 diag = hi - lo;
+	float mesh_scale = std::max(std::max(diag.x, diag.y), diag.z);
+	V3 center = center3 ? ld(center3) : V3{0.f, 0.f, 0.f};
+	HostMesh mesh;
+	mesh.tris.resize(n_tris);
+	st(mesh.center, center);
+	for (size_t i = 0; i < n_vertices; ++i) {
+		V3 p = ld(vertices + 3 * i);
+		V3 q = (p - lo - V3{diag.x * 0.5f, diag.y * 0.5f, diag.z * 0.5f}) / mesh_scale;
+		q = {q.x + 0.5f, q.y + 0.5f, q.z + 0.5f};
+		q = q + center;
+		Triangle& t = mesh.tris[i / 3];
+		st(i % 3 == 0 ? t.a : (i % 3 == 1 ? t.b : t.c), q);
+	}
+	build_bvh4(mesh.tris, 8, mesh.nodes);
+	bounds(mesh.tris.data(), mesh.tris.data() + mesh.tris.size(), mesh.bmin, mesh.bmax); // BoundingBox(MeshData*), geometry_bvh.cu:14-34
+	ctx->meshes.push_back(std::move(mesh));
+	rebuild_scene(ctx);
+}
+
+// ascii .obj: 'v' and 'f' records; polygons are fan-triangulated (tinyobj triangulate=true), non-triangle faces kept
+std::vector<float> load_obj(const std::string& path) {
+	std::string text = read_file(path);
+	std::vector<float> verts, out;
+	size_t pos = 0;
+	while (pos < text.size()) {
+		size_t eol = text.find('\n', pos);
+		if (eol == std::string::npos) eol = text.size();
+		const char* p = text.data() + pos;
+		const char* end = text.data() + eol;
+		while (p < end && (*p == ' ' || *p == '\t')) ++p;
+		if (end - p > 2 && p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+			char* q = nullptr;
+			p += 2;
+			for (int k = 0; k < 3; ++k) {
+				verts.push_back(strtof(p, &q));
+				p = q;
+			}
+		} else if (end - p > 2 && p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+			p += 2;
+			std::vector<long> idx;
+			while (p < end) {
+				while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+				if (p >= end) break;
+				char* q = nullptr;
+				long i = strtol(p, &q, 10);
+				if (q == p) break;
+				long nv = (long)(verts.size() / 3);
+				idx.push_back(i > 0 ? i - 1 : nv + i);
+				p = q;
+				while (p < end && *p != ' ' && *p != '\t') ++p; // skip /vt/vn
+			}
+			for (size_t k = 1; k + 1 < idx.size(); ++k) {
+				for (long vi : {idx[0], idx[k], idx[k + 1]}) {
+					if (vi < 0 || (size_t)vi * 3 + 2 >= verts.size()) throw std::runtime_error("Error loading '" + path + "': face index out of range");
+					out.insert(out.end(), verts.begin() + vi * 3, verts.begin() + vi * 3 + 3);
+				}
+			}
+		}
+		pos = eol + 1;
+	}
+	return out;
+}
+
+// geometry_load_stl (:2751-2784): binary STL
+std::vector<float> load_stl(const std::string& path) {
+	std::string data = read_file(path);
+	if (data.size() < 84) throw std::runtime_error("Mesh file '" + path + "' too small for STL header");
+	uint32_t nfaces;
+	memcpy(&nfaces, data.data() + 80, 4);
+	if (memcmp(data.data(), "solid", 5) == 0 || nfaces == 0) throw std::runtime_error("ASCII STL file '" + path + "' not supported");
+	std::vector<float> out;
+	for (uint32_t i = 0; i < nfaces; ++i) {
+		size_t off = 84 + (size_t)i * 50;
+		if (off + 50 > data.size()) break;
+		float v[9];
+		memcpy(v, data.data() + off + 12, 36);
+		out.insert(out.end(), v, v + 9);
+	}
+	return out;
+}
+
+void load_mesh_file_impl(ngp_ctx* ctx, const std::string& path, const float* center3) {
+	std::vector<float> v;
+	if (ends_with_ci(path, ".obj")) v = load_obj(path);
+	else if (ends_with_ci(path, ".stl")) v = load_stl(path);
+	else throw std::runtime_error("mesh data path must be a mesh in ascii .obj or binary .stl format.");
+	add_mesh_impl(ctx, v.data(), (uint32_t)(v.size() / 9), center3);
+}
+
+} // namespace
+
+extern "C" {
+
+int ngp_clear_meshes(ngp_ctx* ctx) {
+	return guarded(ctx, [&] {
+		for (auto& m : ctx->meshes) free_mesh_device(m);
+		ctx->meshes.clear();
+		rebuild_scene(ctx);
+	});
+}
+
+int ngp_add_mesh(ngp_ctx* ctx, const float* vertices, uint32_t n_tris, const float* center3) {
+	return guarded(ctx, [&] { add_mesh_impl(ctx, vertices, n_tris, center3); });
+}
+
+int ngp_load_mesh_file(ngp_ctx* ctx, const char* path, const float* center3) {
+	return guarded(ctx, [&] {
+		if (!path) throw std::runtime_error("null path");
+		load_mesh_file_impl(ctx, path, center3);
+	});
+}
+
+int ngp_load_scene(ngp_ctx* ctx, const char* json_path) {
+	return guarded(ctx, [&] {
+		if (!json_path) throw std::runtime_error("null path");
+		mj::Value json = mj::parse_json(read_file(json_path));
+		if (!json.is_object() || json.size() == 0) throw std::runtime_error("Geometry file must contain an array of geometry metadata.");
+		const mj::Value& geometries = json.at("geometry");
+		const std::string base = parent_dir(json_path);
+		for (auto& m : ctx->meshes) free_mesh_device(m);
+		ctx->meshes.clear();
+		for (const mj::Value& g : geometries.arr) {
+			std::string path = g.at("path").str();
+			if (!path.empty() && path[0] != '/') path = base + "/" + path;
+			const std::string& type = g.at("type").str();
+			float center[3];
+			for (int i = 0; i < 3; ++i) center[i] = (float)g.at("center").at((size_t)i).num();
+			if (type == "Mesh") load_mesh_file_impl(ctx, path, center);
+			else if (type == "Nerf") load_snapshot_path(ctx, path);
+			else throw std::runtime_error("Geometry type must be either 'Mesh' or 'Nerf'.");
+		}
+		rebuild_scene(ctx);
+	});
+}
+
+int ngp_n_meshes(const ngp_ctx* ctx) { return ctx ? (int)ctx->meshes.size() : -1; }
+
+int ngp_get_mesh_info(const ngp_ctx* ctx, int mesh, uint32_t* n_tris, uint32_t* n_nodes, float* aabb6) {
+	if (!ctx || ctx->meshes.empty()) return -1;
+	if (mesh == -1) {
+		if (aabb6) { memcpy(aabb6, ctx->mesh_scene.scene_min, 12); memcpy(aabb6 + 3, ctx->mesh_scene.scene_max, 12); }
+		if (n_tris) { *n_tris = 0; for (auto& m : ctx->meshes) *n_tris += (uint32_t)m.tris.size(); }
+		if (n_nodes) { *n_nodes = 0; for (auto& m : ctx->meshes) *n_nodes += (uint32_t)m.nodes.size(); }
+		return 0;
+	}
+	if (mesh < 0 || mesh >= (int)ctx->meshes.size()) return -1;
+	const HostMesh& m = ctx->meshes[(size_t)mesh];
+	if (n_tris) *n_tris = (uint32_t)m.tris.size();
+	if (n_nodes) *n_nodes = (uint32_t)m.nodes.size();
+	if (aabb6) { memcpy(aabb6, m.bmin, 12); memcpy(aabb6 + 3, m.bmax, 12); }
+	return 0;
+}
+
+int ngp_get_mesh_bvh(const ngp_ctx* ctx, int mesh, void* nodes_out, void* triangles_out) {
+	if (!ctx || mesh < 0 || mesh >= (int)ctx->meshes.size()) return -1;
+	const HostMesh& m = ctx->meshes[(size_t)mesh];
+	if (nodes_out) memcpy(nodes_out, m.nodes.data(), m.nodes.size() * sizeof(TriangleBvhNode));
+	if (triangles_out) memcpy(triangles_out, m.tris.data(), m.tris.size() * sizeof(Triangle));
+	return 0;
+}
+
+int ngp_set_geometry_opts(ngp_ctx* ctx, const ngp_geometry_opts* o) {
+	if (!ctx || !o) return -1;
+	static_assert(sizeof(ngp_geometry_opts) == sizeof(MeshShadeParams), "geometry opts layout");
+	memcpy(&ctx->shade, o, sizeof(MeshShadeParams));
+	return 0;
+}
+
+int ngp_trace_mesh_rays(ngp_ctx* ctx, uint32_t n, float* positions, float* directions) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (ctx->meshes.empty()) throw std::runtime_error("no meshes loaded");
+		if (n == 0) return;
+		if (!positions || !directions) throw std::runtime_error("null argument");
+		float *d_p = nullptr, *d_d = nullptr;
+		const size_t bytes = (size_t)n * 3 * sizeof(float);
+		NGP_HIP_CHECK(hipMalloc((void**)&d_p, bytes));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_d, bytes));
+		NGP_HIP_CHECK(hipMemcpy(d_p, positions, bytes, hipMemcpyHostToDevice));
+		NGP_HIP_CHECK(hipMemcpy(d_d, directions, bytes, hipMemcpyHostToDevice));
+		launch_trace_mesh_rays(ctx->mesh_scene, n, d_p, d_d, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipMemcpy(positions, d_p, bytes, hipMemcpyDeviceToHost));
+		NGP_HIP_CHECK(hipMemcpy(directions, d_d, bytes, hipMemcpyDeviceToHost));
+		(void)hipFree(d_p);
+		(void)hipFree(d_d);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+} // extern "C"

@@ -51,8 +51,22 @@ class Camera(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [
         ("render_mode", C.c_int32), ("min_transmittance", C.c_float), ("background", C.c_float * 4), ("exposure", C.c_float),
-        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32),
     ]
+
+
+class GeometryOpts(C.Structure):
+    _fields_ = [
+        ("sun_dir", C.c_float * 3), ("up_dir", C.c_float * 3),
+        ("metallic", C.c_float), ("subsurface", C.c_float), ("specular", C.c_float), ("roughness", C.c_float),
+        ("sheen", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
+        ("basecolor", C.c_float * 3), ("ambientcolor", C.c_float * 3),
+    ]
+
+
+MODE_NERF, MODE_GEOMETRY = 0, 1
+BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
+TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
 
 
 class RenderStats(C.Structure):
@@ -99,6 +113,15 @@ def load_library():
     L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.ngp_get_density_bitfield.argtypes = [vp, vp, vp]
     L.ngp_init_rays.argtypes = [vp, C.POINTER(Camera), vp]
+    L.ngp_load_scene.argtypes = [vp, C.c_char_p]
+    L.ngp_add_mesh.argtypes = [vp, vp, C.c_uint32, vp]
+    L.ngp_load_mesh_file.argtypes = [vp, C.c_char_p, vp]
+    L.ngp_clear_meshes.argtypes = [vp]
+    L.ngp_n_meshes.argtypes = [vp]
+    L.ngp_get_mesh_info.argtypes = [vp, ip, vp, vp, vp]
+    L.ngp_get_mesh_bvh.argtypes = [vp, ip, vp, vp]
+    L.ngp_set_geometry_opts.argtypes = [vp, C.POINTER(GeometryOpts)]
+    L.ngp_trace_mesh_rays.argtypes = [vp, C.c_uint32, vp, vp]
     _lib = L
     return L
 
@@ -123,7 +146,8 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
     return cam
 
 
-def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1):
+def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1,
+              testbed_mode=MODE_NERF):
     o = RenderOpts()
     o.render_mode = 0
     o.min_transmittance = min_transmittance
@@ -133,6 +157,7 @@ def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=
     o.to_srgb = int(to_srgb)
     o.spp = spp
     o.shard_index, o.shard_count = shard_index, shard_count
+    o.testbed_mode = testbed_mode
     return o
 
 
@@ -249,6 +274,56 @@ class Context:
         arr = (RenderStats * n)()
         self._check(self.L.ngp_get_render_history(self.h, n, arr))
         return [{k: getattr(st, k) for k, _ in RenderStats._fields_} for st in arr]
+
+    # ---------------------------------------------------------------- geometry mode
+    def add_mesh(self, triangles, center=(0.0, 0.0, 0.0)):
+        v = np.ascontiguousarray(triangles, np.float32).reshape(-1)
+        c = np.asarray(center, np.float32)
+        self._check(self.L.ngp_add_mesh(self.h, _p(v), v.size // 9, _p(c)))
+
+    def load_mesh_file(self, path, center=(0.0, 0.0, 0.0)):
+        c = np.asarray(center, np.float32)
+        self._check(self.L.ngp_load_mesh_file(self.h, os.fsencode(path), _p(c)))
+
+    def load_scene(self, path):
+        self._check(self.L.ngp_load_scene(self.h, os.fsencode(path)))
+
+    def clear_meshes(self):
+        self._check(self.L.ngp_clear_meshes(self.h))
+
+    def n_meshes(self):
+        return self.L.ngp_n_meshes(self.h)
+
+    def mesh_info(self, mesh=-1):
+        nt, nn = C.c_uint32(0), C.c_uint32(0)
+        bb = np.zeros(6, np.float32)
+        if self.L.ngp_get_mesh_info(self.h, mesh, C.addressof(nt), C.addressof(nn), _p(bb)) != 0:
+            raise IndexError(mesh)
+        return {"n_tris": nt.value, "n_nodes": nn.value, "aabb": (bb[:3].copy(), bb[3:].copy())}
+
+    def mesh_bvh(self, mesh):
+        info = self.mesh_info(mesh)
+        nodes = np.zeros(info["n_nodes"], BVH_NODE_DTYPE)
+        tris = np.zeros(info["n_tris"], TRIANGLE_DTYPE)
+        if self.L.ngp_get_mesh_bvh(self.h, mesh, _p(nodes), _p(tris)) != 0:
+            raise IndexError(mesh)
+        return nodes, tris
+
+    def set_geometry_opts(self, sun_dir=(1.0, 1.0, 1.0), up_dir=(0.0, 1.0, 0.0), metallic=0.0, subsurface=0.0, specular=1.0, roughness=0.5,
+                          sheen=0.0, clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0)):
+        o = GeometryOpts()
+        for i in range(3):
+            o.sun_dir[i], o.up_dir[i], o.basecolor[i], o.ambientcolor[i] = sun_dir[i], up_dir[i], basecolor[i], ambientcolor[i]
+        o.metallic, o.subsurface, o.specular, o.roughness = metallic, subsurface, specular, roughness
+        o.sheen, o.clearcoat, o.clearcoat_gloss = sheen, clearcoat, clearcoat_gloss
+        if self.L.ngp_set_geometry_opts(self.h, C.byref(o)) != 0:
+            raise RuntimeError("ngp_set_geometry_opts failed")
+
+    def trace_mesh_rays(self, positions, directions):
+        p = np.ascontiguousarray(positions, np.float32).copy()
+        d = np.ascontiguousarray(directions, np.float32).copy()
+        self._check(self.L.ngp_trace_mesh_rays(self.h, p.shape[0], _p(p), _p(d)))
+        return p, d
 
     # ---------------------------------------------------------------- stages
     def grid_encode(self, pos01):
