@@ -27,7 +27,10 @@ typedef struct ngp_ctx ngp_ctx;
 enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
 
 /* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
-enum ngp_render_mode { NGP_RENDER_SHADE = 0 };
+enum ngp_render_mode {
+	NGP_RENDER_SHADE = 0,
+	NGP_RENDER_SHADE_ENVMAP = 1 /* ERenderMode::ShadeEnvMap: meshes lit by the NeRF-derived irradiance probe (ngp_compute_envmap) */
+};
 
 /* ETestbedMode subset (common.h:35-43): Nerf, and the fork's Geometry mode (meshes + NeRF, depth composited) */
 enum ngp_testbed_mode { NGP_MODE_NERF = 0, NGP_MODE_GEOMETRY = 1 };
@@ -173,6 +176,23 @@ NGP_API int ngp_get_mesh_bvh(const ngp_ctx* ctx, int mesh, void* nodes_out, void
 NGP_API int ngp_set_geometry_opts(ngp_ctx* ctx, const ngp_geometry_opts* opts);
 /* M2 mesh_raytrace_kernel (src/geometry_bvh.cu:646-676): host positions / directions n x 3, updated in place */
 NGP_API int ngp_trace_mesh_rays(ngp_ctx* ctx, uint32_t n, float* positions, float* directions);
+
+
+/* --- irradiance probes: Testbed::computeEnvmap / computeEnvmapMultiple (declared testbed.h:709-743, no body in the
+ * reference; ray generators src/testbed_nerf.cu:1559-1773, tracer trace_mesh :2146-2262). Traces n_theta x n_phi
+ * (x n_origin^2) rays through the NeRF and stores the lat-long RGBA texture (texel idx = i_theta + n_theta*j_phi,
+ * mean over a texel's rays) in the context, plus E(n) tabulated at the texel directions. */
+enum ngp_probe_mode { NGP_PROBE_CENTER = 0, NGP_PROBE_CENTER_OUTWARD = 1, NGP_PROBE_MULTI_CENTER = 2 };
+typedef struct ngp_probe_desc {
+	int32_t mode; /* ngp_probe_mode */
+	uint32_t n_theta, n_phi, n_origin;
+	float origin[3];         /* NGP_PROBE_CENTER_OUTWARD: shell position */
+	float min_transmittance;
+} ngp_probe_desc;
+NGP_API int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* desc, float* rgba_out /* nullable: n_theta*n_phi*4 */);
+NGP_API int ngp_get_envmap(ngp_ctx* ctx, uint32_t* n_theta, uint32_t* n_phi, float* rgba_out, float* irradiance_rgba_out);
+/* E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi/(n_theta n_phi): host normals n x 3 -> host rgb n x 3 */
+NGP_API int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_out);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,15 @@ class MeshOpts(C.Structure):
         ("metallic", C.c_float), ("subsurface", C.c_float), ("specular", C.c_float), ("roughness", C.c_float),
         ("sheen", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
         ("basecolor", C.c_float * 3), ("ambientcolor", C.c_float * 3),
+        ("irradiance", C.c_void_p), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32),
     ]
+
+
+class ProbeDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32), ("n_origin", C.c_uint32), ("origin", C.c_float * 3)]
+
+
+PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 
 
 PAYLOAD_DTYPE = np.dtype(
@@ -308,6 +316,49 @@ class Oracle:
         L.orc_mesh_scene_n_nodes.restype = C.c_uint32
         L.orc_trace_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_render_mesh.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(MeshOpts), C.c_void_p, C.c_void_p]
+        L.orc_probe_n_rays.argtypes = [C.POINTER(ProbeDesc)]
+        L.orc_probe_n_rays.restype = C.c_uint32
+        L.orc_probe_payloads.argtypes = [C.POINTER(NerfModel), C.POINTER(ProbeDesc), C.c_void_p]
+        L.orc_compute_envmap.argtypes = [C.POINTER(NerfModel), C.POINTER(ProbeDesc), C.POINTER(RenderOpts), C.c_void_p, C.POINTER(RenderStats)]
+        L.orc_irradiance.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_texel_direction.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+
+    # ------------------------------------------------------------------ probes (orc_probe.c)
+    @staticmethod
+    def make_probe(mode=0, n_theta=32, n_phi=16, n_origin=1, origin=(0.0, 0.0, 0.0)):
+        d = ProbeDesc()
+        d.mode, d.n_theta, d.n_phi, d.n_origin = mode, n_theta, n_phi, n_origin
+        for i in range(3):
+            d.origin[i] = origin[i]
+        return d
+
+    def probe_payloads(self, m, desc):
+        pl = np.zeros(self.lib.orc_probe_n_rays(C.byref(desc)), PAYLOAD_DTYPE)
+        self.lib.orc_probe_payloads(C.byref(m), C.byref(desc), _ptr(pl))
+        return pl
+
+    def compute_envmap(self, m, desc, opts=None):
+        opts = opts or self.make_opts()
+        env = np.zeros((desc.n_phi, desc.n_theta, 4), np.float32)
+        st = RenderStats()
+        self.lib.orc_compute_envmap(C.byref(m), C.byref(desc), C.byref(opts), _ptr(env), C.byref(st))
+        return env, {k: getattr(st, k) for k, _ in RenderStats._fields_}
+
+    def irradiance(self, envmap, normals):
+        env = np.ascontiguousarray(envmap, np.float32)
+        nrm = np.ascontiguousarray(normals, np.float32)
+        out = np.zeros((nrm.shape[0], 3), np.float32)
+        self.lib.orc_irradiance(env.shape[1], env.shape[0], _ptr(env), nrm.shape[0], _ptr(nrm), _ptr(out))
+        return out
+
+    def texel_directions(self, n_theta, n_phi):
+        out = np.zeros((n_phi, n_theta, 3), np.float32)
+        tmp = np.zeros(3, np.float32)
+        for j in range(n_phi):
+            for i in range(n_theta):
+                self.lib.orc_texel_direction(n_theta, n_phi, i, j, _ptr(tmp))
+                out[j, i] = tmp
+        return out
 
     def mesh_scene(self, meshes):
         """meshes: list of (vertices float32 (n_tris, 3, 3) in file space, center (3,))."""
@@ -335,8 +386,13 @@ class Oracle:
 
     @staticmethod
     def make_mesh_opts(sun_dir=(1.0, 1.0, 1.0), up_dir=(0.0, 1.0, 0.0), metallic=0.0, subsurface=0.0, specular=1.0, roughness=0.5, sheen=0.0,
-                       clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0)):
+                       clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0), irradiance=None):
         o = MeshOpts()
+        if irradiance is not None:
+            irr = np.ascontiguousarray(irradiance, np.float32)
+            assert irr.ndim == 3 and irr.shape[2] == 4
+            o._keep = irr
+            o.irradiance, o.n_theta, o.n_phi = irr.ctypes.data, irr.shape[1], irr.shape[0]
         for i in range(3):
             o.sun_dir[i], o.up_dir[i], o.basecolor[i], o.ambientcolor[i] = sun_dir[i], up_dir[i], basecolor[i], ambientcolor[i]
         o.metallic, o.subsurface, o.specular, o.roughness = metallic, subsurface, specular, roughness

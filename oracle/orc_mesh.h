@@ -15,6 +15,10 @@ typedef struct orc_mesh_opts { /* BRDFParams (common.h:167-177) + m_sun_dir, m_u
 	float sun_dir[3], up_dir[3];
 	float metallic, subsurface, specular, roughness, sheen, clearcoat, clearcoat_gloss;
 	float basecolor[3], ambientcolor[3];
+	/* ShadeEnvMap: ambient light = E(N)/pi looked up (nearest texel) in an irradiance map tabulated at the probe
+	 * texture's texel directions (n_theta*n_phi*4 floats); NULL = Shade mode (sky ambient) */
+	const float* irradiance;
+	uint32_t n_theta, n_phi;
 } orc_mesh_opts;
 
 /* triangles are reordered in place */

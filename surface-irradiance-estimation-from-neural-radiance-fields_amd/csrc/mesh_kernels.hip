@@ -169,7 +169,7 @@ NGP_DEV f3 evaluate_shading(f3 base_color, f3 ambient_color, f3 light_color, flo
 }
 
 // render_geometry_mesh (src/testbed_geometry_training.cu:2202-2320), Shade mode, floor disabled, one thread per pixel
-__global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams P, const CameraParams C, float4* __restrict__ frame_buffer,
+__global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams P, const IrradianceMap I, const CameraParams C, float4* __restrict__ frame_buffer,
                                   float* __restrict__ depth_buffer, uint32_t shard_index, uint32_t shard_count) {
 	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x;
 	uint32_t y = threadIdx.y + blockDim.y * blockIdx.y;
@@ -219,7 +219,18 @@ __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams
 	f3 suncol = scale3(scale3(mk3(255.f / 255.0f, 225.f / 255.0f, 195.f / 255.0f), 4.f), shadow);
 	f3 skycol = scale3(scale3(mk3(195.f / 255.0f, 215.f / 255.0f, 255.f / 255.0f), 4.f), skyam);
 	f3 base = ld3(P.basecolor);
-	f3 color = evaluate_shading(mul3(base, base), mul3(ld3(P.ambientcolor), skycol), suncol, P.metallic, P.subsurface, P.specular, P.roughness, 0.f, P.sheen,
+	f3 ambc = mul3(ld3(P.ambientcolor), skycol);
+	if (I.irradiance) { // ShadeEnvMap: ambient light = E(N)/pi from the NeRF-derived irradiance map (nearest texel)
+		float uu = (1.0f - N.z) * 0.5f;
+		float vv = atan2f(N.y, N.x) / (2.0f * PI_F) + 0.5f;
+		int ti = (int)__builtin_floorf(uu * (float)I.n_theta);
+		int tj = (int)__builtin_floorf(vv * (float)I.n_phi);
+		ti = ti < 0 ? 0 : (ti >= (int)I.n_theta ? (int)I.n_theta - 1 : ti);
+		tj = ((tj % (int)I.n_phi) + (int)I.n_phi) % (int)I.n_phi;
+		float4 E = I.irradiance[(size_t)ti + (size_t)I.n_theta * tj];
+		ambc = mk3(E.x / PI_F, E.y / PI_F, E.z / PI_F);
+	}
+	f3 color = evaluate_shading(mul3(base, base), ambc, suncol, P.metallic, P.subsurface, P.specular, P.roughness, 0.f, P.sheen,
 	                            0.f, P.clearcoat, P.clearcoat_gloss, sun, scale3(normalize3(primary_dir), -1.0f), N);
 	frame_buffer[idx] = make_float4(color.x, color.y, color.z, 1.0f);
 	depth_buffer[idx] = dot3(cam_fwd, sub3(pos, cam_pos));
@@ -235,11 +246,11 @@ __global__ void trace_mesh_rays_kernel(const MeshSceneParams S, uint32_t n, floa
 	directions[3 * (size_t)i] = d.x; directions[3 * (size_t)i + 1] = d.y; directions[3 * (size_t)i + 2] = d.z;
 }
 
-void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
+void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
                         uint32_t shard_index, uint32_t shard_count, hipStream_t stream) {
 	dim3 threads(16, 8, 1);
 	dim3 blocks((C.width + 15) / 16, (C.height + 7) / 8, 1);
-	hipLaunchKernelGGL(render_mesh_fused, blocks, threads, 0, stream, S, P, C, frame_buffer, depth_buffer, shard_index, shard_count);
+	hipLaunchKernelGGL(render_mesh_fused, blocks, threads, 0, stream, S, P, I, C, frame_buffer, depth_buffer, shard_index, shard_count);
 }
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream) {
 	hipLaunchKernelGGL(trace_mesh_rays_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, S, n, positions, directions);

@@ -28,14 +28,19 @@ struct Accum {
 // shade_kernel_nerf (src/testbed_nerf.cu:1361-1401, Shade mode) / shade_kernel_nerf_geometry depth test
 // (src/testbed_geometry_training.cu:1843-1846) for one finished ray. compact_kernel_nerf (:1420) only forwards
 // rays with alpha > 0.001.
-NGP_DEV bool shade_ray(const FrameParams& F, uint32_t idx, const Accum& acc) {
+template <bool PROBE>
+NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, uint32_t idx, const Accum& acc) {
 	if (!(acc.a > 0.001f)) return false;
-	if (F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
+	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
 	if (!F.linear_colors) {
 		r = srgb_to_linear(r);
 		g = srgb_to_linear(g);
 		b = srgb_to_linear(b);
+	}
+	if (PROBE) {
+		P.ray_rgba[idx] = make_float4(r, g, b, a);
+		return true;
 	}
 	float4 fb = F.frame_buffer[idx];
 	float k = 1.0f - a;
@@ -48,7 +53,56 @@ NGP_DEV bool shade_ray(const FrameParams& F, uint32_t idx, const Accum& acc) {
 	return true;
 }
 
-__global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
+// K10 / K11 / K12: init_rays_from_{center, center_outward, multiple_center}_with_payload_kernel_nerf
+// (src/testbed_nerf.cu:1559-1773) for probe ray q (= the reference's payload index `mulidx`)
+NGP_DEV float halton(uint32_t base, uint32_t idx) { // random_val.cuh:338-350
+	float f = 1, result = 0;
+	while (idx > 0) {
+		f /= (float)base;
+		result += f * (float)(idx % base);
+		idx /= base;
+	}
+	return result;
+}
+NGP_DEV f3 cylindrical_to_dir_nerf(float px, float py) { // src/testbed_nerf.cu:1546-1557
+	const float cos_theta = -2.0f * px + 1.0f;
+	const float phi = 2.0f * 3.14159265358979323846f * (py - 0.5f);
+	const float sin_theta = __builtin_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+	return mk3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+}
+NGP_DEV void init_probe_ray(const ProbeParams& P, uint32_t q, RayState& r) {
+	const uint32_t no = P.mode == 2 ? P.n_origin : 1u;
+	const uint32_t w = P.n_theta * no;
+	uint32_t tm = q % w, pm = q / w;
+	uint32_t theta_mul = tm / no, theta_rem = tm % no, phi_mul = pm / no, phi_rem = pm % no;
+	f3 local = cylindrical_to_dir_nerf((float)theta_mul / (float)P.n_theta, (float)phi_mul / (float)P.n_phi);
+	f3 origin = mk3(P.center[0], P.center[1], P.center[2]);
+	f3 dir = local;
+	if (P.mode == 1) {
+		origin = mk3(P.origin[0], P.origin[1], P.origin[2]);
+		f3 n = normalize3(origin); // compute_local_frame, random_val.cuh:167-186
+		float sz = (n.z >= 0) ? 1.0f : -1.0f;
+		float a = 1 / (sz + n.z);
+		float ya = n.y * a;
+		float b = n.x * ya;
+		float c = n.x * sz;
+		float frame[9] = {c * n.x * a - 1, sz * b, c, b, n.y * ya - sz, n.y, n.x, n.y, n.z};
+		dir = m3_mulv(frame, local);
+	} else if (P.mode == 2) {
+		uint32_t hi = theta_rem * no + phi_rem;
+		origin = add3(origin, mk3(halton(2, hi) - 0.5f, halton(3, hi) - 0.5f, halton(5, hi) - 0.5f));
+	}
+	dir = normalize3(dir);
+	if (P.mode == 1) dir = scale3(dir, -1.0f);
+	r.o = origin;
+	r.d = dir;
+	r.t = 0.0f;
+	r.idx = q;
+	r.alive = true;
+}
+
+template <bool PROBE>
+NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	__shared__ uint4 s_w[N_FRAGS * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
@@ -95,7 +149,16 @@ __global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, 
 			}
 			if (!exhausted) {
 				uint32_t slot = tile_next + lanes_below(dead_mask);
-				if (!ray.alive && slot < 64) {
+				if (PROBE) {
+					uint32_t q = tile * 64u + slot;
+					if (!ray.alive && slot < 64 && q < P.n_rays) {
+						init_probe_ray(P, q, ray);
+						idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+						acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+						step = 1;
+						++n_alive_init;
+					}
+				} else if (!ray.alive && slot < 64) {
 					uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
 					uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
 					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
@@ -119,10 +182,10 @@ __global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, 
 		// ---- K4: skip empty space, emit the next sample (generate_next_nerf_network_inputs, :430-477)
 		float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 		if (ray.alive) {
-			float t = skip_empty_space<false>(ray.t, M, ray.o, ray.d, idir);
+			float t = skip_empty_space<PROBE>(ray.t, M, ray.o, ray.d, idir); // trace_mesh uses the 200-iteration skip
 			if (t >= MAX_DEPTH) {
 				ray.alive = false;
-				n_hit += shade_ray(F, ray.idx, acc) ? 1u : 0u;
+				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
 			} else {
 				float dt = calc_dt(t, M.cone_angle);
 				f3 w = div3(sub3(add3(ray.o, scale3(ray.d, t)), amin), adiag); // warp_position
@@ -184,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, 
 			if (acc.a > (1.0f - F.min_transmittance)) {
 				acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
 				ray.alive = false;
-				n_hit += shade_ray(F, ray.idx, acc) ? 1u : 0u;
+				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
 			} else if (step >= MARCH_ITER) {
 				ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
 			}
@@ -201,6 +264,68 @@ __global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, 
 		atomicAdd(&F.counters[0], (unsigned long long)n_alive_init);
 		atomicAdd(&F.counters[1], (unsigned long long)n_hit);
 		atomicAdd(&F.counters[2], (unsigned long long)n_samples);
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false>(M, C, F, P);
+}
+
+// the same machinery fed by the probe ray fans instead of the camera (Testbed::computeEnvmap*, testbed.h:709-743)
+__global__ __launch_bounds__(BLOCK) void trace_probe_fused(const ModelParams M, const FrameParams F, const ProbeParams P) {
+	CameraParams C{};
+	fused_body<true>(M, C, F, P);
+}
+
+// probe texture: texel = mean of its rays' shaded RGBA, summed in increasing ray index
+__global__ void probe_reduce_kernel(const ProbeParams P, float4* __restrict__ envmap) {
+	uint32_t texel = blockIdx.x * blockDim.x + threadIdx.x;
+	if (texel >= P.n_theta * P.n_phi) return;
+	const uint32_t no = P.mode == 2 ? P.n_origin : 1u;
+	uint32_t i = texel % P.n_theta, j = texel / P.n_theta;
+	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (uint32_t pr = 0; pr < no; ++pr) {
+		for (uint32_t tr = 0; tr < no; ++tr) {
+			float4 v = P.ray_rgba[(i * no + tr) + P.n_theta * no * (j * no + pr)];
+			acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+		}
+	}
+	float inv = 1.0f / (float)(no * no);
+	envmap[texel] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+// E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi / (n_theta n_phi); one block per query normal
+__global__ void irradiance_kernel(uint32_t n_theta, uint32_t n_phi, const float4* __restrict__ envmap, uint32_t n, const float* __restrict__ normals,
+                                  int normals_are_texels, float4* __restrict__ out) {
+	__shared__ double s[3][256];
+	const uint32_t q = blockIdx.x;
+	if (q >= n) return;
+	f3 nrm;
+	if (normals_are_texels) nrm = cylindrical_to_dir_nerf((float)(q % n_theta) / (float)n_theta, (float)(q / n_theta) / (float)n_phi);
+	else nrm = mk3(normals[3 * (size_t)q], normals[3 * (size_t)q + 1], normals[3 * (size_t)q + 2]);
+	double a0 = 0, a1 = 0, a2 = 0;
+	for (uint32_t t = threadIdx.x; t < n_theta * n_phi; t += blockDim.x) {
+		f3 w = cylindrical_to_dir_nerf((float)(t % n_theta) / (float)n_theta, (float)(t / n_theta) / (float)n_phi);
+		float c = dot3(nrm, w);
+		if (c > 0.0f) {
+			float4 L = envmap[t];
+			a0 += (double)(L.x * c); a1 += (double)(L.y * c); a2 += (double)(L.z * c);
+		}
+	}
+	s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = a2;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) {
+			s[0][threadIdx.x] += s[0][threadIdx.x + off];
+			s[1][threadIdx.x] += s[1][threadIdx.x + off];
+			s[2][threadIdx.x] += s[2][threadIdx.x + off];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const double d_omega = 4.0 * 3.14159265358979323846 / ((double)n_theta * (double)n_phi);
+		out[q] = make_float4((float)(s[0][0] * d_omega), (float)(s[1][0] * d_omega), (float)(s[2][0] * d_omega), 0.f);
 	}
 }
 
@@ -352,6 +477,16 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 // launchers (called from ngp_api.cpp)
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream) {
 	hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+}
+void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream) {
+	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, F, P);
+}
+void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream) {
+	uint32_t n = P.n_theta * P.n_phi;
+	hipLaunchKernelGGL(probe_reduce_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, P, envmap);
+}
+void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream) {
+	hipLaunchKernelGGL(irradiance_kernel, dim3(n), dim3(256), 0, stream, n_theta, n_phi, envmap, n, normals, normals_are_texels, out);
 }
 void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream) {
 	uint32_t n_waves = (n + 63) / 64;

@@ -724,7 +724,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
-	if (opts.render_mode != NGP_RENDER_SHADE) throw std::runtime_error("only render_mode Shade is implemented");
+	if (opts.render_mode != NGP_RENDER_SHADE && opts.render_mode != NGP_RENDER_SHADE_ENVMAP) throw std::runtime_error("only render modes Shade and ShadeEnvMap are implemented");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const size_t n_pixels = (size_t)cam.width * cam.height;
@@ -764,7 +764,16 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		NGP_HIP_CHECK(hipMemsetAsync(F.depth_buffer, 0, n_pixels * sizeof(float), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
 		const bool last = s == spp - 1;
-		if (have_meshes) launch_render_mesh(ctx->mesh_scene, ctx->shade, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, stream);
+		if (have_meshes) {
+			IrradianceMap I{};
+			if (opts.render_mode == NGP_RENDER_SHADE_ENVMAP) {
+				if (!ctx->d_irradiance) throw std::runtime_error("render_mode ShadeEnvMap needs ngp_compute_envmap first");
+				I.irradiance = ctx->d_irradiance;
+				I.n_theta = ctx->env_n_theta;
+				I.n_phi = ctx->env_n_phi;
+			}
+			launch_render_mesh(ctx->mesh_scene, ctx->shade, I, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, stream);
+		}
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
 		// persistent grid: 4 workgroups of 4 waves per CU; surplus waves find the queue empty and exit
 		int n_blocks = ctx->n_cus * 4;
@@ -784,6 +793,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 } // namespace
 
 namespace ngp {
+void ensure_sync_buffers(ngp_ctx* ctx) { ensure_frame_buffers(ctx, 0); }
 void load_snapshot_path(ngp_ctx* ctx, const std::string& p) {
 	std::string data = read_file(p);
 	bool compressed = ends_with_ci(p, ".ingp"); // testbed.cu:262-266
@@ -829,6 +839,8 @@ void ngp_destroy(ngp_ctx* ctx) {
 		if (m.d_nodes) (void)hipFree(m.d_nodes);
 	}
 	if (ctx->d_meshrefs) (void)hipFree(ctx->d_meshrefs);
+	if (ctx->d_envmap) (void)hipFree(ctx->d_envmap);
+	if (ctx->d_irradiance) (void)hipFree(ctx->d_irradiance);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->d_depth) (void)hipFree(ctx->d_depth);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);

@@ -33,8 +33,11 @@ void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_gri
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
                                float exposure, int to_srgb, float4* rgba_out, hipStream_t stream);
 
-void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
+void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
                         uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
+void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream);
+void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream);
+void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream);
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream);
 
 struct HostMesh { // MeshData (mesh.h:18-24) after load_mesh
@@ -109,6 +112,11 @@ struct ngp_ctx {
 	ngp::MeshSceneParams mesh_scene{};
 	ngp::MeshShadeParams shade{{0.57735026f, 0.57735026f, 0.57735026f}, {0.f, 1.f, 0.f}, 0.f, 0.f, 1.f, 0.5f, 0.f, 0.f, 0.f, {0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}};
 
+	// ---- irradiance probe texture (m_envmap_tex / gridSize, testbed.h:949-950) and E(n) tabulated at its texels
+	float4* d_envmap = nullptr;
+	float4* d_irradiance = nullptr;
+	uint32_t env_n_theta = 0, env_n_phi = 0;
+
 	// ---- frame
 	size_t n_pixels_alloc = 0;
 	float4* d_frame = nullptr;
@@ -169,4 +177,5 @@ inline bool ends_with_ci(const std::string& s, const std::string& suffix) {
 
 
 void load_snapshot_path(ngp_ctx* ctx, const std::string& path);
+void ensure_sync_buffers(ngp_ctx* ctx);
 } // namespace ngp

@@ -79,6 +79,16 @@ struct FrameParams {
 	int32_t depth_test;
 };
 
+// ---- irradiance probes
+struct ProbeParams {
+	int32_t mode; // 0 centre fan (K10), 1 shell position looking inward (K11), 2 Halton-jittered centres (K12)
+	uint32_t n_theta, n_phi, n_origin;
+	float origin[3];
+	float center[3]; // render_aabb.center()
+	uint32_t n_rays;
+	float4* ray_rgba; // one shaded RGBA per probe ray (zero when the ray saw nothing)
+};
+
 // ---- geometry mode (meshes)
 struct Triangle { // triangle.cuh:163 -- 36 B
 	float a[3], b[3], c[3];
@@ -103,6 +113,10 @@ struct MeshShadeParams { // BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir
 	float sun_dir[3], up_dir[3];
 	float metallic, subsurface, specular, roughness, sheen, clearcoat, clearcoat_gloss;
 	float basecolor[3], ambientcolor[3];
+};
+struct IrradianceMap { // E(n) tabulated at the probe texture's texel directions; nullptr = not computed
+	const float4* irradiance;
+	uint32_t n_theta, n_phi;
 };
 
 } // namespace ngp

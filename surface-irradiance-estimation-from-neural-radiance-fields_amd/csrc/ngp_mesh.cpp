@@ -355,4 +355,98 @@ int ngp_trace_mesh_rays(ngp_ctx* ctx, uint32_t n, float* positions, float* direc
 	});
 }
 
+
+// ------------------------------------------------------------------------------------------------ irradiance probes
+int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (!d || d->n_theta == 0 || d->n_phi == 0 || d->mode < 0 || d->mode > 2) throw std::runtime_error("invalid probe descriptor");
+		const uint32_t no = d->mode == NGP_PROBE_MULTI_CENTER ? d->n_origin : 1u;
+		if (no == 0) throw std::runtime_error("invalid probe descriptor: n_origin");
+		ensure_sync_buffers(ctx);
+		ProbeParams P{};
+		P.mode = d->mode;
+		P.n_theta = d->n_theta;
+		P.n_phi = d->n_phi;
+		P.n_origin = no;
+		for (int i = 0; i < 3; ++i) {
+			P.origin[i] = d->origin[i];
+			P.center[i] = 0.5f * (ctx->M.raabb_max[i] + ctx->M.raabb_min[i]); // render_aabb.center()
+		}
+		const uint64_t n_rays64 = (uint64_t)d->n_theta * d->n_phi * no * no;
+		if (n_rays64 > (1ull << 28)) throw std::runtime_error("probe too large");
+		P.n_rays = (uint32_t)n_rays64;
+		const uint32_t n_texels = d->n_theta * d->n_phi;
+		NGP_HIP_CHECK(hipMalloc((void**)&P.ray_rgba, (size_t)P.n_rays * sizeof(float4)));
+		if (ctx->d_envmap) (void)hipFree(ctx->d_envmap);
+		if (ctx->d_irradiance) (void)hipFree(ctx->d_irradiance);
+		ctx->d_envmap = ctx->d_irradiance = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_envmap, (size_t)n_texels * sizeof(float4)));
+		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_irradiance, (size_t)n_texels * sizeof(float4)));
+		hipStream_t stream = ctx->stream;
+		const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
+		FrameParams F{};
+		F.queue = (uint32_t*)ctx->d_sync;
+		F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
+		F.n_local_tiles = (P.n_rays + 63) / 64;
+		F.shard_index = 0;
+		F.shard_count = 1;
+		F.min_transmittance = d->min_transmittance > 0.f ? d->min_transmittance : 0.01f;
+		F.linear_colors = ctx->desc.linear_colors;
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
+		NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
+		NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
+		int n_blocks = std::min<int>(ctx->n_cus * 4, (int)((F.n_local_tiles + 3) / 4));
+		launch_trace_probe(ctx->M, F, P, std::max(n_blocks, 1), stream);
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
+		launch_probe_reduce(P, ctx->d_envmap, stream);
+		launch_irradiance(d->n_theta, d->n_phi, ctx->d_envmap, n_texels, nullptr, 1, ctx->d_irradiance, stream);
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame1[slot], stream));
+		ctx->hist_n_rays[slot] = P.n_rays;
+		ctx->last_stream = stream;
+		++ctx->n_calls;
+		NGP_HIP_CHECK(hipStreamSynchronize(stream));
+		NGP_HIP_CHECK(hipGetLastError());
+		(void)hipFree(P.ray_rgba);
+		ctx->env_n_theta = d->n_theta;
+		ctx->env_n_phi = d->n_phi;
+		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, (size_t)n_texels * sizeof(float4), hipMemcpyDeviceToHost));
+	});
+}
+
+int ngp_get_envmap(ngp_ctx* ctx, uint32_t* n_theta, uint32_t* n_phi, float* rgba_out, float* irradiance_rgba_out) {
+	return guarded(ctx, [&] {
+		if (!ctx->d_envmap) throw std::runtime_error("no probe texture: call ngp_compute_envmap first");
+		if (n_theta) *n_theta = ctx->env_n_theta;
+		if (n_phi) *n_phi = ctx->env_n_phi;
+		const size_t bytes = (size_t)ctx->env_n_theta * ctx->env_n_phi * sizeof(float4);
+		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, bytes, hipMemcpyDeviceToHost));
+		if (irradiance_rgba_out) NGP_HIP_CHECK(hipMemcpy(irradiance_rgba_out, ctx->d_irradiance, bytes, hipMemcpyDeviceToHost));
+	});
+}
+
+int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_out) {
+	return guarded(ctx, [&] {
+		if (!ctx->d_envmap) throw std::runtime_error("no probe texture: call ngp_compute_envmap first");
+		if (n == 0) return;
+		if (!normals || !rgb_out) throw std::runtime_error("null argument");
+		float* d_n = nullptr;
+		float4* d_o = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_n, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
+		NGP_HIP_CHECK(hipMemcpy(d_n, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		launch_irradiance(ctx->env_n_theta, ctx->env_n_phi, ctx->d_envmap, n, d_n, 0, d_o, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		std::vector<float4> tmp(n);
+		NGP_HIP_CHECK(hipMemcpy(tmp.data(), d_o, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+		for (uint32_t i = 0; i < n; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
+		(void)hipFree(d_n);
+		(void)hipFree(d_o);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
 } // extern "C"

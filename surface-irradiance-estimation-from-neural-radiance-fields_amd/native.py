@@ -64,7 +64,14 @@ class GeometryOpts(C.Structure):
     ]
 
 
+class ProbeDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32), ("n_origin", C.c_uint32), ("origin", C.c_float * 3),
+                ("min_transmittance", C.c_float)]
+
+
 MODE_NERF, MODE_GEOMETRY = 0, 1
+RENDER_SHADE, RENDER_SHADE_ENVMAP = 0, 1
+PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
 
@@ -122,6 +129,9 @@ def load_library():
     L.ngp_get_mesh_bvh.argtypes = [vp, ip, vp, vp]
     L.ngp_set_geometry_opts.argtypes = [vp, C.POINTER(GeometryOpts)]
     L.ngp_trace_mesh_rays.argtypes = [vp, C.c_uint32, vp, vp]
+    L.ngp_compute_envmap.argtypes = [vp, C.POINTER(ProbeDesc), vp]
+    L.ngp_get_envmap.argtypes = [vp, vp, vp, vp, vp]
+    L.ngp_irradiance.argtypes = [vp, C.c_uint32, vp, vp]
     _lib = L
     return L
 
@@ -147,9 +157,9 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
 
 
 def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1,
-              testbed_mode=MODE_NERF):
+              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE):
     o = RenderOpts()
-    o.render_mode = 0
+    o.render_mode = render_mode
     o.min_transmittance = min_transmittance
     for i in range(4):
         o.background[i] = background[i]
@@ -324,6 +334,30 @@ class Context:
         d = np.ascontiguousarray(directions, np.float32).copy()
         self._check(self.L.ngp_trace_mesh_rays(self.h, p.shape[0], _p(p), _p(d)))
         return p, d
+
+    # ---------------------------------------------------------------- irradiance probes
+    def compute_envmap(self, mode=PROBE_CENTER, n_theta=32, n_phi=16, n_origin=1, origin=(0.0, 0.0, 0.0), min_transmittance=0.01):
+        d = ProbeDesc()
+        d.mode, d.n_theta, d.n_phi, d.n_origin, d.min_transmittance = mode, n_theta, n_phi, n_origin, min_transmittance
+        for i in range(3):
+            d.origin[i] = origin[i]
+        env = np.zeros((n_phi, n_theta, 4), np.float32)
+        self._check(self.L.ngp_compute_envmap(self.h, C.byref(d), _p(env)))
+        return env
+
+    def get_envmap(self):
+        nt, nph = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.ngp_get_envmap(self.h, C.addressof(nt), C.addressof(nph), None, None))
+        env = np.zeros((nph.value, nt.value, 4), np.float32)
+        irr = np.zeros((nph.value, nt.value, 4), np.float32)
+        self._check(self.L.ngp_get_envmap(self.h, None, None, _p(env), _p(irr)))
+        return env, irr
+
+    def irradiance(self, normals):
+        nrm = np.ascontiguousarray(normals, np.float32)
+        out = np.zeros((nrm.shape[0], 3), np.float32)
+        self._check(self.L.ngp_irradiance(self.h, nrm.shape[0], _p(nrm), _p(out)))
+        return out
 
     # ---------------------------------------------------------------- stages
     def grid_encode(self, pos01):
