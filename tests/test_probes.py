@@ -44,7 +44,9 @@ def test_irradiance_of_constant_environment(oracle):
     n = rng.normal(size=(16, 3)).astype(np.float32)
     n /= np.linalg.norm(n, axis=1, keepdims=True)
     E = oracle.irradiance(env, n)
-    assert np.allclose(E, np.pi * np.float32([0.5, 1.0, 2.0]), rtol=5e-3)
+    # (texel directions sit at i/n_theta, not at cell centres -- as the reference's generators do -- so the
+    # quadrature is first order: ~1/n_theta)
+    assert np.allclose(E, np.pi * np.float32([0.5, 1.0, 2.0]), rtol=2e-2)
     # a single bright texel: E = L max(0, n.w) dOmega
     env2 = np.zeros((8, 16, 4), np.float32)
     env2[3, 5, :3] = 7.0
@@ -54,7 +56,7 @@ def test_irradiance_of_constant_environment(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,kw", [(0, {}), (2, {"n_origin": 2}), (1, {"origin": (0.5, 0.5, 1.6)})])
+@pytest.mark.parametrize("mode,kw", [(0, {}), (2, {"n_origin": 2}), (1, {"origin": (0.9, 0.85, 0.8)})])
 def test_envmap_and_irradiance_parity(mode, kw, gpu_ctx, oracle, scene_unit):
     gpu_ctx.set_model(scene_unit)
     m = oracle.make_model(scene_unit)
