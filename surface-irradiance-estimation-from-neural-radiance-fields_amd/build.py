@@ -42,5 +42,44 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def pyngp_path():
+    import sysconfig
+
+    return os.path.join(HERE, "pyngp" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pyngp(force=False, verbose=False):
+    """pybind11 module `pyngp` (csrc/pyngp.cpp over the C++ Testbed shim), linked against libngp_hip.so."""
+    import pybind11
+    import sysconfig
+
+    out = pyngp_path()
+    srcs = [os.path.join(CSRC, "pyngp.cpp"), os.path.join(CSRC, "testbed_shim.h"), os.path.join(HERE, "..", "include", "ngp_hip.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    build()
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include(),
+           srcs[0], "-o", out, "-L", HERE, "-lngp_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("building pyngp failed")
+    return out
+
+
+def import_pyngp():
+    """Import the in-tree pyngp extension (build it first if needed)."""
+    import importlib.util
+
+    path = build_pyngp()
+    spec = importlib.util.spec_from_file_location("pyngp", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_pyngp(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,119 @@
+// pybind11 module `pyngp`: the subset of the reference's src/python_api.cu that the inference path of scripts/run.py
+// uses (Testbed, TestbedMode, RenderMode; load_*, render, camera and render-state properties), bound to the
+// C-ABI-backed ngp::Testbed shim. Same names and defaults as python_api.cu:263-733.
+#include "testbed_shim.h"
+
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+namespace py = pybind11;
+using namespace ngp;
+
+static std::array<float, 12> to_colmajor(const py::array_t<float, py::array::c_style | py::array::forcecast>& a) {
+	if (a.ndim() != 2 || a.shape(0) != 3 || a.shape(1) != 4) throw std::runtime_error("expected a 3x4 matrix");
+	std::array<float, 12> m;
+	auto r = a.unchecked<2>();
+	for (int c = 0; c < 4; ++c)
+		for (int row = 0; row < 3; ++row) m[c * 3 + row] = r(row, c);
+	return m;
+}
+static py::array_t<float> from_colmajor(const std::array<float, 12>& m) {
+	py::array_t<float> a({3, 4});
+	auto w = a.mutable_unchecked<2>();
+	for (int c = 0; c < 4; ++c)
+		for (int row = 0; row < 3; ++row) w(row, c) = m[c * 3 + row];
+	return a;
+}
+
+PYBIND11_MODULE(pyngp, m) {
+	m.doc() = "MI355X-native NeRF renderer behind the instant-ngp Testbed API (inference path)";
+	py::enum_<ETestbedMode>(m, "TestbedMode")
+		.value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
+		.value("Volume", ETestbedMode::Volume).value("Geometry", ETestbedMode::Geometry).value("None", ETestbedMode::None)
+		.export_values();
+	// the reference registers the name "Shade" twice (python_api.cu:284-294), which pybind11 rejects at import;
+	// ShadeNerf keeps its own name here
+	py::enum_<ERenderMode>(m, "RenderMode")
+		.value("AO", ERenderMode::AO).value("Shade", ERenderMode::Shade).value("Normals", ERenderMode::Normals)
+		.value("Positions", ERenderMode::Positions).value("Depth", ERenderMode::Depth).value("Distortion", ERenderMode::Distortion)
+		.value("Cost", ERenderMode::Cost).value("Slice", ERenderMode::Slice).value("ShadeNerf", ERenderMode::ShadeNerf)
+		.value("ShadeEnvMap", ERenderMode::ShadeEnvMap).value("ShadeGridEnvMap", ERenderMode::ShadeGridEnvMap)
+		.export_values();
+
+	// nested under Testbed like python_api.cu does (py::class_<Testbed::Nerf> nerf(testbed, "Nerf")): the exported enum
+	// value TestbedMode.Nerf already owns the module-level name "Nerf"
+	py::class_<Testbed> testbed(m, "Testbed");
+	py::class_<Testbed::TrainingImageMetadata>(testbed, "TrainingImageMetadata")
+		.def_readonly("resolution", &Testbed::TrainingImageMetadata::resolution)
+		.def_readonly("focal_length", &Testbed::TrainingImageMetadata::focal_length)
+		.def_readonly("principal_point", &Testbed::TrainingImageMetadata::principal_point);
+	py::class_<Testbed::NerfDatasetView>(testbed, "NerfDataset")
+		.def_readonly("n_images", &Testbed::NerfDatasetView::n_images)
+		.def_readonly("metadata", &Testbed::NerfDatasetView::metadata)
+		.def_readonly("aabb_scale", &Testbed::NerfDatasetView::aabb_scale)
+		.def_readonly("scale", &Testbed::NerfDatasetView::scale)
+		.def_readonly("offset", &Testbed::NerfDatasetView::offset);
+	py::class_<Testbed::Nerf::Training>(testbed, "NerfTraining")
+		.def_readonly("dataset", &Testbed::Nerf::Training::dataset)
+		.def_readwrite("view", &Testbed::Nerf::Training::view);
+	py::class_<Testbed::Nerf>(testbed, "Nerf")
+		.def_readwrite("render_min_transmittance", &Testbed::Nerf::render_min_transmittance)
+		.def_readonly("cone_angle_constant", &Testbed::Nerf::cone_angle_constant)
+		.def_readonly("training", &Testbed::Nerf::training);
+	py::class_<Testbed::BRDFParams>(testbed, "BRDFParams")
+		.def_readwrite("metallic", &Testbed::BRDFParams::metallic).def_readwrite("subsurface", &Testbed::BRDFParams::subsurface)
+		.def_readwrite("specular", &Testbed::BRDFParams::specular).def_readwrite("roughness", &Testbed::BRDFParams::roughness)
+		.def_readwrite("sheen", &Testbed::BRDFParams::sheen).def_readwrite("clearcoat", &Testbed::BRDFParams::clearcoat)
+		.def_readwrite("clearcoat_gloss", &Testbed::BRDFParams::clearcoat_gloss)
+		.def_readwrite("basecolor", &Testbed::BRDFParams::basecolor).def_readwrite("ambientcolor", &Testbed::BRDFParams::ambientcolor);
+
+	testbed
+		.def(py::init<ETestbedMode, int>(), py::arg("mode") = ETestbedMode::None, py::arg("device") = 0)
+		.def(py::init<ETestbedMode, const std::string&, int>(), py::arg("mode"), py::arg("data_path"), py::arg("device") = 0)
+		.def("load_training_data", &Testbed::load_training_data, py::call_guard<py::gil_scoped_release>(), "Load training data from a given path.")
+		.def("load_snapshot", &Testbed::load_snapshot, py::arg("path"), "Load a previously saved snapshot")
+		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false, py::arg("compress") = true)
+		.def("load_file", &Testbed::load_file, py::arg("path"))
+		.def("load_mesh", &Testbed::load_mesh, py::arg("path"), py::arg("center") = std::array<float, 3>{0.f, 0.f, 0.f})
+		.def("reset_camera", &Testbed::reset_camera)
+		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& a) { t.set_nerf_camera_matrix(to_colmajor(a)); })
+		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
+		.def("compute_envmap", &Testbed::computeEnvmapMultipleMain, py::arg("n_theta") = 256, py::arg("n_phi") = 128, py::arg("n_origin") = 1)
+		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float start_t, float end_t, float fps, float shutter_fraction) {
+				py::array_t<float> result({height, width, 4});
+				{
+					py::gil_scoped_release release;
+					t.render_to_cpu(result.mutable_data(), width, height, spp, linear, start_t, end_t, fps, shutter_fraction);
+				}
+				return result;
+			}, "Renders an image at the requested resolution. Does not require a window.",
+			py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f,
+			py::arg("end_t") = -1.f, py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		.def_property("camera_matrix", [](Testbed& t) { return from_colmajor(t.m_camera); },
+			[](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& a) { t.m_camera = to_colmajor(a); })
+		.def_property("fov", &Testbed::fov, &Testbed::set_fov)
+		.def_readwrite("fov_axis", &Testbed::m_fov_axis)
+		.def_readwrite("relative_focal_length", &Testbed::m_relative_focal_length)
+		.def_readwrite("screen_center", &Testbed::m_screen_center)
+		.def_readwrite("zoom", &Testbed::m_zoom)
+		.def_readwrite("scale", &Testbed::m_scale)
+		.def_readwrite("background_color", &Testbed::m_background_color)
+		.def_readwrite("snap_to_pixel_centers", &Testbed::m_snap_to_pixel_centers)
+		.def_readwrite("exposure", &Testbed::m_exposure)
+		.def_readwrite("render_mode", &Testbed::m_render_mode)
+		.def_readwrite("render_near_distance", &Testbed::m_render_near_distance)
+		.def_readwrite("sun_dir", &Testbed::m_sun_dir)
+		.def_readwrite("up_dir", &Testbed::m_up_dir)
+		.def_readwrite("root_dir", &Testbed::m_root_dir)
+		.def_readonly("data_path", &Testbed::m_data_path)
+		.def_readonly("aabb", &Testbed::m_aabb)
+		.def_readonly("render_aabb", &Testbed::m_render_aabb)
+		.def_readonly("mode", &Testbed::m_testbed_mode)
+		.def_readonly("training_step", &Testbed::m_training_step)
+		.def_readonly("loss", &Testbed::m_loss)
+		.def_readwrite("brdf", &Testbed::brdf)
+		.def_property("shall_train", [](Testbed& t) { return t.m_train; },
+			[](Testbed& t, bool v) { if (v) throw std::runtime_error("training is out of scope of the MI355X inference renderer"); t.m_train = false; })
+		.def_readonly("nerf", &Testbed::nerf);
+}

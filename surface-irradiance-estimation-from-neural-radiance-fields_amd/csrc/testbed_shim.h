@@ -1,0 +1,259 @@
+// ngp::Testbed -- host-side mirror of the reference's facade (include/neural-graphics-primitives/testbed.h) for the
+// inference path, written against the C ABI only (include/ngp_hip.h). Same member names, argument meaning and error
+// behaviour (std::runtime_error) as the reference so that scripts/run.py-style drivers and src/python_api.cu-style
+// bindings work unchanged for load -> set camera -> render. Training, GUI, VR, DLSS, SDF/image/volume are not here.
+#pragma once
+
+#include "../../include/ngp_hip.h"
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace ngp {
+
+enum class ETestbedMode : int { Nerf, Sdf, Image, Volume, Geometry, None }; // common.h:35-43
+enum class ERenderMode : int { AO, Shade, Normals, Positions, Depth, Distortion, Cost, Slice, ShadeNerf, ShadeEnvMap, ShadeGridEnvMap, EncodingVis }; // common.h:58-72
+
+class Testbed {
+public:
+	struct TrainingImageMetadata {
+		std::array<int, 2> resolution;
+		std::array<float, 2> focal_length;
+		std::array<float, 2> principal_point;
+	};
+	struct NerfDatasetView { // testbed.nerf.training.dataset
+		size_t n_images = 0;
+		std::vector<TrainingImageMetadata> metadata;
+		std::vector<std::array<float, 12>> xforms;
+		int aabb_scale = 1;
+		float scale = 1.f;
+		std::array<float, 3> offset{0.f, 0.f, 0.f};
+	};
+	struct Nerf {
+		float render_min_transmittance = 0.01f; // nerf.h:172
+		float cone_angle_constant = 0.f;
+		struct Training {
+			NerfDatasetView dataset;
+			int view = 0;
+		} training;
+	} nerf;
+
+	explicit Testbed(ETestbedMode mode = ETestbedMode::None, int device = 0) : m_testbed_mode(mode) {
+		m_ctx = ngp_create(device);
+		if (!m_ctx) throw std::runtime_error("Testbed: no HIP device available (the MI355X renderer has no CPU fallback)");
+		reset_camera();
+	}
+	Testbed(ETestbedMode mode, const std::string& data_path, int device = 0) : Testbed(mode, device) { load_training_data(data_path); }
+	~Testbed() { ngp_destroy(m_ctx); }
+	Testbed(const Testbed&) = delete;
+	Testbed& operator=(const Testbed&) = delete;
+
+	// ---- loading (src/testbed.cu:125-152, 319-395, 5465-5475; src/testbed_geometry_training.cu:3101-3210)
+	static ETestbedMode mode_from_scene(const std::string& scene) { // src/common_host.cu:146-166
+		struct stat st;
+		if (stat(scene.c_str(), &st) != 0) return ETestbedMode::None;
+		auto ends = [&](const char* e) { size_t n = strlen(e); return scene.size() >= n && strcasecmp(scene.c_str() + scene.size() - n, e) == 0; };
+		if (S_ISDIR(st.st_mode) || ends(".json")) {
+			size_t slash = scene.find_last_of('/');
+			std::string fname = slash == std::string::npos ? scene : scene.substr(slash + 1);
+			return fname.find("geometry") != std::string::npos ? ETestbedMode::Geometry : ETestbedMode::Nerf;
+		}
+		if (ends(".obj") || ends(".stl")) return ETestbedMode::Sdf;
+		if (ends(".nvdb")) return ETestbedMode::Volume;
+		return ETestbedMode::Image;
+	}
+	void load_training_data(const std::string& path) {
+		ETestbedMode scene_mode = mode_from_scene(path);
+		if (scene_mode == ETestbedMode::None) throw std::runtime_error("Data path '" + path + "' does not exist.");
+		if (scene_mode != ETestbedMode::Nerf && scene_mode != ETestbedMode::Geometry) throw std::runtime_error("Only NeRF and geometry scenes are supported by the MI355X renderer.");
+		m_testbed_mode = scene_mode;
+		m_data_path = path;
+		if (scene_mode == ETestbedMode::Geometry) {
+			check(ngp_load_scene(m_ctx, path.c_str()));
+			sync_model_state();
+		} else {
+			check(ngp_load_training_data(m_ctx, path.c_str()));
+			sync_dataset();
+		}
+	}
+	void load_snapshot(const std::string& path) {
+		check(ngp_load_snapshot_file(m_ctx, path.c_str()));
+		if (m_testbed_mode != ETestbedMode::Geometry) m_testbed_mode = ETestbedMode::Nerf;
+		sync_model_state();
+		float m[12], rfl[2], sc[2], zoom;
+		int32_t axis;
+		if (ngp_get_snapshot_camera(m_ctx, m, rfl, &axis, sc, &zoom) == 0) { // src/testbed.cu:5404-5420
+			memcpy(m_camera.data(), m, sizeof(m));
+			m_relative_focal_length = {rfl[0], rfl[1]};
+			m_fov_axis = axis;
+			m_screen_center = {sc[0], sc[1]};
+			m_zoom = zoom;
+		}
+	}
+	void save_snapshot(const std::string& path, bool include_optimizer_state = false, bool compress = true) {
+		(void)include_optimizer_state; // inference state only
+		check(ngp_save_snapshot_file(m_ctx, path.c_str(), compress ? 1 : 0));
+	}
+	void load_file(const std::string& path) { // src/testbed.cu:319-395
+		auto ends = [&](const char* e) { size_t n = strlen(e); return path.size() >= n && strcasecmp(path.c_str() + path.size() - n, e) == 0; };
+		if (ends(".ingp") || ends(".msgpack")) { load_snapshot(path); return; }
+		load_training_data(path);
+	}
+	void load_mesh(const std::string& path, const std::array<float, 3>& center = {0.f, 0.f, 0.f}) {
+		check(ngp_load_mesh_file(m_ctx, path.c_str(), center.data()));
+		m_testbed_mode = ETestbedMode::Geometry;
+	}
+
+	// ---- camera (src/testbed.cu:425-427, 481-496, 541-566, 3750-3764, 4474-4481)
+	void reset_camera() {
+		m_fov_axis = 1;
+		m_zoom = 1.0f;
+		m_screen_center = {0.5f, 0.5f};
+		set_fov(50.625f);
+		m_scale = 1.5f;
+		m_camera = {1.f, 0.f, 0.f, 0.f, -1.f, 0.f, 0.f, 0.f, -1.f, 0.5f, 0.5f, 0.5f};
+		for (int i = 0; i < 3; ++i) m_camera[9 + i] -= m_scale * m_camera[6 + i];
+	}
+	void set_nerf_camera_matrix(const std::array<float, 12>& cam /* column-major 4x3, NeRF convention */) {
+		std::array<float, 12> r = cam; // NerfDataset::nerf_matrix_to_ngp, nerf_loader.h:101-120
+		const auto& ds = nerf.training.dataset;
+		for (int i = 0; i < 3; ++i) {
+			r[3 + i] *= -1.f;
+			r[6 + i] *= -1.f;
+			r[9 + i] = r[9 + i] * ds.scale + ds.offset[i];
+		}
+		for (int c = 0; c < 4; ++c) {
+			float t = r[c * 3 + 0];
+			r[c * 3 + 0] = r[c * 3 + 1];
+			r[c * 3 + 1] = r[c * 3 + 2];
+			r[c * 3 + 2] = t;
+		}
+		m_camera = r;
+	}
+	void set_camera_to_training_view(int trainview) {
+		const auto& ds = nerf.training.dataset;
+		if (trainview < 0 || (size_t)trainview >= ds.n_images) throw std::runtime_error("Invalid training view.");
+		m_camera = ds.xforms[(size_t)trainview];
+		const auto& md = ds.metadata[(size_t)trainview];
+		for (int i = 0; i < 2; ++i) m_relative_focal_length[i] = md.focal_length[i] / (float)md.resolution[m_fov_axis];
+		m_screen_center = {1.0f - md.principal_point[0], 1.0f - md.principal_point[1]};
+		nerf.training.view = trainview;
+	}
+	float fov() const { return 2.0f * 180.0f / 3.14159265358979323846f * std::atan(1.0f / (m_relative_focal_length[m_fov_axis] * 2.0f)); }
+	void set_fov(float degrees) {
+		float f = 0.5f / std::tan(0.5f * degrees * 3.14159265358979323846f / 180.0f);
+		m_relative_focal_length = {f, f};
+	}
+
+	// ---- render: Testbed::render_to_cpu (src/python_api.cu:124-202). out: height*width*4 floats.
+	void render_to_cpu(float* out, int width, int height, int spp, bool linear, float start_time = -1.f, float end_time = -1.f, float fps = 30.f, float shutter_fraction = 1.0f, float* depth_out = nullptr) {
+		(void)fps; (void)shutter_fraction;
+		if (start_time >= 0.f || end_time >= 0.f) throw std::runtime_error("camera-path rendering (start_t/end_t) is not supported by the MI355X renderer");
+		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap) throw std::runtime_error("only render modes Shade and ShadeEnvMap are supported (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
+		ngp_camera cam{};
+		memcpy(cam.matrix, m_camera.data(), sizeof(cam.matrix));
+		cam.width = width;
+		cam.height = height;
+		const float res_axis = (float)(m_fov_axis == 0 ? width : height);
+		cam.focal_length[0] = m_relative_focal_length[0] * res_axis * m_zoom; // calc_focal_length
+		cam.focal_length[1] = m_relative_focal_length[1] * res_axis * m_zoom;
+		cam.screen_center[0] = (0.5f - m_screen_center[0]) * m_zoom + 0.5f;   // render_screen_center
+		cam.screen_center[1] = (0.5f - m_screen_center[1]) * m_zoom + 0.5f;
+		cam.spp_index = 0;
+		cam.snap_to_pixel_centers = m_snap_to_pixel_centers ? 1 : 0;
+		cam.near_distance = m_render_near_distance;
+		ngp_render_opts o{};
+		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : NGP_RENDER_SHADE;
+		o.min_transmittance = nerf.render_min_transmittance;
+		memcpy(o.background, m_background_color.data(), sizeof(o.background));
+		o.exposure = m_exposure;
+		o.to_srgb = linear ? 0 : 1;
+		o.spp = spp;
+		o.shard_index = 0;
+		o.shard_count = 1;
+		o.testbed_mode = m_testbed_mode == ETestbedMode::Geometry ? NGP_MODE_GEOMETRY : NGP_MODE_NERF;
+		ngp_geometry_opts g{};
+		memcpy(g.sun_dir, m_sun_dir.data(), 12);
+		memcpy(g.up_dir, m_up_dir.data(), 12);
+		g.metallic = brdf.metallic; g.subsurface = brdf.subsurface; g.specular = brdf.specular; g.roughness = brdf.roughness;
+		g.sheen = brdf.sheen; g.clearcoat = brdf.clearcoat; g.clearcoat_gloss = brdf.clearcoat_gloss;
+		memcpy(g.basecolor, brdf.basecolor.data(), 12);
+		memcpy(g.ambientcolor, brdf.ambientcolor.data(), 12);
+		ngp_set_geometry_opts(m_ctx, &g);
+		check(ngp_render(m_ctx, &cam, &o, out, depth_out));
+	}
+	// irradiance probe pre-pass: what src/main.cu:185-188 calls before the render loop in ShadeEnvMap mode
+	void computeEnvmapMultipleMain(uint32_t n_theta = 256, uint32_t n_phi = 128, uint32_t n_origin = 1) {
+		ngp_probe_desc d{};
+		d.mode = n_origin > 1 ? NGP_PROBE_MULTI_CENTER : NGP_PROBE_CENTER;
+		d.n_theta = n_theta; d.n_phi = n_phi; d.n_origin = n_origin;
+		d.min_transmittance = nerf.render_min_transmittance;
+		check(ngp_compute_envmap(m_ctx, &d, nullptr));
+	}
+
+	struct BRDFParams { // common.h:167-177
+		float metallic = 0.f, subsurface = 0.f, specular = 1.f, roughness = 0.5f, sheen = 0.f, clearcoat = 0.f, clearcoat_gloss = 0.f;
+		std::array<float, 3> basecolor{0.8f, 0.8f, 0.8f}, ambientcolor{0.f, 0.f, 0.f};
+	} brdf;
+
+	ngp_ctx* ctx() { return m_ctx; }
+
+	// public state, names as in testbed.h
+	ETestbedMode m_testbed_mode;
+	std::array<float, 12> m_camera{};
+	std::array<float, 2> m_relative_focal_length{1.f, 1.f};
+	uint32_t m_fov_axis = 1;
+	float m_zoom = 1.f;
+	std::array<float, 2> m_screen_center{0.5f, 0.5f};
+	float m_scale = 1.0f;
+	std::array<float, 4> m_background_color{0.f, 0.f, 0.f, 1.f};
+	std::array<float, 3> m_up_dir{0.f, 1.f, 0.f};
+	std::array<float, 3> m_sun_dir{0.57735026f, 0.57735026f, 0.57735026f};
+	float m_exposure = 0.f;
+	// The fork defaults to ShadeGridEnvMap, for which the reference has no kernel; every BASELINE run pins Shade.
+	ERenderMode m_render_mode = ERenderMode::Shade;
+	bool m_snap_to_pixel_centers = false;
+	float m_render_near_distance = 0.f;
+	bool m_train = false;
+	std::string m_data_path, m_root_dir;
+	std::array<float, 6> m_aabb{0, 0, 0, 1, 1, 1}, m_render_aabb{0, 0, 0, 1, 1, 1};
+	uint32_t m_training_step = 0;
+	float m_loss = 0.f;
+
+private:
+	void check(int rc) {
+		if (rc != 0) throw std::runtime_error(ngp_last_error(m_ctx));
+	}
+	void sync_dataset() {
+		auto& ds = nerf.training.dataset;
+		int n = ngp_n_training_views(m_ctx);
+		ds.n_images = n > 0 ? (size_t)n : 0;
+		ds.metadata.resize(ds.n_images);
+		ds.xforms.resize(ds.n_images);
+		for (size_t i = 0; i < ds.n_images; ++i) {
+			int32_t res[2];
+			ngp_get_training_view(m_ctx, (int)i, ds.xforms[i].data(), res, ds.metadata[i].focal_length.data(), ds.metadata[i].principal_point.data());
+			ds.metadata[i].resolution = {res[0], res[1]};
+		}
+		int32_t aabb_scale = 1, is_hdr = 0;
+		ngp_get_dataset_info(m_ctx, &aabb_scale, &ds.scale, ds.offset.data(), &is_hdr);
+		ds.aabb_scale = aabb_scale;
+	}
+	void sync_model_state() {
+		ngp_model_desc d;
+		if (ngp_get_model(m_ctx, &d) == 0) {
+			memcpy(m_aabb.data(), d.aabb_min, 12); memcpy(m_aabb.data() + 3, d.aabb_max, 12);
+			memcpy(m_render_aabb.data(), d.render_aabb_min, 12); memcpy(m_render_aabb.data() + 3, d.render_aabb_max, 12);
+			nerf.cone_angle_constant = d.cone_angle_constant;
+		}
+		sync_dataset();
+	}
+	ngp_ctx* m_ctx = nullptr;
+};
+
+} // namespace ngp

@@ -1,0 +1,99 @@
+"""The drop-in surface: the pybind11 module `pyngp` (reference src/python_api.cu) driven the way scripts/run.py
+drives it: load snapshot / training data, set the camera, render."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg, psnr
+
+
+@pytest.fixture(scope="module")
+def pyngp():
+    return pkg("build").import_pyngp()
+
+
+def test_pyngp_surface(pyngp):
+    for name in ("Testbed", "TestbedMode", "RenderMode"):
+        assert hasattr(pyngp, name)
+    assert pyngp.TestbedMode.Geometry != pyngp.TestbedMode.Nerf and hasattr(pyngp.RenderMode, "ShadeEnvMap")
+    for m in ("load_training_data", "load_snapshot", "save_snapshot", "load_file", "render", "set_nerf_camera_matrix", "set_camera_to_training_view",
+              "camera_matrix", "fov", "fov_axis", "background_color", "snap_to_pixel_centers", "exposure", "render_mode", "shall_train", "nerf",
+              "screen_center", "root_dir", "sun_dir", "up_dir"):
+        assert hasattr(pyngp.Testbed, m), m
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            pyngp.Testbed()
+
+
+@pytest.mark.gpu
+def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene_unit):
+    # a snapshot + a transforms.json on disk, like `run.py --load_snapshot s.ingp --screenshot_transforms t.json`
+    gpu_ctx.set_model(scene_unit)
+    snap = str(tmp_path / "lego.ingp")
+    gpu_ctx.save_snapshot_file(snap)
+    frames = []
+    for az in (30.0, 140.0):
+        c2w = np.eye(4, dtype=np.float64)
+        ngp = scene_mod.orbit_camera(az)  # invert nerf_matrix_to_ngp to get a NeRF-convention pose
+        m = ngp[[2, 0, 1], :].copy()
+        m[:, 3] = (m[:, 3] - 0.5) / 0.33
+        m[:, 1] *= -1
+        m[:, 2] *= -1
+        c2w[:3, :4] = m
+        frames.append({"file_path": f"r_{int(az)}", "transform_matrix": c2w.tolist()})
+    tj = tmp_path / "transforms.json"
+    tj.write_text(json.dumps({"camera_angle_x": 0.6911, "w": 160, "h": 90, "aabb_scale": 1, "frames": frames}))
+
+    testbed = pyngp.Testbed()
+    testbed.root_dir = str(tmp_path)
+    testbed.load_file(snap)
+    assert testbed.mode == pyngp.TestbedMode.Nerf
+    testbed.shall_train = False
+    with pytest.raises(RuntimeError, match="out of scope"):
+        testbed.shall_train = True
+    testbed.background_color = [0.0, 0.0, 0.0, 1.0]
+    testbed.snap_to_pixel_centers = True
+    testbed.nerf.render_min_transmittance = 1e-4
+    testbed.load_training_data(str(tj))
+    assert testbed.nerf.training.dataset.n_images == 2
+    res = testbed.nerf.training.dataset.metadata[0].resolution
+    assert list(res) == [160, 90]
+    testbed.fov_axis = 0
+    testbed.fov = 0.6911 * 180 / np.pi
+    with open(tj) as f:
+        ref_transforms = json.load(f)
+    for idx, fr in enumerate(ref_transforms["frames"]):
+        testbed.set_nerf_camera_matrix(np.matrix(fr["transform_matrix"])[:-1, :])
+        image = testbed.render(160, 90, 1, True)
+        assert image.shape == (90, 160, 4) and image.dtype == np.float32
+        az = (30.0, 140.0)[idx]
+        cam = native.make_camera(scene_mod.orbit_camera(az), 160, 90, scene_mod.focal_from_fov_x(160, 0.6911))
+        direct = gpu_ctx.render(cam, native.make_opts(min_transmittance=1e-4))
+        assert psnr(image[..., :3], direct[..., :3]) > 45.0  # the pose goes through a fp32 NeRF<->NGP round trip
+        assert np.allclose(testbed.camera_matrix, scene_mod.orbit_camera(az), atol=1e-5)
+    # training-view camera (principal point + focal from metadata) renders the same view
+    testbed.set_camera_to_training_view(1)
+    image2 = testbed.render(160, 90, 1, True)
+    assert psnr(image2[..., :3], image[..., :3]) > 45.0
+    # sRGB output and a second sample
+    srgb = testbed.render(160, 90, 2, False)
+    assert srgb.shape == (90, 160, 4) and srgb[..., :3].mean() > image2[..., :3].mean()
+    testbed.save_snapshot(str(tmp_path / "again.msgpack"))
+    t2 = pyngp.Testbed()
+    t2.load_snapshot(str(tmp_path / "again.msgpack"))
+    t2.snap_to_pixel_centers = True
+    t2.nerf.render_min_transmittance = 1e-4
+    t2.camera_matrix = testbed.camera_matrix
+    t2.fov_axis = 0
+    t2.relative_focal_length = testbed.relative_focal_length
+    t2.screen_center = testbed.screen_center
+    assert np.array_equal(t2.render(160, 90, 1, True), image2)
+    with pytest.raises(RuntimeError, match="does not exist"):
+        testbed.load_training_data(str(tmp_path / "nope"))
+    testbed.render_mode = pyngp.RenderMode.Normals
+    with pytest.raises(RuntimeError, match="only render modes"):
+        testbed.render(8, 8, 1, True)
