@@ -17,7 +17,11 @@
 namespace ngp {
 
 constexpr int BLOCK = 256;
-constexpr int REFILL_MIN = 8; // refill once at least this many of a wave's 64 ray slots are free
+// Scheduling knobs of the wave loop (FrameParams::tune, defaults set by the host):
+//   refill_min  refill once at least this many of a wave's 64 ray slots are free
+//   skip_steps  empty-space iterations per lane between two looks at the sample queue
+//   go_min      run the network once this many samples wait ...
+//   max_stall   ... or after this many rounds of waiting for marching lanes
 
 struct Accum {
 	float r, g, b, a;
@@ -101,12 +105,26 @@ NGP_DEV void init_probe_ray(const ProbeParams& P, uint32_t q, RayState& r) {
 	r.alive = true;
 }
 
-template <bool PROBE>
+// s_memtime stamp for the diagnostic section profile (cdna_hip_programming.md "In-kernel stamps"); never executed by
+// the production instantiation
+NGP_DEV unsigned long long stamp() {
+	unsigned long long t;
+	__builtin_amdgcn_sched_barrier(0);
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+	__builtin_amdgcn_sched_barrier(0);
+	return t;
+}
+
+template <bool PROBE, bool PROF = false>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	__shared__ uint4 s_w[N_FRAGS * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
+	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP]; // 32 KB: empty-space summary of the occupancy grid
+	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < (M.max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
+	if (threadIdx.x < NERF_CASCADES * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
 	__syncthreads();
 
 	const int lane = threadIdx.x & 63;
@@ -116,7 +134,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
 	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
 
-	// per-lane ray slot
+	// per-lane ray slot. A slot is free (!alive), marching through empty space (alive && !ready) or holding a
+	// sample that waits for the network (ready).
 	RayState ray;
 	ray.alive = false;
 	ray.o = ray.d = mk3(0.f, 0.f, 0.f);
@@ -125,17 +144,33 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	f3 idir = mk3(0.f, 0.f, 0.f);
 	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint32_t step = 1;
+	uint32_t skip_i = 1;
+	bool ready = false, counted = false;
+	bool finished = false; // the ray has ended and waits to be shaded (once per round, with every other finished ray)
+	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 
 	// wave-uniform tile reservoir
 	uint32_t tile = 0, tile_next = 64;
 	bool exhausted = false;
+	int stall = 0;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
+	unsigned long long pt[4] = {0, 0, 0, 0}, p_iters = 0, p_passes = 0, p_rounds = 0, p_lane_steps = 0, t0 = 0, t1 = 0;
 
 	for (;;) {
-		// ---- refill free slots from the tile queue (K1 + K2)
+		if (PROF) t0 = stamp();
+		// ---- retire: K7 for every ray that ended since the last round (kept out of the divergent march / composite code)
+		if (__any(finished)) {
+			if (finished) {
+				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
+				finished = false;
+			}
+		}
+		// ---- refill free slots from the tile queue: K1 and the start-of-ray jitter of K2. The skip to the first
+		// occupied voxel that K2 also does (advance_pos_nerf, :356) is the same loop as K4's and runs below with every
+		// other marching lane -- a ray with nothing in front of it must not stall the 63 other slots of its wave.
 		unsigned long long dead_mask = __ballot(!ray.alive);
 		int n_dead = __popcll(dead_mask);
-		if (!exhausted && n_dead >= REFILL_MIN) {
+		if (!exhausted && n_dead >= F.tune[0]) {
 			if (tile_next >= 64) {
 				uint32_t tq = 0;
 				if (lane == 0) tq = atomicAdd(F.queue, 1u);
@@ -149,14 +184,12 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 			if (!exhausted) {
 				uint32_t slot = tile_next + lanes_below(dead_mask);
+				bool fresh = false;
 				if (PROBE) {
 					uint32_t q = tile * 64u + slot;
 					if (!ray.alive && slot < 64 && q < P.n_rays) {
 						init_probe_ray(P, q, ray);
-						idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-						acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-						step = 1;
-						++n_alive_init;
+						fresh = true;
 					}
 				} else if (!ray.alive && slot < 64) {
 					uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
@@ -165,50 +198,91 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 						init_ray(M, C, x, y, ray);
 						// src/testbed_nerf.cu:1490-1493
 						if (F.depth_buffer[ray.idx] < 0.01f) F.depth_buffer[ray.idx] = MAX_DEPTH;
-						advance_pos(M, C, ray);
 						if (ray.alive) {
-							idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-							acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-							step = 1;
-							++n_alive_init;
+							ray.t = advance_n_steps(ray.t, M.cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
+							fresh = true;
 						}
 					}
+				}
+				if (fresh) {
+					idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+					acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+					step = 1;
+					skip_i = 1;
+					ready = false;
+					counted = PROBE; // probe rays count as alive from the start (there is no K2 for them)
+					if (PROBE) ++n_alive_init;
 				}
 				uint32_t adv = tile_next + (uint32_t)n_dead;
 				tile_next = adv > 64u ? 64u : adv;
 			}
 		}
 
-		// ---- K4: skip empty space, emit the next sample (generate_next_nerf_network_inputs, :430-477)
-		float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
-		if (ray.alive) {
-			float t = skip_empty_space<PROBE>(ray.t, M, ray.o, ray.d, idir); // trace_mesh uses the 200-iteration skip
-			if (t >= MAX_DEPTH) {
-				ray.alive = false;
-				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
-			} else {
-				float dt = calc_dt(t, M.cone_angle);
-				f3 w = div3(sub3(add3(ray.o, scale3(ray.d, t)), amin), adiag); // warp_position
-				wx = w.x; wy = w.y; wz = w.z;
-				wdt = warp_dt(dt);
-				ray.t = t + dt;
+		if (PROF) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; }
+		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494), at most SKIP_STEPS of
+		// its iterations per lane and round; a lane that reaches an occupied voxel emits its sample and waits.
+		for (int k = 0; k < F.tune[1]; ++k) {
+			const bool marching = ray.alive && !ready;
+			if (!__any(marching)) break;
+			if (PROF) { ++p_rounds; p_lane_steps += (unsigned long long)__popcll(__ballot(marching)); }
+			if (marching) {
+				f3 pos = add3(ray.o, scale3(ray.d, ray.t));
+				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
+				if (PROBE && skip_i >= 200) out = true; // the 200-iteration variant of trace_mesh (:497-534)
+				if (out) {
+					ray.alive = false;
+					finished = true;
+				} else {
+					uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
+					mip = mip > M.max_cascade ? M.max_cascade : mip;
+					uint32_t empty = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip);
+					if (empty == 0u) {
+						float dt = calc_dt(ray.t, M.cone_angle);
+						f3 w = div3(sub3(pos, amin), adiag); // warp_position
+						wx = w.x; wy = w.y; wz = w.z;
+						wdt = warp_dt(dt);
+						ray.t = ray.t + dt;
+						ready = true;
+						skip_i = 1;
+						if (!counted) { counted = true; ++n_alive_init; }
+					} else {
+						// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
+						// the cell, so the block summary of the final level is looked up again
+						while (mip < M.max_cascade) {
+							uint32_t e = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1);
+							if (e == 0u) break;
+							++mip;
+							empty = e;
+						}
+						ray.t = advance_to_next_voxel(ray.t, M.cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
+						++skip_i;
+					}
+				}
 			}
 		}
-		unsigned long long alive_mask = __ballot(ray.alive);
-		int n_alive = __popcll(alive_mask);
-		if (n_alive == 0) {
-			if (exhausted) break;
+		unsigned long long ready_mask = __ballot(ready);
+		int n_ready = __popcll(ready_mask);
+		const bool any_marching = __any(ray.alive && !ready);
+		if (PROF) { t1 = stamp(); pt[1] += t1 - t0; t0 = t1; ++p_iters; }
+		if (n_ready == 0) {
+			if (exhausted && !__any(ray.alive) && !__any(finished)) break;
 			continue;
 		}
+		// run the network once enough samples wait, or nothing else can make progress; never starve a waiting sample
+		if (n_ready < F.tune[2] && any_marching && stall < F.tune[3]) {
+			++stall;
+			continue;
+		}
+		stall = 0;
 
-		// ---- compact live slots onto MFMA sample slots: a bijection lane -> slot (live first)
-		uint32_t my_slot = ray.alive ? lanes_below(alive_mask) : (uint32_t)n_alive + lanes_below(~alive_mask);
+		// ---- compact waiting samples onto MFMA sample slots: a bijection lane -> slot (ready lanes first)
+		uint32_t my_slot = ready ? lanes_below(ready_mask) : (uint32_t)n_ready + lanes_below(~ready_mask);
 		int slot_owner = __builtin_amdgcn_ds_permute((int)(my_slot * 4u), lane); // lane k learns who owns slot k
 		float ddx = (ray.d.x + 1.0f) * 0.5f, ddy = (ray.d.y + 1.0f) * 0.5f, ddz = (ray.d.z + 1.0f) * 0.5f; // warp_direction
 
 		// ---- K5: network, 16 samples per pass
 		half_t o_r = 0, o_g = 0, o_b = 0, o_s = 0;
-		const int n_pass = (n_alive + 15) >> 4;
+		const int n_pass = (n_ready + 15) >> 4;
 		for (int p = 0; p < n_pass; ++p) {
 			int src = __shfl(slot_owner, 16 * p + c, 64);
 			float sx = __shfl(wx, src, 64), sy = __shfl(wy, src, 64), sz = __shfl(wz, src, 64);
@@ -227,8 +301,10 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 		}
 
+		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
-		if (ray.alive) {
+		if (ready) {
+			ready = false;
 			++n_samples;
 			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
 			float T = 1.0f - acc.a;
@@ -247,11 +323,19 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			if (acc.a > (1.0f - F.min_transmittance)) {
 				acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
 				ray.alive = false;
-				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
+				finished = true;
 			} else if (step >= MARCH_ITER) {
 				ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
 			}
 		}
+		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; }
+	}
+	if (PROF && lane == 0 && F.prof) {
+		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], pt[k]);
+		atomicAdd(&F.prof[4], p_iters);
+		atomicAdd(&F.prof[5], p_passes);
+		atomicAdd(&F.prof[6], p_rounds);
+		atomicAdd(&F.prof[7], p_lane_steps);
 	}
 
 	// ---- counters (one atomic per wave and counter)
@@ -270,6 +354,11 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 __global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false>(M, C, F, P);
+}
+// diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
+__global__ __launch_bounds__(BLOCK) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, true>(M, C, F, P);
 }
 
 // the same machinery fed by the probe ray fans instead of the camera (Testbed::computeEnvmap*, testbed.h:709-743)
@@ -429,6 +518,30 @@ __global__ void grid_to_bitfield_kernel(uint32_t n_elements, uint32_t n_nonzero_
 	bitfield[i] = bits;
 }
 
+// empty-space summary: one bit per 4x4x4 block (8 consecutive Morton-ordered bytes) of every mip
+__global__ void coarse_occupancy_kernel(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
+	uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; // output word: 32 blocks = 256 bytes of bitfield
+	if (w >= NERF_CASCADES * COARSE_WORDS_PER_MIP) return;
+	const uint2* src = (const uint2*)(bitfield + (size_t)w * 256);
+	uint32_t bits = 0;
+	for (int b = 0; b < 32; ++b) {
+		uint2 v = src[b];
+		bits |= ((v.x | v.y) != 0u ? 1u : 0u) << b;
+	}
+	coarse[w] = bits;
+}
+// second level: one bit per 16x16x16 block = 64 consecutive 4x4x4 blocks = 2 words of the first level
+__global__ void coarse16_occupancy_kernel(uint32_t* __restrict__ coarse) {
+	uint32_t w = threadIdx.x; // NERF_CASCADES * 16 output words
+	if (w >= NERF_CASCADES * 16) return;
+	uint32_t bits = 0;
+	for (int b = 0; b < 32; ++b) {
+		uint32_t a0 = coarse[(size_t)(w * 32 + b) * 2], a1 = coarse[(size_t)(w * 32 + b) * 2 + 1];
+		bits |= ((a0 | a1) != 0u ? 1u : 0u) << b;
+	}
+	coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + w] = bits;
+}
+
 __global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_elements) return;
@@ -476,7 +589,8 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 // ---------------------------------------------------------------------------------------------------------
 // launchers (called from ngp_api.cpp)
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream) {
-	hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 }
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream) {
 	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, F, P);
@@ -519,6 +633,11 @@ void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_gri
 		hipLaunchKernelGGL(bitfield_max_pool_kernel, dim3((n_elements / 64 + 255) / 256), dim3(256), 0, stream, n_elements / 64,
 		                   d_bitfield + (size_t)(level - 1) * (n_elements / 8), d_bitfield + (size_t)level * (n_elements / 8));
 	}
+}
+void launch_coarse_occupancy(const uint8_t* bitfield, uint32_t* coarse, hipStream_t stream) {
+	uint32_t n = NERF_CASCADES * COARSE_WORDS_PER_MIP;
+	hipLaunchKernelGGL(coarse_occupancy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bitfield, coarse);
+	hipLaunchKernelGGL(coarse16_occupancy_kernel, dim3(1), dim3(128), 0, stream, coarse);
 }
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
                                float exposure, int to_srgb, float4* rgba_out, hipStream_t stream) {

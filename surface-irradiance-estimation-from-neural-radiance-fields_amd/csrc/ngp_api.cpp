@@ -183,6 +183,8 @@ void free_model(ngp_ctx* ctx) {
 	if (ctx->d_params) (void)hipFree(ctx->d_params);
 	if (ctx->d_wfrags) (void)hipFree(ctx->d_wfrags);
 	if (ctx->d_bitfield) (void)hipFree(ctx->d_bitfield);
+	if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
+	ctx->d_coarse = nullptr;
 	if (ctx->d_density_f16) (void)hipFree(ctx->d_density_f16);
 	if (ctx->d_density_f32) (void)hipFree(ctx->d_density_f32);
 	if (ctx->d_partial) (void)hipFree(ctx->d_partial);
@@ -258,10 +260,13 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	}
 	launch_density_grid_to_bitfield(ctx->d_density_f16, (uint32_t)d.n_density_grid, max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield,
 	                                &ctx->bitfield_mean, ctx->stream);
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_coarse, ((size_t)NERF_CASCADES * COARSE_WORDS_PER_MIP + NERF_CASCADES * 16) * sizeof(uint32_t)));
+	launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, ctx->stream);
 	NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	NGP_HIP_CHECK(hipGetLastError());
 
 	M.grid = (const uint2*)ctx->d_params;
+	M.coarse = ctx->d_coarse;
 	M.wfrags = ctx->d_wfrags;
 	M.bitfield = ctx->d_bitfield;
 	for (int i = 0; i < 3; ++i) {
@@ -271,6 +276,10 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		M.raabb_max[i] = d.render_aabb_max[i];
 	}
 	for (int i = 0; i < 9; ++i) M.r2l[i] = d.render_aabb_to_local[i];
+	{
+		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		M.r2l_identity = memcmp(M.r2l, ident, sizeof(ident)) == 0 ? 1u : 0u;
+	}
 	M.max_cascade = max_cascade;
 	M.cone_angle = d.cone_angle_constant;
 	M.rgb_act = d.rgb_activation;
@@ -745,6 +754,14 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.n_local_tiles = n_tiles > opts.shard_index ? (n_tiles - opts.shard_index + shard_count - 1) / shard_count : 0;
 	F.min_transmittance = opts.min_transmittance;
 	F.linear_colors = ctx->desc.linear_colors;
+	F.prof = nullptr;
+	memcpy(F.tune, ctx->tune, sizeof(F.tune));
+	if (const char* t = getenv("NGP_TUNE")) sscanf(t, "%d,%d,%d,%d", &F.tune[0], &F.tune[1], &F.tune[2], &F.tune[3]); // experiments only
+	if (getenv("NGP_PROFILE_SECTIONS")) { // diagnostic: per-section cycle sums of the fused kernel, printed by ngp_get_render_stats
+		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 64));
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 64, stream));
+		F.prof = ctx->d_prof;
+	}
 	const bool geometry = opts.testbed_mode == NGP_MODE_GEOMETRY;
 	const bool have_meshes = geometry && !ctx->meshes.empty();
 	F.depth_test = geometry ? 1 : 0; // shade_kernel_nerf_geometry
@@ -753,6 +770,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		for (int i = 0; i < 3; ++i) { M.raabb_min[i] = ctx->mesh_scene.scene_min[i]; M.raabb_max[i] = ctx->mesh_scene.scene_max[i]; }
 		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 		memcpy(M.r2l, ident, sizeof(ident));
+		M.r2l_identity = 1u;
 	}
 
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
@@ -1073,6 +1091,13 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 		if (!ctx->n_calls) throw std::runtime_error("nothing rendered yet");
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
 		read_history_slot(ctx, ctx->n_calls - 1, out);
+		if (ctx->d_prof && getenv("NGP_PROFILE_SECTIONS")) {
+			unsigned long long p[8];
+			NGP_HIP_CHECK(hipMemcpy(p, ctx->d_prof, sizeof(p), hipMemcpyDeviceToHost));
+			double tot = (double)(p[0] + p[1] + p[2] + p[3]);
+			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
+			        100.0 * p[0] / tot, 100.0 * p[1] / tot, 100.0 * p[2] / tot, 100.0 * p[3] / tot, p[4], p[5], tot / (double)p[4], (double)p[2] / (double)p[5], p[6], p[7], (double)p[7] / (double)p[6], (double)p[1] / (double)p[6]);
+		}
 	});
 }
 

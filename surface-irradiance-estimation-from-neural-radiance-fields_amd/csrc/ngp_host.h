@@ -30,6 +30,7 @@ void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos
 void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream);
 void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_grid, uint32_t max_cascade, float* d_grid_f32, double* d_partial,
                                      uint8_t* d_bitfield, float* out_mean, hipStream_t stream);
+void launch_coarse_occupancy(const uint8_t* bitfield, uint32_t* coarse, hipStream_t stream);
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
                                float exposure, int to_srgb, float4* rgba_out, hipStream_t stream);
 
@@ -89,6 +90,7 @@ struct ngp_ctx {
 	void* d_params = nullptr;
 	uint4* d_wfrags = nullptr;
 	uint8_t* d_bitfield = nullptr;
+	uint32_t* d_coarse = nullptr;
 	uint16_t* d_density_f16 = nullptr;
 	float* d_density_f32 = nullptr;
 	double* d_partial = nullptr;
@@ -130,6 +132,8 @@ struct ngp_ctx {
 	uint64_t hist_n_rays[HISTORY] = {};
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
 	hipStream_t last_stream = nullptr;
+	unsigned long long* d_prof = nullptr;
+	int32_t tune[4] = {32, 4, 32, 1};
 };
 
 namespace ngp {

@@ -47,6 +47,7 @@ struct ModelParams {
 	const uint2* grid;       // fp16 x4 per entry
 	const uint4* wfrags;     // [N_FRAGS][64] x 8 fp16, MFMA A fragments in lane order
 	const uint8_t* bitfield; // 8 x 128^3 bits
+	const uint32_t* coarse;  // 8 x 32^3 bits: bit (morton >> 6) of mip m is set iff any cell of that 4x4x4 block is occupied
 	LevelInfo levels[N_LEVELS];
 	float aabb_min[3], aabb_diag[3];
 	float raabb_min[3], raabb_max[3];
@@ -54,7 +55,9 @@ struct ModelParams {
 	uint32_t max_cascade;
 	float cone_angle;
 	uint32_t rgb_act, density_act;
+	uint32_t r2l_identity; // render_aabb_to_local is the identity (the usual case): skip the matrix product
 };
+constexpr uint32_t COARSE_WORDS_PER_MIP = 32 * 32 * 32 / 32;
 
 struct CameraParams {
 	float m[12]; // column-major 4x3
@@ -77,6 +80,8 @@ struct FrameParams {
 	float min_transmittance;
 	int32_t linear_colors;
 	int32_t depth_test;
+	int32_t tune[4];          // refill_min, skip_steps, go_min, max_stall (nerf_kernels.hip)
+	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums
 };
 
 // ---- irradiance probes

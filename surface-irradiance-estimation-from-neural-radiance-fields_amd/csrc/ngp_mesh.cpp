@@ -394,6 +394,7 @@ int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 		F.shard_count = 1;
 		F.min_transmittance = d->min_transmittance > 0.f ? d->min_transmittance : 0.01f;
 		F.linear_colors = ctx->desc.linear_colors;
+		memcpy(F.tune, ctx->tune, sizeof(F.tune));
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 		NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));

@@ -1,0 +1,15 @@
+"""Diagnostic: share of wave cycles per section of render_nerf_fused (NGP_PROFILE_SECTIONS=1 selects the stamped twin)."""
+import importlib, os, sys
+os.environ["NGP_PROFILE_SECTIONS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "surface-irradiance-estimation-from-neural-radiance-fields_amd"
+native, synthetic, scene = (importlib.import_module(PKG + "." + m) for m in ("native", "synthetic", "scene"))
+sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)
+ctx = native.Context(0)
+ctx.set_model(sc)
+w, h = 1920, 1080
+for az in (45.0, 135.0):
+    cam = native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(w, 0.6911))
+    ctx.render(cam)
+    st = ctx.render_stats()
+    print(az, st)
