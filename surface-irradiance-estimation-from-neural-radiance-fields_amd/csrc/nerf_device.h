@@ -322,11 +322,14 @@ NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, Corner
 		int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
 		uint32_t idx = L.hashed ? (ix[bx] ^ iy[by] ^ iz[bz]) : (ix[bx] + iy[by] + iz[bz]);
 		idx = L.mask ? (idx & L.mask) : (idx % L.size);
-		cs.index[c] = L.offset + idx;
+		cs.index[c] = (L.offset + idx) * 8u; // byte offset of the 4 x fp16 entry
 		cs.weight[c] = ((bx ? wx : wx0) * (by ? wy : wy0)) * (bz ? wz : wz0);
 	}
 }
 
+// result[f] += (half)(weight * (float)value[f]): hipcc turns each line into v_fma_mixlo_f16 (fp32 product rounded to
+// fp16) + v_add_f16, the same two roundings per feature as tcnn's kernel_grid. (A half2 formulation compiles to
+// cvt/mul/cvt_pk/pk_add -- more instructions -- so the scalar form stays.)
 NGP_DEV void accumulate_corner(uint2 v, float w, half_t* r) {
 	union { uint2 u; half_t h[4]; } cv;
 	cv.u = v;
@@ -345,15 +348,51 @@ NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const LevelInfo*
 	level_corners(lv[h], x, y, z, c0);
 	level_corners(lv[h + 4], x, y, z, c1);
 	uint2 v0[8], v1[8];
+	const char* base = (const char*)grid; // 32-bit byte offsets: the table is far below 4 GiB (checked by the host)
 #pragma unroll
-	for (int c = 0; c < 8; ++c) v0[c] = grid[c0.index[c]];
+	for (int c = 0; c < 8; ++c) v0[c] = *(const uint2*)(base + c0.index[c]);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) v1[c] = grid[c1.index[c]];
+	for (int c = 0; c < 8; ++c) v1[c] = *(const uint2*)(base + c1.index[c]);
 	half_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
 	for (int c = 0; c < 8; ++c) accumulate_corner(v0[c], c0.weight[c], r);
 #pragma unroll
 	for (int c = 0; c < 8; ++c) accumulate_corner(v1[c], c1.weight[c], r + 4);
+	half8 out;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) out[j] = r[j];
+	return out;
+}
+
+// The same encode split in two so that a wave can keep the gathers of two 16-sample passes (32 loads per lane) in
+// flight before it consumes either: issue computes the 16 addresses / weights and starts the loads, finish
+// accumulates. The values returned are identical to encode_level_pair's.
+struct EncodeInFlight {
+	uint2 v[16];
+	float w[16];
+};
+NGP_DEV void encode_issue(const uint2* __restrict__ grid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
+	CornerSet c0, c1;
+	level_corners(lv[h], x, y, z, c0);
+	level_corners(lv[h + 4], x, y, z, c1);
+	const char* base = (const char*)grid;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		e.v[c] = *(const uint2*)(base + c0.index[c]);
+		e.w[c] = c0.weight[c];
+	}
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		e.v[8 + c] = *(const uint2*)(base + c1.index[c]);
+		e.w[8 + c] = c1.weight[c];
+	}
+}
+NGP_DEV half8 encode_finish(const EncodeInFlight& e) {
+	half_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[c], e.w[c], r);
+#pragma unroll
+	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[8 + c], e.w[8 + c], r + 4);
 	half8 out;
 #pragma unroll
 	for (int j = 0; j < 8; ++j) out[j] = r[j];
@@ -401,14 +440,17 @@ NGP_DEV half8 ld_frag(const uint4* s_w, int f, int lane) {
 	return cv.h;
 }
 NGP_DEV floatx4 mfma16(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// ReLU + round to fp16. max(round(x), 0) == round(max(x, 0)) (rounding keeps the sign), so the ReLU runs on packed
+// halves: 4 cvt_pk + 4 pk_max per 8 activations.
 NGP_DEV half8 relu_pack(floatx4 lo, floatx4 hi) {
 	half8 r;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
-		r[j] = (half_t)fmaxf(lo[j], 0.0f);
-		r[4 + j] = (half_t)fmaxf(hi[j], 0.0f);
+		r[j] = (half_t)lo[j];
+		r[4 + j] = (half_t)hi[j];
 	}
-	return r;
+	const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+	return __builtin_elementwise_max(r, zero);
 }
 
 struct MlpOut {
@@ -416,8 +458,41 @@ struct MlpOut {
 	half_t sigma;   // density logit, valid in lanes with h == 0
 };
 
-NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, float dx01, float dy01, float dz01) {
-	const int h = lane >> 4;
+// All 16 SH coefficients of one direction as fp16 (what the owning lane stores once per ray).
+NGP_DEV void sh4_all(float dx01, float dy01, float dz01, half_t* out16) {
+	float x = dx01 * 2.0f - 1.0f, y = dy01 * 2.0f - 1.0f, z = dz01 * 2.0f - 1.0f;
+	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	out16[0] = (half_t)0.28209479177387814f;
+	out16[1] = (half_t)(-0.48860251190291987f * y);
+	out16[2] = (half_t)(0.48860251190291987f * z);
+	out16[3] = (half_t)(-0.48860251190291987f * x);
+	out16[4] = (half_t)(1.0925484305920792f * xy);
+	out16[5] = (half_t)(-1.0925484305920792f * yz);
+	out16[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
+	out16[7] = (half_t)(-1.0925484305920792f * xz);
+	out16[8] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+	out16[9] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+	out16[10] = (half_t)(2.8906114426405538f * xy * z);
+	out16[11] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+	out16[12] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+	out16[13] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+	out16[14] = (half_t)(1.4453057213202769f * z * (x2 - y2));
+	out16[15] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+}
+
+struct Sh4 { // SH coefficients 4h..4h+3 of the sample's direction, fp16
+	half_t v[4];
+};
+NGP_DEV Sh4 sh4_from_dir(int h, float dx01, float dy01, float dz01) {
+	float sh[4];
+	sh4_quad(h, dx01, dy01, dz01, sh);
+	Sh4 r;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) r.v[j] = (half_t)sh[j];
+	return r;
+}
+
+NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 	// density head: 32 -> 64 (ReLU) -> 16
 	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
@@ -428,13 +503,11 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, float dx01, float
 	floatx4 dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
 	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
 	// rgb head input: [density out 4h..4h+3 | SH 4h..4h+3]
-	float sh[4];
-	sh4_quad(h, dx01, dy01, dz01, sh);
 	half8 rin;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		rin[j] = (half_t)dens[j];
-		rin[4 + j] = (half_t)sh[j];
+		rin[4 + j] = shq.v[j];
 	}
 	MlpOut out;
 	out.sigma = rin[0];

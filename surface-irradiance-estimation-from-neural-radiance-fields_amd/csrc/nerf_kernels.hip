@@ -121,6 +121,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	__shared__ LevelInfo s_lv[N_LEVELS];
 	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP]; // 32 KB: empty-space summary of the occupancy grid
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
+	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	for (uint32_t i = threadIdx.x; i < (M.max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
@@ -205,6 +206,12 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					}
 				}
 				if (fresh) {
+					{ // K5c once per ray: the direction (and so its SH encoding) is constant along the ray
+						union { half_t h[16]; uint2 u[4]; } sh;
+						sh4_all((ray.d.x + 1.0f) * 0.5f, (ray.d.y + 1.0f) * 0.5f, (ray.d.z + 1.0f) * 0.5f, sh.h);
+#pragma unroll
+						for (int q = 0; q < 4; ++q) s_sh[threadIdx.x * 4 + q] = sh.u[q];
+					}
 					idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
 					acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 					step = 1;
@@ -278,27 +285,59 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// ---- compact waiting samples onto MFMA sample slots: a bijection lane -> slot (ready lanes first)
 		uint32_t my_slot = ready ? lanes_below(ready_mask) : (uint32_t)n_ready + lanes_below(~ready_mask);
 		int slot_owner = __builtin_amdgcn_ds_permute((int)(my_slot * 4u), lane); // lane k learns who owns slot k
-		float ddx = (ray.d.x + 1.0f) * 0.5f, ddy = (ray.d.y + 1.0f) * 0.5f, ddz = (ray.d.z + 1.0f) * 0.5f; // warp_direction
 
-		// ---- K5: network, 16 samples per pass
+		// ---- K5: network, 16 samples per pass; two passes are run together whenever 17+ samples wait, so that 32
+		// gathers per lane and two independent MFMA chains are in flight (the loop is latency-, not issue-bound)
 		half_t o_r = 0, o_g = 0, o_b = 0, o_s = 0;
 		const int n_pass = (n_ready + 15) >> 4;
-		for (int p = 0; p < n_pass; ++p) {
+		const int wave_base = threadIdx.x & ~63;
+		const int hq = lane >> 4;
+		const int from = (int)(my_slot & 15u);
+		const int my_pass = (int)(my_slot >> 4);
+		auto sample_of = [&](int p, float& sx, float& sy, float& sz, Sh4& shq) {
 			int src = __shfl(slot_owner, 16 * p + c, 64);
-			float sx = __shfl(wx, src, 64), sy = __shfl(wy, src, 64), sz = __shfl(wz, src, 64);
-			float sdx = __shfl(ddx, src, 64), sdy = __shfl(ddy, src, 64), sdz = __shfl(ddz, src, 64);
-			half8 enc = encode_level_pair(M.grid, s_lv, lane >> 4, sx, sy, sz);
-			MlpOut mo = mlp_pass(s_w, lane, enc, sdx, sdy, sdz);
+			sx = __shfl(wx, src, 64);
+			sy = __shfl(wy, src, 64);
+			sz = __shfl(wz, src, 64);
+			union { uint2 u; half_t h[4]; } cv; // the 4 SH coefficients this lane group feeds to the rgb head
+			cv.u = s_sh[(wave_base + src) * 4 + hq];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) shq.v[j] = cv.h[j];
+		};
+		auto deliver = [&](int p, const MlpOut& mo) {
 			// results live in lanes 0..15 (h == 0); the owner of slot 16p+c pulls them from lane c
 			union { half_t h[2]; int i; } lo, hi;
 			lo.h[0] = mo.rgb[0]; lo.h[1] = mo.rgb[1];
 			hi.h[0] = mo.rgb[2]; hi.h[1] = mo.sigma;
-			int from = (int)(my_slot & 15u);
 			int rlo = __shfl(lo.i, from, 64), rhi = __shfl(hi.i, from, 64);
-			if ((int)(my_slot >> 4) == p) {
+			if (my_pass == p) {
 				lo.i = rlo; hi.i = rhi;
 				o_r = lo.h[0]; o_g = lo.h[1]; o_b = hi.h[0]; o_s = hi.h[1];
 			}
+		};
+		int p = 0;
+		for (; p + 1 < n_pass; p += 2) {
+			float ax, ay, az, bx, by, bz;
+			Sh4 sha, shb;
+			sample_of(p, ax, ay, az, sha);
+			sample_of(p + 1, bx, by, bz, shb);
+			EncodeInFlight ea, eb;
+			encode_issue(M.grid, s_lv, hq, ax, ay, az, ea);
+			encode_issue(M.grid, s_lv, hq, bx, by, bz, eb);
+			half8 enca = encode_finish(ea);
+			half8 encb = encode_finish(eb);
+			MlpOut moa = mlp_pass(s_w, lane, enca, sha);
+			MlpOut mob = mlp_pass(s_w, lane, encb, shb);
+			deliver(p, moa);
+			deliver(p + 1, mob);
+		}
+		if (p < n_pass) {
+			float ax, ay, az;
+			Sh4 sha;
+			sample_of(p, ax, ay, az, sha);
+			half8 enc = encode_level_pair(M.grid, s_lv, hq, ax, ay, az);
+			MlpOut mo = mlp_pass(s_w, lane, enc, sha);
+			deliver(p, mo);
 		}
 
 		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
@@ -351,18 +390,18 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	}
 }
 
-__global__ __launch_bounds__(BLOCK) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false>(M, C, F, P);
 }
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
-__global__ __launch_bounds__(BLOCK) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, true>(M, C, F, P);
 }
 
 // the same machinery fed by the probe ray fans instead of the camera (Testbed::computeEnvmap*, testbed.h:709-743)
-__global__ __launch_bounds__(BLOCK) void trace_probe_fused(const ModelParams M, const FrameParams F, const ProbeParams P) {
+__global__ __launch_bounds__(BLOCK, 2) void trace_probe_fused(const ModelParams M, const FrameParams F, const ProbeParams P) {
 	CameraParams C{};
 	fused_body<true>(M, C, F, P);
 }
@@ -452,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
 		half8 enc = encode_level_pair(M.grid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
-		MlpOut mo = mlp_pass(s_w, lane, enc, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]);
+		MlpOut mo = mlp_pass(s_w, lane, enc, sh4_from_dir(lane >> 4, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]));
 		if (s < n && lane < 16) {
 			union { half_t h; uint16_t u; } cv;
 			cv.h = mo.rgb[0]; out[(size_t)s * 4 + 0] = cv.u;
