@@ -159,18 +159,19 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 	for (;;) {
 		if (PROF) t0 = stamp();
-		// ---- retire: K7 for every ray that ended since the last round (kept out of the divergent march / composite code)
-		if (__any(finished)) {
-			if (finished) {
-				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
-				finished = false;
-			}
-		}
 		// ---- refill free slots from the tile queue: K1 and the start-of-ray jitter of K2. The skip to the first
 		// occupied voxel that K2 also does (advance_pos_nerf, :356) is the same loop as K4's and runs below with every
 		// other marching lane -- a ray with nothing in front of it must not stall the 63 other slots of its wave.
 		unsigned long long dead_mask = __ballot(!ray.alive);
 		int n_dead = __popcll(dead_mask);
+		// ---- retire: K7 for the rays that ended since the last refill, all at once (sRGB->linear is three powf and a
+		// frame-buffer read-modify-write; run per round it would execute with one or two live lanes)
+		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
+			if (finished) {
+				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
+				finished = false;
+			}
+		}
 		if (!exhausted && n_dead >= F.tune[0]) {
 			if (tile_next >= 64) {
 				uint32_t tq = 0;
@@ -245,7 +246,9 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					uint32_t empty = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip);
 					if (empty == 0u) {
 						float dt = calc_dt(ray.t, M.cone_angle);
-						f3 w = div3(sub3(pos, amin), adiag); // warp_position
+						f3 w = sub3(pos, amin); // warp_position: (pos - min) / diag
+						if (M.diag_pow2) w = mul3(w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
+						else w = div3(w, adiag);
 						wx = w.x; wy = w.y; wz = w.z;
 						wdt = warp_dt(dt);
 						ray.t = ray.t + dt;

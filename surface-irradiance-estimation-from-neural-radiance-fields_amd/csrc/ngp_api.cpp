@@ -279,6 +279,13 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	{
 		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 		M.r2l_identity = memcmp(M.r2l, ident, sizeof(ident)) == 0 ? 1u : 0u;
+		M.diag_pow2 = 1u;
+		for (int i = 0; i < 3; ++i) {
+			int e;
+			float m = frexpf(M.aabb_diag[i], &e);
+			if (!(m == 0.5f) || e < -100 || e > 100) M.diag_pow2 = 0u; // power of two, comfortably inside the normal range
+			M.aabb_inv_diag[i] = 1.0f / M.aabb_diag[i];
+		}
 	}
 	M.max_cascade = max_cascade;
 	M.cone_angle = d.cone_angle_constant;

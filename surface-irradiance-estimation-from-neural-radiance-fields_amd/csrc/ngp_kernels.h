@@ -56,6 +56,8 @@ struct ModelParams {
 	float cone_angle;
 	uint32_t rgb_act, density_act;
 	uint32_t r2l_identity; // render_aabb_to_local is the identity (the usual case): skip the matrix product
+	uint32_t diag_pow2;    // every component of aabb_diag is a power of two: x / diag == x * (1/diag) bit for bit
+	float aabb_inv_diag[3];
 };
 constexpr uint32_t COARSE_WORDS_PER_MIP = 32 * 32 * 32 / 32;
 
