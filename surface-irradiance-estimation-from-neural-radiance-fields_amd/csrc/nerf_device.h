@@ -162,7 +162,15 @@ NGP_DEV bool density_grid_occupied_at_lds(f3 pos, const uint8_t* __restrict__ bi
 // largest aligned empty block around pos that the LDS summaries can vouch for: 1 cell (-> 1), 4x4x4 (-> 4) or
 // 16x16x16 (-> 16). Out-of-range positions count as a single empty cell, like density_grid_occupied_at.
 // s_coarse: [mip][1024] words (4^3 blocks = morton >> 6), s_coarse16: [mip][16] words (16^3 blocks = morton >> 12).
-NGP_DEV uint32_t empty_block_size_at(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip) {
+// The 64 occupancy bits of a 4x4x4 block are one aligned 8-byte word of the Morton-ordered bitfield; a marching lane
+// keeps the last block it read (a ray spends ~18 consecutive samples in one block), so most lookups touch no memory.
+struct OccBlockCache {
+	uint32_t key; // (mip << 26) | block, 0xffffffff = empty
+	uint2 bits;
+};
+
+NGP_DEV uint32_t empty_block_size_at(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip,
+                                     OccBlockCache& cache) {
 	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
 	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
 	int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
@@ -174,7 +182,13 @@ NGP_DEV uint32_t empty_block_size_at(f3 pos, const uint8_t* __restrict__ bitfiel
 	if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
 	uint32_t b4 = idx >> 6;
 	if (!((s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] >> (b4 & 31u)) & 1u)) return 4u;
-	return (bitfield[idx / 8 + (NERF_GRID_N_CELLS / 8) * mip] & (1u << (idx % 8))) != 0 ? 0u : 1u;
+	const uint32_t key = (mip << 26) | b4;
+	if (cache.key != key) {
+		cache.bits = *(const uint2*)(bitfield + (size_t)b4 * 8 + (size_t)(NERF_GRID_N_CELLS / 8) * mip);
+		cache.key = key;
+	}
+	const uint32_t word = (idx & 32u) ? cache.bits.y : cache.bits.x; // bit (idx % 8) of byte idx / 8 == bit (idx & 63) of the block word
+	return ((word >> (idx & 31u)) & 1u) ? 0u : 1u;
 }
 
 // res is a power of two, so t / res == t * (1/res) bit for bit; inv_res spares the IEEE division sequence

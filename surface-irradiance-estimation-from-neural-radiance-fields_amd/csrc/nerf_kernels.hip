@@ -115,8 +115,13 @@ NGP_DEV unsigned long long stamp() {
 	return t;
 }
 
-template <bool PROBE, bool PROF = false>
+// UNIT: unit-cube scenes (aabb_scale 1 => one cascade, cone angle 0 => fixed step sqrt(3)/1024; load_nerf_post,
+// src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
+// exponential-stepping branches; the arithmetic that remains is the same expression for expression.
+template <bool PROBE, bool PROF = false, bool UNIT = false>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
+	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
+	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
 	__shared__ uint4 s_w[N_FRAGS * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
 	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP]; // 32 KB: empty-space summary of the occupancy grid
@@ -124,7 +129,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < (M.max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
+	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
 	if (threadIdx.x < NERF_CASCADES * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
 	__syncthreads();
 
@@ -147,6 +152,9 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	uint32_t step = 1;
 	uint32_t skip_i = 1;
 	bool ready = false, counted = false;
+	OccBlockCache occ_cache;
+	occ_cache.key = 0xffffffffu;
+	occ_cache.bits = make_uint2(0u, 0u);
 	bool finished = false; // the ray has ended and waits to be shaded (once per round, with every other finished ray)
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 
@@ -201,7 +209,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 						// src/testbed_nerf.cu:1490-1493
 						if (F.depth_buffer[ray.idx] < 0.01f) F.depth_buffer[ray.idx] = MAX_DEPTH;
 						if (ray.alive) {
-							ray.t = advance_n_steps(ray.t, M.cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
+							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
 							fresh = true;
 						}
 					}
@@ -242,10 +250,10 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					finished = true;
 				} else {
 					uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
-					mip = mip > M.max_cascade ? M.max_cascade : mip;
-					uint32_t empty = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip);
+					mip = mip > max_cascade ? max_cascade : mip;
+					uint32_t empty = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip, occ_cache);
 					if (empty == 0u) {
-						float dt = calc_dt(ray.t, M.cone_angle);
+						float dt = calc_dt(ray.t, cone_angle);
 						f3 w = sub3(pos, amin); // warp_position: (pos - min) / diag
 						if (M.diag_pow2) w = mul3(w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
 						else w = div3(w, adiag);
@@ -258,13 +266,13 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					} else {
 						// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
 						// the cell, so the block summary of the final level is looked up again
-						while (mip < M.max_cascade) {
-							uint32_t e = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1);
+						while (mip < max_cascade) {
+							uint32_t e = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache);
 							if (e == 0u) break;
 							++mip;
 							empty = e;
 						}
-						ray.t = advance_to_next_voxel(ray.t, M.cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
+						ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
 						++skip_i;
 					}
 				}
@@ -396,6 +404,10 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false>(M, C, F, P);
+}
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, true>(M, C, F, P);
 }
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
@@ -631,7 +643,9 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 // ---------------------------------------------------------------------------------------------------------
 // launchers (called from ngp_api.cpp)
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream) {
+	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
 	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 }
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream) {
