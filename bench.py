@@ -82,38 +82,47 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the renderer has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # == local_rank on a real run; lets a 1-GPU box rehearse N > 1 (gloo)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NGP_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg("build").build()
     native, synthetic, scene_mod, parallel = pkg("native"), pkg("synthetic"), pkg("scene"), pkg("parallel")
     sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)  # identical on every rank (seeded)
-    ctx = native.Context(local_rank)
+    ctx = native.Context(dev_index)
     ctx.set_model(sc)  # replica per GPU; a broadcast is not needed because every rank generates the same bytes
 
     w, h = args.width, args.height
     focal = scene_mod.focal_from_fov_x(w, FOV_X)
     cams = [native.make_camera(scene_mod.orbit_camera(az), w, h, focal) for az in AZIMUTHS]
-    opts = native.make_opts(shard_index=rank, shard_count=world)
-    rgbad = torch.zeros((h, w, 5), dtype=torch.float32, device=dev)  # not used for rendering; see below
-    rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
-    depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
     stream = torch.cuda.Stream(dev)  # the stream every kernel, copy and collective of a step is enqueued on
     torch.cuda.set_stream(stream)
+    if world > 1:
+        # tile-packed output: the fused kernel writes this rank's tiles in the layout the all_gather moves
+        opts = native.make_opts(shard_index=rank, shard_count=world, packed_output=True)
+        gatherer = parallel.PackedFrameGather(w, h, world, dev)
+        rgba, depth = gatherer.buffers()
+    else:
+        opts = native.make_opts()
+        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
 
     def step(i):
         ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), stream.cuda_stream)
         if world > 1:
-            rgbad[..., :4] = rgba
-            rgbad[..., 4] = depth
-            return parallel.gather_frame(rgbad, w, h, rank, world)
-        return rgba
+            return gatherer.gather(rgba, depth)  # every rank ends the step holding the full frame
+        return rgba, depth
 
     def fence():
         if world > 1:

@@ -86,6 +86,11 @@ typedef struct ngp_render_opts {
 	/* camera-tile sharding across GPUs: this context renders 8x8-pixel tiles t with t % shard_count == shard_index */
 	uint32_t shard_index, shard_count;
 	int32_t testbed_mode;     /* ngp_testbed_mode: Geometry = render_geometry_mesh then render_geometry_nerf (src/testbed.cu:4833-4889) */
+	/* 0: rgba/depth are W*H images (pixel x + W*y). 1: tile-packed -- only this shard's tiles, local tile q (global tile
+	 * shard_index + q*shard_count, tiles numbered row-major over ceil(W/8) x ceil(H/8)) occupies pixels [64q, 64q+64),
+	 * slot (x&7) + 8*(y&7); buffers hold 64 * ngp_packed_tiles(...) pixels. This is the layout the per-frame RCCL
+	 * all_gather moves, so no pack pass is needed on the sending side. */
+	int32_t packed_output;
 } ngp_render_opts;
 
 /* BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir (testbed.h:875-876) used by shade_kernel_mesh_geometry */
@@ -141,6 +146,8 @@ NGP_API int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opt
  * `stream` (a hipStream_t, NULL = default stream) without synchronising: for callers that keep the image on the GPU
  * (RCCL gather of tiles, benchmarks). */
 NGP_API int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, void* d_rgba, void* d_depth, void* stream);
+/* number of local tiles (hence 64x that many pixels) of a tile-packed frame */
+NGP_API uint32_t ngp_packed_tiles(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count);
 /* counters + timings of the last ngp_render / ngp_render_device (synchronises the stream) */
 NGP_API int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out);
 /* the same for the last n calls (oldest first; the context keeps 256), read once after a batch of asynchronous

@@ -170,14 +170,15 @@ NGP_DEV f3 evaluate_shading(f3 base_color, f3 ambient_color, f3 light_color, flo
 
 // render_geometry_mesh (src/testbed_geometry_training.cu:2202-2320), Shade mode, floor disabled, one thread per pixel
 __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams P, const IrradianceMap I, const CameraParams C, float4* __restrict__ frame_buffer,
-                                  float* __restrict__ depth_buffer, uint32_t shard_index, uint32_t shard_count) {
+                                  float* __restrict__ depth_buffer, uint32_t shard_index, uint32_t shard_count, int packed) {
 	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x;
 	uint32_t y = threadIdx.y + blockDim.y * blockIdx.y;
 	if (x >= (uint32_t)C.width || y >= (uint32_t)C.height) return;
 	// camera-tile sharding: same 8x8 tile -> rank mapping as the NeRF pass
 	uint32_t tile = (y >> 3) * (((uint32_t)C.width + 7u) >> 3) + (x >> 3);
 	if (tile % shard_count != shard_index) return;
-	const uint32_t idx = x + (uint32_t)C.width * y;
+	// tile-packed layout: local tile q = tile / shard_count, slot = (x & 7) + 8 * (y & 7)
+	const uint32_t idx = packed ? (tile / shard_count) * 64u + (x & 7u) + 8u * (y & 7u) : x + (uint32_t)C.width * y;
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
 	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
 	// M1: init_rays_with_payload_kernel_mesh_geometry (:488-579)
@@ -247,10 +248,10 @@ __global__ void trace_mesh_rays_kernel(const MeshSceneParams S, uint32_t n, floa
 }
 
 void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
-                        uint32_t shard_index, uint32_t shard_count, hipStream_t stream) {
+                        uint32_t shard_index, uint32_t shard_count, int packed, hipStream_t stream) {
 	dim3 threads(16, 8, 1);
 	dim3 blocks((C.width + 15) / 16, (C.height + 7) / 8, 1);
-	hipLaunchKernelGGL(render_mesh_fused, blocks, threads, 0, stream, S, P, I, C, frame_buffer, depth_buffer, shard_index, shard_count);
+	hipLaunchKernelGGL(render_mesh_fused, blocks, threads, 0, stream, S, P, I, C, frame_buffer, depth_buffer, shard_index, shard_count, packed);
 }
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream) {
 	hipLaunchKernelGGL(trace_mesh_rays_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, S, n, positions, directions);

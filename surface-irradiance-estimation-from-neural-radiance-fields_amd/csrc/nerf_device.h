@@ -271,12 +271,14 @@ NGP_DEV float aabb_ray_entry(const float* bmin, const float* bmax, f3 pos, f3 di
 struct RayState {
 	f3 o, d;
 	float t;
-	uint32_t idx;
+	uint32_t idx; // pixel index x + W*y (seeds the start-of-ray jitter); probe rays: ray id
+	uint32_t out; // where the ray's pixel lives in frame_buffer / depth_buffer (== idx unless the layout is tile-packed)
 	bool alive;
 };
 
 NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
 	r.idx = x + (uint32_t)C.width * y;
+	r.out = r.idx;
 	float u = ((float)x + C.pixel_offset[0]) / (float)C.width;
 	float v = ((float)y + C.pixel_offset[1]) / (float)C.height;
 	f3 dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);

@@ -102,6 +102,7 @@ NGP_DEV void init_probe_ray(const ProbeParams& P, uint32_t q, RayState& r) {
 	r.d = dir;
 	r.t = 0.0f;
 	r.idx = q;
+	r.out = q;
 	r.alive = true;
 }
 
@@ -147,6 +148,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	ray.o = ray.d = mk3(0.f, 0.f, 0.f);
 	ray.t = 0.f;
 	ray.idx = 0;
+	ray.out = 0;
 	f3 idir = mk3(0.f, 0.f, 0.f);
 	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint32_t step = 1;
@@ -159,7 +161,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 
 	// wave-uniform tile reservoir
-	uint32_t tile = 0, tile_next = 64;
+	uint32_t tile = 0, tile_next = 64, tile_local = 0;
 	bool exhausted = false;
 	int stall = 0;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
@@ -176,7 +178,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// frame-buffer read-modify-write; run per round it would execute with one or two live lanes)
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
 			if (finished) {
-				n_hit += shade_ray<PROBE>(F, P, ray.idx, acc) ? 1u : 0u;
+				n_hit += shade_ray<PROBE>(F, P, ray.out, acc) ? 1u : 0u;
 				finished = false;
 			}
 		}
@@ -189,6 +191,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					exhausted = true;
 				} else {
 					tile = F.shard_index + F.shard_count * tq;
+					tile_local = tq;
 					tile_next = 0;
 				}
 			}
@@ -206,8 +209,9 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
 					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
 						init_ray(M, C, x, y, ray);
+						if (F.packed) ray.out = tile_local * 64u + slot;
 						// src/testbed_nerf.cu:1490-1493
-						if (F.depth_buffer[ray.idx] < 0.01f) F.depth_buffer[ray.idx] = MAX_DEPTH;
+						if (F.depth_buffer[ray.out] < 0.01f) F.depth_buffer[ray.out] = MAX_DEPTH;
 						if (ray.alive) {
 							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
 							fresh = true;

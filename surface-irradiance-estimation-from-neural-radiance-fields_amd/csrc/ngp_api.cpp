@@ -743,8 +743,11 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (opts.render_mode != NGP_RENDER_SHADE && opts.render_mode != NGP_RENDER_SHADE_ENVMAP) throw std::runtime_error("only render modes Shade and ShadeEnvMap are implemented");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
-	const size_t n_pixels = (size_t)cam.width * cam.height;
-	ensure_frame_buffers(ctx, n_pixels);
+	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
+	const uint32_t local_tiles = tiles_total > opts.shard_index ? (tiles_total - opts.shard_index + shard_count - 1) / shard_count : 0;
+	// frame-buffer extent: the whole image, or only this shard's tiles in tile-packed order
+	const size_t n_pixels = opts.packed_output ? (size_t)local_tiles * 64 : (size_t)cam.width * cam.height;
+	ensure_frame_buffers(ctx, n_pixels ? n_pixels : 1);
 	const int spp = opts.spp > 0 ? opts.spp : 1;
 
 	FrameParams F{};
@@ -761,6 +764,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.n_local_tiles = n_tiles > opts.shard_index ? (n_tiles - opts.shard_index + shard_count - 1) / shard_count : 0;
 	F.min_transmittance = opts.min_transmittance;
 	F.linear_colors = ctx->desc.linear_colors;
+	F.packed = opts.packed_output ? 1 : 0;
 	F.prof = nullptr;
 	memcpy(F.tune, ctx->tune, sizeof(F.tune));
 	if (const char* t = getenv("NGP_TUNE")) sscanf(t, "%d,%d,%d,%d", &F.tune[0], &F.tune[1], &F.tune[2], &F.tune[3]); // experiments only
@@ -797,7 +801,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 				I.n_theta = ctx->env_n_theta;
 				I.n_phi = ctx->env_n_phi;
 			}
-			launch_render_mesh(ctx->mesh_scene, ctx->shade, I, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, stream);
+			launch_render_mesh(ctx->mesh_scene, ctx->shade, I, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, F.packed, stream);
 		}
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
 		// persistent grid: 4 workgroups of 4 waves per CU; surplus waves find the queue empty and exit
@@ -1067,9 +1071,16 @@ int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts
 	});
 }
 
+uint32_t ngp_packed_tiles(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count) {
+	if (width <= 0 || height <= 0 || shard_count == 0 || shard_index >= shard_count) return 0;
+	const uint32_t tiles_total = (uint32_t)((width + 7) / 8) * (uint32_t)((height + 7) / 8);
+	return tiles_total > shard_index ? (tiles_total - shard_index + shard_count - 1) / shard_count : 0;
+}
+
 int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out) {
 	return guarded(ctx, [&] {
 		if (!cam || !opts || !rgba_out) throw std::runtime_error("null argument");
+		if (opts->packed_output) throw std::runtime_error("packed_output is for ngp_render_device (GPU-resident tiles); ngp_render returns images");
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 		const size_t n_pixels = (size_t)cam->width * cam->height;
 		ensure_frame_buffers(ctx, n_pixels);

@@ -35,7 +35,7 @@ void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, fl
                                float exposure, int to_srgb, float4* rgba_out, hipStream_t stream);
 
 void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
-                        uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
+                        uint32_t shard_index, uint32_t shard_count, int packed, hipStream_t stream);
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream);
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream);
 void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream);

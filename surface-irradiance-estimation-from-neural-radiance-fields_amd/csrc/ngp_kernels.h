@@ -82,6 +82,7 @@ struct FrameParams {
 	float min_transmittance;
 	int32_t linear_colors;
 	int32_t depth_test;
+	int32_t packed;           // 1: pixel (local tile q, slot s) is written at q*64+s (tile-packed layout for the RCCL gather) instead of x+W*y
 	int32_t tune[4];          // refill_min, skip_steps, go_min, max_stall (nerf_kernels.hip)
 	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums
 };

@@ -177,6 +177,7 @@ public:
 		o.shard_index = 0;
 		o.shard_count = 1;
 		o.testbed_mode = m_testbed_mode == ETestbedMode::Geometry ? NGP_MODE_GEOMETRY : NGP_MODE_NERF;
+		o.packed_output = 0;
 		ngp_geometry_opts g{};
 		memcpy(g.sun_dir, m_sun_dir.data(), 12);
 		memcpy(g.up_dir, m_up_dir.data(), 12);

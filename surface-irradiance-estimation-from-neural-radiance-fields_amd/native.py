@@ -51,7 +51,7 @@ class Camera(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [
         ("render_mode", C.c_int32), ("min_transmittance", C.c_float), ("background", C.c_float * 4), ("exposure", C.c_float),
-        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32),
+        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32), ("packed_output", C.c_int32),
     ]
 
 
@@ -114,6 +114,8 @@ def load_library():
     L.ngp_get_dataset_info.argtypes = [vp, vp, vp, vp, vp]
     L.ngp_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp]
     L.ngp_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp, vp]
+    L.ngp_packed_tiles.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
+    L.ngp_packed_tiles.restype = C.c_uint32
     L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
     L.ngp_get_render_history.argtypes = [vp, ip, C.POINTER(RenderStats)]
     L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
@@ -157,7 +159,7 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
 
 
 def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1,
-              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE):
+              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE, packed_output=False):
     o = RenderOpts()
     o.render_mode = render_mode
     o.min_transmittance = min_transmittance
@@ -168,6 +170,7 @@ def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=
     o.spp = spp
     o.shard_index, o.shard_count = shard_index, shard_count
     o.testbed_mode = testbed_mode
+    o.packed_output = int(packed_output)
     return o
 
 

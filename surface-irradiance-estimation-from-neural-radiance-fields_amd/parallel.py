@@ -66,3 +66,48 @@ def gather_frame(local_img, width, height, rank, world_size, group=None):
     out = packed.new_empty((world_size * n_slots,) + tuple(packed.shape[1:]))  # concatenated along dim 0
     dist.all_gather_into_tensor(out, packed, group=group)
     return unpack_tiles(out.view((world_size, n_slots) + tuple(packed.shape[1:])), width, height, world_size)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tile-packed path (what bench.py uses for N > 1): the renderer writes this rank's tiles straight into the layout the
+# collective moves (ngp_render_opts.packed_output), so a frame costs: fused kernel -> tonemap -> all_gather(rgba),
+# all_gather(depth) -> one index_select each to scatter tiles into the image. The index tables are built once.
+class PackedFrameGather:
+    def __init__(self, width, height, world_size, device):
+        self.w, self.h, self.world = width, height, world_size
+        tx, ty = tile_grid(width, height)
+        n_tiles = tx * ty
+        self.n_slots = (n_tiles + world_size - 1) // world_size
+        # source row (rank, slot, within) of every image pixel
+        ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+        tile = (ys // TILE) * tx + (xs // TILE)
+        rank, slot = tile % world_size, tile // world_size
+        within = (xs % TILE) + TILE * (ys % TILE)
+        self.src = ((rank * self.n_slots + slot) * 64 + within).reshape(-1).to(device)
+        self.device = device
+
+    def buffers(self):
+        """(rgba, depth) send buffers for one rank: n_slots*64 pixels each (the tail of a rank with fewer tiles stays 0)."""
+        n = self.n_slots * 64
+        return (torch.zeros((n, 4), dtype=torch.float32, device=self.device), torch.zeros((n,), dtype=torch.float32, device=self.device))
+
+    def gather(self, rgba_packed, depth_packed, group=None):
+        import torch.distributed as dist
+
+        n = self.n_slots * 64
+        g_rgba = rgba_packed.new_empty((self.world * n, 4))
+        g_depth = depth_packed.new_empty((self.world * n,))
+        if self.world > 1:
+            h1 = dist.all_gather_into_tensor(g_rgba, rgba_packed, group=group, async_op=True)
+            h2 = dist.all_gather_into_tensor(g_depth, depth_packed, group=group, async_op=True)
+            h1.wait()
+            h2.wait()
+        else:
+            g_rgba.copy_(rgba_packed)
+            g_depth.copy_(depth_packed)
+        return self.unpack(g_rgba, g_depth)
+
+    def unpack(self, g_rgba, g_depth):
+        img = g_rgba.index_select(0, self.src).view(self.h, self.w, 4)
+        depth = g_depth.index_select(0, self.src).view(self.h, self.w)
+        return img, depth

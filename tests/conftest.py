@@ -61,6 +61,11 @@ def scene_big(oracle):
 
 @pytest.fixture(scope="session")
 def gpu_ctx(native):
+    # torch bundles its own HIP runtime; when a test uses both (tile gather), torch has to initialise first
+    import torch
+
+    if torch.cuda.is_available():
+        torch.zeros(1, device="cuda")
     ctx = native.Context(0)
     yield ctx
     ctx.close()

@@ -212,6 +212,33 @@ def test_tile_sharding_covers_frame(gpu_ctx, native, scene_mod, scene_unit):
     assert hits == gpu_ctx.render_stats()["n_rays_hit"]
 
 
+def test_tile_packed_output_matches_image_layout(gpu_ctx, native, scene_mod, scene_unit):
+    """packed_output (the layout the RCCL all_gather moves) holds exactly the pixels of the plain image."""
+    import ctypes as C
+
+    import torch
+    from conftest import pkg
+
+    par = pkg("parallel")
+    w, h, world = 120, 67, 3  # not a multiple of the tile in y
+    gpu_ctx.set_model(scene_unit)
+    cam = native.make_camera(scene_mod.orbit_camera(45.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+    full, full_depth = gpu_ctx.render(cam, native.make_opts(), want_depth=True)
+    dev = torch.device("cuda", 0)
+    g = par.PackedFrameGather(w, h, world, dev)
+    parts_rgba, parts_depth = [], []
+    for r in range(world):
+        rgba, depth = g.buffers()
+        assert native.load_library().ngp_packed_tiles(w, h, r, world) <= g.n_slots
+        gpu_ctx.render_device(cam, native.make_opts(shard_index=r, shard_count=world, packed_output=True), rgba.data_ptr(), depth.data_ptr(), None)
+        gpu_ctx.render_stats()  # synchronises the context's stream
+        parts_rgba.append(rgba)
+        parts_depth.append(depth)
+    img, dep = g.unpack(torch.cat(parts_rgba), torch.cat(parts_depth))
+    assert np.array_equal(img.cpu().numpy(), full)
+    assert np.array_equal(dep.cpu().numpy(), full_depth)
+
+
 def test_render_is_deterministic(gpu_ctx, native, scene_mod, scene_unit):
     gpu_ctx.set_model(scene_unit)
     cam = native.make_camera(scene_mod.orbit_camera(45.0), 128, 72, scene_mod.focal_from_fov_x(128, 0.6911))
