@@ -36,7 +36,7 @@ def pkg(sub):
 
 def cpu_baseline(scene_dict, scene_mod):
     """The oracle (kind "port": the reference has no CPU path, scripts/run.py:25 hard-imports the CUDA module) on a
-    bounded sample of the same workload: the same camera and model at 480x270 (1/16 of the pixels)."""
+    bounded sample of the same workload: the same camera and model at 960x540 (1/4 of the pixels)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -51,7 +51,7 @@ def cpu_baseline(scene_dict, scene_mod):
     grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
     sc["density_grid_bitfield"], _ = o.density_grid_to_bitfield(grid, sc["max_cascade"])
     m = o.make_model(sc)
-    w, h = WIDTH // 4, HEIGHT // 4
+    w, h = WIDTH // 2, HEIGHT // 2
     cam = o.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("NGP_BENCH_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
@@ -60,7 +60,23 @@ def cpu_baseline(scene_dict, scene_mod):
     dt = time.perf_counter() - t0
     o.release(m)
     return {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same model+camera at {w}x{h} (1/16 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+            "sample": f"same model+camera at {w}x{h} (1/4 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the fused kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read from inside the process, hence the file."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return int(json.load(f)["traffic_bytes_per_launch_corrected"])
+    except Exception:
+        return None
 
 
 def main():
@@ -192,7 +208,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic(),
                 "kernel": "render_nerf_fused",
                 "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
