@@ -243,3 +243,18 @@ def test_tile_pack_unpack_roundtrip():
         packed = torch.stack([par.pack_tiles(img, w, h, r, world, n) for r in range(world)])
         assert torch.equal(par.unpack_tiles(packed, w, h, world), img)
         assert sum(par.local_tiles(w, h, r, world).numel() for r in range(world)) == par.tile_grid(w, h)[0] * par.tile_grid(w, h)[1]
+
+
+def test_constant_division_is_exact(tmp_path):
+    """csrc/nerf_device.h:div_const replaces `/` by a reciprocal multiply and one FMA correction for the three
+    constant divisors of the march (STEPSIZE, MAX_CONE_STEPSIZE, the dt warp): it must be the IEEE quotient for
+    every float the march can produce, checked exhaustively on [1e-9, 65536) and its negatives."""
+    import subprocess
+
+    with open("/proc/cpuinfo") as f:
+        has_fma = " fma " in f.read()
+    exe = tmp_path / "div_const_check"
+    flags = ["-O2", "-fopenmp", "-ffp-contract=off"] + (["-mfma"] if has_fma else [])
+    subprocess.check_call(["gcc", *flags, "-o", str(exe), os.path.join(ROOT, "tests", "aux", "div_const_check.c"), "-lm"])
+    out = subprocess.run([str(exe), "1" if has_fma else "251"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
