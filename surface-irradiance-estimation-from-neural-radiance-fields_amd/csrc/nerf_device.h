@@ -316,22 +316,45 @@ struct CornerSet {
 	float weight[8];
 };
 
-NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, CornerSet& cs) {
+struct CellPos {
+	uint32_t gx, gy, gz;
+	float wx, wy, wz;
+};
+NGP_DEV CellPos level_cell(const LevelInfo& L, float x, float y, float z) {
 	float fx = __builtin_fmaf(L.scale, x, 0.5f), fy = __builtin_fmaf(L.scale, y, 0.5f), fz = __builtin_fmaf(L.scale, z, 0.5f);
 	float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy), flz = __builtin_floorf(fz);
-	uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
-	float wx = fx - flx, wy = fy - fly, wz = fz - flz;
-	float wx0 = 1.0f - wx, wy0 = 1.0f - wy, wz0 = 1.0f - wz;
+	CellPos c;
+	c.gx = (uint32_t)(int)flx; c.gy = (uint32_t)(int)fly; c.gz = (uint32_t)(int)flz;
+	c.wx = fx - flx; c.wy = fy - fly; c.wz = fz - flz;
+	return c;
+}
+NGP_DEV void corner_weights(const CellPos& p, float* weight) {
+	float wx0 = 1.0f - p.wx, wy0 = 1.0f - p.wy, wz0 = 1.0f - p.wz;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+		weight[c] = ((bx ? p.wx : wx0) * (by ? p.wy : wy0)) * (bz ? p.wz : wz0);
+	}
+}
+NGP_DEV bool level_in_xor_range(const LevelInfo& L, const CellPos& p) {
+	uint32_t m = p.gx > p.gy ? p.gx : p.gy;
+	m = m > p.gz ? m : p.gz;
+	return m <= L.coord_max;
+}
+
+// tcnn grid_index, byte offsets into ModelParams::grid -- any position, any level shape
+NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, CornerSet& cs) {
+	CellPos p = level_cell(L, x, y, z);
 	uint32_t ix[2], iy[2], iz[2];
 	if (L.hashed) {
-		ix[0] = gx;               ix[1] = gx + 1u;
-		iy[0] = gy * 2654435761u; iy[1] = (gy + 1u) * 2654435761u;
-		iz[0] = gz * 805459861u;  iz[1] = (gz + 1u) * 805459861u;
+		ix[0] = p.gx;               ix[1] = p.gx + 1u;
+		iy[0] = p.gy * 2654435761u; iy[1] = (p.gy + 1u) * 2654435761u;
+		iz[0] = p.gz * 805459861u;  iz[1] = (p.gz + 1u) * 805459861u;
 	} else {
 		uint32_t r2 = L.res * L.res;
-		ix[0] = gx;         ix[1] = gx + 1u;
-		iy[0] = gy * L.res; iy[1] = (gy + 1u) * L.res;
-		iz[0] = gz * r2;    iz[1] = (gz + 1u) * r2;
+		ix[0] = p.gx;         ix[1] = p.gx + 1u;
+		iy[0] = p.gy * L.res; iy[1] = (p.gy + 1u) * L.res;
+		iz[0] = p.gz * r2;    iz[1] = (p.gz + 1u) * r2;
 	}
 #pragma unroll
 	for (int c = 0; c < 8; ++c) {
@@ -339,8 +362,41 @@ NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, Corner
 		uint32_t idx = L.hashed ? (ix[bx] ^ iy[by] ^ iz[bz]) : (ix[bx] + iy[by] + iz[bz]);
 		idx = L.mask ? (idx & L.mask) : (idx % L.size);
 		cs.index[c] = (L.offset + idx) * 8u; // byte offset of the 4 x fp16 entry
-		cs.weight[c] = ((bx ? wx : wx0) * (by ? wy : wy0)) * (bz ? wz : wz0);
 	}
+	corner_weights(p, cs.weight);
+}
+
+// The same 8 entries through the xor layout (byte offsets into ModelParams::xgrid): 2 multiplies, 3 adds and per
+// corner one v_xor3 + one v_and_or, for dense and hashed levels alike. Only valid when level_in_xor_range().
+NGP_DEV void level_corners_xor(const LevelInfo& L, const CellPos& p, CornerSet& cs) {
+	uint32_t ix[2], iy[2], iz[2];
+	ix[0] = p.gx << 3;        ix[1] = ix[0] + 8u;
+	iy[0] = p.gy * L.mul_y8;  iy[1] = iy[0] + L.mul_y8;
+	iz[0] = p.gz * L.mul_z8;  iz[1] = iz[0] + L.mul_z8;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+		cs.index[c] = ((ix[bx] ^ iy[by] ^ iz[bz]) & L.mask8) | L.base8;
+	}
+	corner_weights(p, cs.weight);
+}
+
+// Corner offsets + weights of the two levels a lane owns, and which table they index. Every render sample lies in
+// the xor layout's range; positions outside [0, 1] (possible through ngp_grid_encode / a render box larger than the
+// training box) take the tcnn-order table for the whole wave.
+NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y,
+                                       float z, CornerSet& c0, CornerSet& c1) {
+	const LevelInfo& L0 = lv[h];
+	const LevelInfo& L1 = lv[h + 4];
+	CellPos p0 = level_cell(L0, x, y, z), p1 = level_cell(L1, x, y, z);
+	if (__all((int)level_in_xor_range(L0, p0) & (int)level_in_xor_range(L1, p1))) {
+		level_corners_xor(L0, p0, c0);
+		level_corners_xor(L1, p1, c1);
+		return xgrid;
+	}
+	level_corners(L0, x, y, z, c0);
+	level_corners(L1, x, y, z, c1);
+	return (const char*)grid;
 }
 
 // result[f] += (half)(weight * (float)value[f]): hipcc turns each line into v_fma_mixlo_f16 (fp32 product rounded to
@@ -359,12 +415,11 @@ NGP_DEV void accumulate_corner(uint2 v, float w, half_t* r) {
 // lane (h, c) of a 16-sample pass encodes levels h and h+4: B-fragment element j<4 is feature j of level h,
 // element j>=4 is feature j-4 of level h+4 (the K permutation n(s,h,j) = 32s + 16(j>>2) + 4h + (j&3) that the
 // host applied to every weight matrix, see ngp_api.cpp build_weight_fragments).
-NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const LevelInfo* lv, int h, float x, float y, float z) {
+NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z) {
 	CornerSet c0, c1;
-	level_corners(lv[h], x, y, z, c0);
-	level_corners(lv[h + 4], x, y, z, c1);
+	// 32-bit byte offsets: both tables are below 4 GiB (checked by the host)
+	const char* base = level_pair_corners(grid, xgrid, lv, h, x, y, z, c0, c1);
 	uint2 v0[8], v1[8];
-	const char* base = (const char*)grid; // 32-bit byte offsets: the table is far below 4 GiB (checked by the host)
 #pragma unroll
 	for (int c = 0; c < 8; ++c) v0[c] = *(const uint2*)(base + c0.index[c]);
 #pragma unroll
@@ -387,11 +442,9 @@ struct EncodeInFlight {
 	uint2 v[16];
 	float w[16];
 };
-NGP_DEV void encode_issue(const uint2* __restrict__ grid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
+NGP_DEV void encode_issue(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
 	CornerSet c0, c1;
-	level_corners(lv[h], x, y, z, c0);
-	level_corners(lv[h + 4], x, y, z, c1);
-	const char* base = (const char*)grid;
+	const char* base = level_pair_corners(grid, xgrid, lv, h, x, y, z, c0, c1);
 #pragma unroll
 	for (int c = 0; c < 8; ++c) {
 		e.v[c] = *(const uint2*)(base + c0.index[c]);

@@ -337,8 +337,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			sample_of(p, ax, ay, az, sha);
 			sample_of(p + 1, bx, by, bz, shb);
 			EncodeInFlight ea, eb;
-			encode_issue(M.grid, s_lv, hq, ax, ay, az, ea);
-			encode_issue(M.grid, s_lv, hq, bx, by, bz, eb);
+			encode_issue(M.grid, M.xgrid, s_lv, hq, ax, ay, az, ea);
+			encode_issue(M.grid, M.xgrid, s_lv, hq, bx, by, bz, eb);
 			half8 enca = encode_finish(ea);
 			half8 encb = encode_finish(eb);
 			MlpOut moa = mlp_pass(s_w, lane, enca, sha);
@@ -350,7 +350,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			float ax, ay, az;
 			Sh4 sha;
 			sample_of(p, ax, ay, az, sha);
-			half8 enc = encode_level_pair(M.grid, s_lv, hq, ax, ay, az);
+			half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, hq, ax, ay, az);
 			MlpOut mo = mlp_pass(s_w, lane, enc, sha);
 			deliver(p, mo);
 		}
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void grid_encode_kernel(const ModelParams M,
 	for (int p = 0; p < 4; ++p) {
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
-		half8 enc = encode_level_pair(M.grid, s_lv, h, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, h, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
 		if (s < n) {
 			union { half_t h; uint16_t u; } cv;
 			for (int j = 0; j < 8; ++j) {
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 	for (int p = 0; p < 4; ++p) {
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
-		half8 enc = encode_level_pair(M.grid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
 		MlpOut mo = mlp_pass(s_w, lane, enc, sh4_from_dir(lane >> 4, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]));
 		if (s < n && lane < 16) {
 			union { half_t h; uint16_t u; } cv;

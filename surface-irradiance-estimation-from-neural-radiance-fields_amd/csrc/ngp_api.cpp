@@ -150,10 +150,73 @@ void build_levels(const ngp_model_desc& d, LevelInfo* lv, uint32_t* total_entrie
 		lv[l].offset = offset;
 		lv[l].hashed = n < stride ? 1u : 0u;
 		lv[l].mask = (n & (n - 1)) == 0 ? n - 1 : 0u;
-		lv[l].pad0 = lv[l].pad1 = 0;
+		lv[l].pad0 = 0;
 		offset += n;
 	}
 	*total_entries = offset;
+}
+
+// Xor layout of the hash-grid table for the render kernels. tcnn's grid_index has two shapes -- a dense
+// x + y*res + z*res^2 (wrapped modulo the level size when a corner coordinate reaches res) and a prime-multiplier
+// xor hash -- and the two halves of a wave work on levels of different shape. Dense levels are therefore re-laid
+// out at load time with power-of-two strides, entry (x, y, z) at x | y << b | z << 2b for x, y, z in [0, res],
+// 2^b > res, each holding the entry tcnn's formula (including its wrap) would have fetched; then
+//   dense:  8x ^ y * (8 << b) ^ z * (8 << 2b)        (disjoint bit fields: xor == add)
+//   hashed: 8x ^ y * (8 * 2654435761) ^ z * (8 * 805459861), masked with 8 * (size - 1)
+// is ONE formula with per-level multipliers, and aligning every level to its power-of-two footprint turns
+// "+ offset" into an OR. Same table entries, so the features are bit-identical; the cost is HBM nobody misses
+// (Lego-shaped model: 23 MB -> 38 MB).
+uint64_t pow2_ceil(uint64_t v) {
+	uint64_t p = 1;
+	while (p < v) p <<= 1;
+	return p;
+}
+void build_xor_layout(LevelInfo* lv, uint32_t n_levels, const uint16_t* grid /* tcnn order, 4 halves per entry */, std::vector<uint64_t>& table) {
+	uint64_t cursor = 0;
+	std::vector<uint32_t> bits(n_levels, 0);
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		LevelInfo& L = lv[l];
+		uint64_t bytes;
+		if (L.hashed) {
+			if ((L.size & (L.size - 1)) != 0) throw std::runtime_error("hashed grid level whose size is not a power of two");
+			bytes = (uint64_t)L.size * 8u;
+		} else {
+			uint32_t b = 0;
+			while ((1u << b) <= L.res) ++b; // 2^b > res: coordinates 0..res fit
+			bits[l] = b;
+			bytes = pow2_ceil(((uint64_t)(L.res + 1u) << (2 * b)) * 8u);
+		}
+		cursor = (cursor + bytes - 1) / bytes * bytes;
+		if (cursor + bytes > 0xFFFFFFFFull) throw std::runtime_error("hash grid too large for 32-bit gather offsets");
+		L.base8 = (uint32_t)cursor;
+		if (L.hashed) {
+			L.coord_max = 0xFFFFFFFFu;
+			L.mul_y8 = 2654435761u * 8u;
+			L.mul_z8 = 805459861u * 8u;
+			L.mask8 = (L.size - 1u) * 8u;
+		} else {
+			L.coord_max = L.res - 1u;
+			L.mul_y8 = 8u << bits[l];
+			L.mul_z8 = 8u << (2 * bits[l]);
+			L.mask8 = 0xFFFFFFFFu;
+		}
+		cursor += bytes;
+	}
+	table.assign(cursor / 8u, 0ull);
+	const uint64_t* src = (const uint64_t*)grid;
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		const LevelInfo& L = lv[l];
+		uint64_t* dst = table.data() + L.base8 / 8u;
+		const uint64_t* level = src + L.offset;
+		if (L.hashed) {
+			std::copy(level, level + L.size, dst);
+			continue;
+		}
+		const uint32_t b = bits[l];
+		for (uint32_t z = 0; z <= L.res; ++z)
+			for (uint32_t y = 0; y <= L.res; ++y)
+				for (uint32_t x = 0; x <= L.res; ++x) dst[x | (y << b) | (z << (2 * b))] = level[(x + y * L.res + z * L.res * L.res) % L.size];
+	}
 }
 
 uint64_t mlp_n_params(uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out) {
@@ -181,6 +244,8 @@ void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t
 
 void free_model(ngp_ctx* ctx) {
 	if (ctx->d_params) (void)hipFree(ctx->d_params);
+	if (ctx->d_xgrid) (void)hipFree(ctx->d_xgrid);
+	ctx->d_xgrid = nullptr;
 	if (ctx->d_wfrags) (void)hipFree(ctx->d_wfrags);
 	if (ctx->d_bitfield) (void)hipFree(ctx->d_bitfield);
 	if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
@@ -235,6 +300,12 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	// grid table
 	NGP_HIP_CHECK(hipMalloc(&ctx->d_params, ng * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_params, ctx->params.data() + nd + nr, ng * sizeof(uint16_t), hipMemcpyHostToDevice));
+	{
+		std::vector<uint64_t> table;
+		build_xor_layout(M.levels, d.n_levels, ctx->params.data() + nd + nr, table);
+		NGP_HIP_CHECK(hipMalloc(&ctx->d_xgrid, table.size() * sizeof(uint64_t)));
+		NGP_HIP_CHECK(hipMemcpy(ctx->d_xgrid, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	}
 	// weight fragments
 	std::vector<uint16_t> frags((size_t)N_FRAGS * 64 * 8);
 	const uint16_t* W = ctx->params.data();
@@ -266,6 +337,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	NGP_HIP_CHECK(hipGetLastError());
 
 	M.grid = (const uint2*)ctx->d_params;
+	M.xgrid = (const char*)ctx->d_xgrid;
 	M.coarse = ctx->d_coarse;
 	M.wfrags = ctx->d_wfrags;
 	M.bitfield = ctx->d_bitfield;

@@ -88,6 +88,7 @@ struct ngp_ctx {
 	std::vector<uint16_t> density_grid;
 	uint32_t max_cascade = 0;
 	void* d_params = nullptr;
+	void* d_xgrid = nullptr; // the grid table again, in the xor layout (ngp_api.cpp build_xor_layout)
 	uint4* d_wfrags = nullptr;
 	uint8_t* d_bitfield = nullptr;
 	uint32_t* d_coarse = nullptr;

@@ -28,8 +28,14 @@ struct LevelInfo {
 	uint32_t offset; // first entry
 	uint32_t hashed; // 1: spatial hash, 0: dense x + y*res + z*res^2
 	uint32_t mask;   // size-1 if size is a power of two, else 0
-	uint32_t pad0, pad1;
+	// xor layout (ModelParams::xgrid): byte offset of corner (x, y, z) = ((8x ^ y*mul_y8 ^ z*mul_z8) & mask8) | base8,
+	// valid while max(x, y, z) of the cell's low corner <= coord_max (always for hashed levels; see ngp_api.cpp
+	// build_xor_layout)
+	uint32_t coord_max;
+	uint32_t mul_y8, mul_z8, mask8, base8;
+	uint32_t pad0;
 };
+static_assert(sizeof(LevelInfo) == 48, "LevelInfo layout");
 
 struct NerfPayload { // nerf_device.cuh:144-152
 	float origin[3];
@@ -44,7 +50,8 @@ struct NerfPayload { // nerf_device.cuh:144-152
 static_assert(sizeof(NerfPayload) == 40, "NerfPayload layout");
 
 struct ModelParams {
-	const uint2* grid;       // fp16 x4 per entry
+	const uint2* grid;       // fp16 x4 per entry, tcnn order (level-major, entry-major)
+	const char* xgrid;       // the same entries in the xor layout: one index formula for dense and hashed levels
 	const uint4* wfrags;     // [N_FRAGS][64] x 8 fp16, MFMA A fragments in lane order
 	const uint8_t* bitfield; // 8 x 128^3 bits
 	const uint32_t* coarse;  // 8 x 32^3 bits: bit (morton >> 6) of mip m is set iff any cell of that 4x4x4 block is occupied
