@@ -399,17 +399,33 @@ NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const cha
 	return (const char*)grid;
 }
 
-// result[f] += (half)(weight * (float)value[f]): hipcc turns each line into v_fma_mixlo_f16 (fp32 product rounded to
-// fp16) + v_add_f16, the same two roundings per feature as tcnn's kernel_grid. (A half2 formulation compiles to
-// cvt/mul/cvt_pk/pk_add -- more instructions -- so the scalar form stays.)
-NGP_DEV void accumulate_corner(uint2 v, float w, half_t* r) {
+// result[f] += (half)(weight * (float)value[f]) with tcnn's roundings: the fp32 product is rounded to fp32, THEN
+// to fp16, then added in fp16. hipcc would fuse the first two steps into v_fma_mix*_f16, which rounds the exact
+// product once -- more accurate, but a different number in ~2e-5 of the cases (tools/micro/mix_probe.hip) -- so the
+// product is pinned as an fp32 value of its own. Features are accumulated as packed pairs (v_pk_add_f16).
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+struct FeatureAcc {
+	half2_t f01, f23;
+};
+NGP_DEV float pinned_product(float w, half_t v) {
+	float p = w * (float)v;
+	asm("" : "+v"(p));
+	return p;
+}
+NGP_DEV void accumulate_corner(uint2 v, float w, FeatureAcc& r) {
 	union { uint2 u; half_t h[4]; } cv;
 	cv.u = v;
-#pragma unroll
-	for (int f = 0; f < 4; ++f) {
-		float prod = w * (float)cv.h[f];
-		r[f] = r[f] + (half_t)prod;
-	}
+	half2_t a, b;
+	a[0] = (half_t)pinned_product(w, cv.h[0]);
+	a[1] = (half_t)pinned_product(w, cv.h[1]);
+	b[0] = (half_t)pinned_product(w, cv.h[2]);
+	b[1] = (half_t)pinned_product(w, cv.h[3]);
+	r.f01 = r.f01 + a;
+	r.f23 = r.f23 + b;
+}
+NGP_DEV void store_features(const FeatureAcc& lo, const FeatureAcc& hi, half8& out) {
+	out[0] = lo.f01[0]; out[1] = lo.f01[1]; out[2] = lo.f23[0]; out[3] = lo.f23[1];
+	out[4] = hi.f01[0]; out[5] = hi.f01[1]; out[6] = hi.f23[0]; out[7] = hi.f23[1];
 }
 
 // lane (h, c) of a 16-sample pass encodes levels h and h+4: B-fragment element j<4 is feature j of level h,
@@ -424,14 +440,13 @@ NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const char* __re
 	for (int c = 0; c < 8; ++c) v0[c] = *(const uint2*)(base + c0.index[c]);
 #pragma unroll
 	for (int c = 0; c < 8; ++c) v1[c] = *(const uint2*)(base + c1.index[c]);
-	half_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	FeatureAcc lo = {{0, 0}, {0, 0}}, hi = {{0, 0}, {0, 0}};
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(v0[c], c0.weight[c], r);
+	for (int c = 0; c < 8; ++c) accumulate_corner(v0[c], c0.weight[c], lo);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(v1[c], c1.weight[c], r + 4);
+	for (int c = 0; c < 8; ++c) accumulate_corner(v1[c], c1.weight[c], hi);
 	half8 out;
-#pragma unroll
-	for (int j = 0; j < 8; ++j) out[j] = r[j];
+	store_features(lo, hi, out);
 	return out;
 }
 
@@ -457,14 +472,13 @@ NGP_DEV void encode_issue(const uint2* __restrict__ grid, const char* __restrict
 	}
 }
 NGP_DEV half8 encode_finish(const EncodeInFlight& e) {
-	half_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	FeatureAcc lo = {{0, 0}, {0, 0}}, hi = {{0, 0}, {0, 0}};
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[c], e.w[c], r);
+	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[c], e.w[c], lo);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[8 + c], e.w[8 + c], r + 4);
+	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[8 + c], e.w[8 + c], hi);
 	half8 out;
-#pragma unroll
-	for (int j = 0; j < 8; ++j) out[j] = r[j];
+	store_features(lo, hi, out);
 	return out;
 }
 
@@ -528,25 +542,31 @@ struct MlpOut {
 };
 
 // All 16 SH coefficients of one direction as fp16 (what the owning lane stores once per ray).
+// fp32 -> fp16 of a value that is first rounded to fp32 (no fusing of the producing multiply into v_fma_mix*_f16,
+// which would round the exact product once; see accumulate_corner)
+NGP_DEV half_t to_half_rn(float v) {
+	asm("" : "+v"(v));
+	return (half_t)v;
+}
 NGP_DEV void sh4_all(float dx01, float dy01, float dz01, half_t* out16) {
 	float x = dx01 * 2.0f - 1.0f, y = dy01 * 2.0f - 1.0f, z = dz01 * 2.0f - 1.0f;
 	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
 	out16[0] = (half_t)0.28209479177387814f;
-	out16[1] = (half_t)(-0.48860251190291987f * y);
-	out16[2] = (half_t)(0.48860251190291987f * z);
-	out16[3] = (half_t)(-0.48860251190291987f * x);
-	out16[4] = (half_t)(1.0925484305920792f * xy);
-	out16[5] = (half_t)(-1.0925484305920792f * yz);
-	out16[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
-	out16[7] = (half_t)(-1.0925484305920792f * xz);
-	out16[8] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
-	out16[9] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
-	out16[10] = (half_t)(2.8906114426405538f * xy * z);
-	out16[11] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
-	out16[12] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
-	out16[13] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
-	out16[14] = (half_t)(1.4453057213202769f * z * (x2 - y2));
-	out16[15] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+	out16[1] = to_half_rn(-0.48860251190291987f * y);
+	out16[2] = to_half_rn(0.48860251190291987f * z);
+	out16[3] = to_half_rn(-0.48860251190291987f * x);
+	out16[4] = to_half_rn(1.0925484305920792f * xy);
+	out16[5] = to_half_rn(-1.0925484305920792f * yz);
+	out16[6] = to_half_rn(0.94617469575755997f * z2 - 0.31539156525251999f);
+	out16[7] = to_half_rn(-1.0925484305920792f * xz);
+	out16[8] = to_half_rn(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+	out16[9] = to_half_rn(0.59004358992664352f * y * (-3.0f * x2 + y2));
+	out16[10] = to_half_rn(2.8906114426405538f * xy * z);
+	out16[11] = to_half_rn(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+	out16[12] = to_half_rn(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+	out16[13] = to_half_rn(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+	out16[14] = to_half_rn(1.4453057213202769f * z * (x2 - y2));
+	out16[15] = to_half_rn(0.59004358992664352f * x * (-x2 + 3.0f * y2));
 }
 
 struct Sh4 { // SH coefficients 4h..4h+3 of the sample's direction, fp16
@@ -557,7 +577,7 @@ NGP_DEV Sh4 sh4_from_dir(int h, float dx01, float dy01, float dz01) {
 	sh4_quad(h, dx01, dy01, dz01, sh);
 	Sh4 r;
 #pragma unroll
-	for (int j = 0; j < 4; ++j) r.v[j] = (half_t)sh[j];
+	for (int j = 0; j < 4; ++j) r.v[j] = to_half_rn(sh[j]);
 	return r;
 }
 
