@@ -125,7 +125,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
 	__shared__ uint4 s_w[N_FRAGS * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
-	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP]; // 32 KB: empty-space summary of the occupancy grid
+	__shared__ uint32_t s_coarse[(UNIT ? 1 : NERF_CASCADES) * COARSE_WORDS_PER_MIP]; // 4 KB per cascade: empty-space summary of the occupancy grid
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
 	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused(const ModelParams 
 	ProbeParams P{};
 	fused_body<false>(M, C, F, P);
 }
-__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, false, true>(M, C, F, P);
 }
