@@ -154,6 +154,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	uint32_t step = 1;
 	uint32_t skip_i = 1;
 	bool ready = false, counted = false;
+	bool held = false; // ready, but left out of the last network phase
 	OccBlockCache occ_cache;
 	occ_cache.key = 0xffffffffu;
 	occ_cache.bits = make_uint2(0u, 0u);
@@ -230,6 +231,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					step = 1;
 					skip_i = 1;
 					ready = false;
+					held = false;
 					counted = PROBE; // probe rays count as alive from the start (there is no K2 for them)
 					if (PROBE) ++n_alive_init;
 				}
@@ -297,8 +299,18 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		}
 		stall = 0;
 
-		// ---- compact waiting samples onto MFMA sample slots: a bijection lane -> slot (ready lanes first)
-		uint32_t my_slot = ready ? lanes_below(ready_mask) : (uint32_t)n_ready + lanes_below(~ready_mask);
+		// ---- choose the samples of this phase: while marching lanes can still deliver more, only whole 16-sample
+		// passes run and the remainder waits (first in line next time), so no MFMA pass and no gather runs part-filled
+		int n_run = n_ready;
+		if (any_marching && n_ready > 16 && F.tune[3] < 16) n_run = n_ready & ~15;
+		const unsigned long long held_mask = __ballot(ready && held);
+		const uint32_t rank = (ready && held) ? lanes_below(held_mask) : (uint32_t)__popcll(held_mask) + lanes_below(ready_mask & ~held_mask);
+		const bool run = ready && rank < (uint32_t)n_run;
+		held = ready && !run;
+		const unsigned long long run_mask = __ballot(run);
+		n_ready = n_run;
+		// ---- compact them onto MFMA sample slots: a bijection lane -> slot (running lanes first)
+		uint32_t my_slot = run ? rank : (uint32_t)n_run + lanes_below(~run_mask);
 		int slot_owner = __builtin_amdgcn_ds_permute((int)(my_slot * 4u), lane); // lane k learns who owns slot k
 
 		// ---- K5: network, 16 samples per pass; two passes are run together whenever 17+ samples wait, so that 32
@@ -357,7 +369,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
-		if (ready) {
+		if (run) {
 			ready = false;
 			++n_samples;
 			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
