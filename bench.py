@@ -122,22 +122,26 @@ def main():
     w, h = args.width, args.height
     focal = scene_mod.focal_from_fov_x(w, FOV_X)
     cams = [native.make_camera(scene_mod.orbit_camera(az), w, h, focal) for az in AZIMUTHS]
-    stream = torch.cuda.Stream(dev)  # the stream every kernel, copy and collective of a step is enqueued on
-    torch.cuda.set_stream(stream)
+    # Two frames in flight: frame i is rendered (and, for N > 1, gathered) on stream i % 2 into buffer set i % 2, so
+    # the drain of one frame's persistent kernel and its all_gather overlap the next frame's render. Every launch,
+    # copy and collective of a step is enqueued on that step's stream; fence() joins both.
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     if world > 1:
         # tile-packed output: the fused kernel writes this rank's tiles in the layout the all_gather moves
         opts = native.make_opts(shard_index=rank, shard_count=world, packed_output=True)
-        gatherer = parallel.PackedFrameGather(w, h, world, dev)
-        rgba, depth = gatherer.buffers()
+        gatherers = [parallel.PackedFrameGather(w, h, world, dev) for _ in streams]
+        outs = [g.buffers() for g in gatherers]
     else:
         opts = native.make_opts()
-        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
-        depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        outs = [(torch.zeros((h, w, 4), dtype=torch.float32, device=dev), torch.zeros((h, w), dtype=torch.float32, device=dev)) for _ in streams]
 
     def step(i):
-        ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            return gatherer.gather(rgba, depth)  # every rank ends the step holding the full frame
+        b = i % len(streams)
+        rgba, depth = outs[b]
+        with torch.cuda.stream(streams[b]):
+            ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), streams[b].cuda_stream)
+            if world > 1:
+                return gatherers[b].gather()  # every rank ends the step holding the full frame
         return rgba, depth
 
     def fence():

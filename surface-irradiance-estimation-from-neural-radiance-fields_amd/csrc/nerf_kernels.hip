@@ -32,6 +32,26 @@ struct Accum {
 // shade_kernel_nerf (src/testbed_nerf.cu:1361-1401, Shade mode) / shade_kernel_nerf_geometry depth test
 // (src/testbed_geometry_training.cu:1843-1846) for one finished ray. compact_kernel_nerf (:1420) only forwards
 // rays with alpha > 0.001.
+// accumulate_kernel with sample_count 0 (the mean of one sample is the sample) + tonemap_kernel, colour space Linear,
+// tonemap curve Identity: background blend, exposure, optional sRGB (src/render_buffer.cu:228-262, 529-561)
+NGP_DEV float4 tonemap_pixel(const FrameParams& F, float r, float g, float b, float a) {
+	float4 tmp = make_float4(r / 1.0f, g / 1.0f, b / 1.0f, a / 1.0f);
+	float weight = (1.0f - tmp.w) * F.background[3];
+	tmp.x += srgb_to_linear(F.background[0]) * weight;
+	tmp.y += srgb_to_linear(F.background[1]) * weight;
+	tmp.z += srgb_to_linear(F.background[2]) * weight;
+	tmp.w += weight;
+	tmp.x *= F.exposure_scale;
+	tmp.y *= F.exposure_scale;
+	tmp.z *= F.exposure_scale;
+	if (F.to_srgb) {
+		tmp.x = linear_to_srgb(tmp.x);
+		tmp.y = linear_to_srgb(tmp.y);
+		tmp.z = linear_to_srgb(tmp.z);
+	}
+	return tmp;
+}
+
 template <bool PROBE>
 NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, uint32_t idx, const Accum& acc) {
 	if (!(acc.a > 0.001f)) return false;
@@ -44,6 +64,11 @@ NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, uint32_t idx,
 	}
 	if (PROBE) {
 		P.ray_rgba[idx] = make_float4(r, g, b, a);
+		return true;
+	}
+	if (F.direct) { // the frame buffer would hold zeros: tmp + 0 * (1 - a) == tmp
+		F.frame_buffer[idx] = tonemap_pixel(F, r, g, b, a);
+		if (a > 0.2f) F.depth_buffer[idx] = acc.depth;
 		return true;
 	}
 	float4 fb = F.frame_buffer[idx];
@@ -108,6 +133,12 @@ NGP_DEV void init_probe_ray(const ProbeParams& P, uint32_t q, RayState& r) {
 
 // s_memtime stamp for the diagnostic section profile (cdna_hip_programming.md "In-kernel stamps"); never executed by
 // the production instantiation
+// chip-wide 100 MHz counter (the same on every CU, unlike s_memtime): wave timelines of the diagnostic build
+NGP_DEV unsigned long long realtime() {
+	unsigned long long t;
+	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+	return t;
+}
 NGP_DEV unsigned long long stamp() {
 	unsigned long long t;
 	__builtin_amdgcn_sched_barrier(0);
@@ -155,6 +186,13 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	uint32_t skip_i = 1;
 	bool ready = false, counted = false;
 	bool held = false; // ready, but left out of the last network phase
+	// Drain phase (tile queue empty): a wave's free slots carry CONTINUATIONS of its live rays, so that one network
+	// phase advances a ray by up to MAX_CHAIN samples instead of one (the reference's n_steps > 1 per compaction
+	// round, src/testbed_nerf.cu:2080-2086). crole = k > 0: this slot marches / holds sample k of another slot's
+	// ray; chain_next = slot that continues after this slot's sample. Compositing walks the chain in order and
+	// stops where the ray terminates, exactly as it would have sample by sample.
+	constexpr int MAX_CHAIN = 4;
+	int crole = 0, chain_next = -1;
 	OccBlockCache occ_cache;
 	occ_cache.key = 0xffffffffu;
 	occ_cache.bits = make_uint2(0u, 0u);
@@ -162,18 +200,22 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 
 	// wave-uniform tile reservoir
-	uint32_t tile = 0, tile_next = 64, tile_local = 0;
 	bool exhausted = false;
 	int stall = 0;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
 	unsigned long long pt[4] = {0, 0, 0, 0}, p_iters = 0, p_passes = 0, p_rounds = 0, p_lane_steps = 0, t0 = 0, t1 = 0;
 
+	unsigned long long rt_start = 0;
+	if (PROF && F.prof) {
+		rt_start = realtime();
+		if (lane == 0) atomicMax(&F.prof[8], ~rt_start); // = min over waves of the start time
+	}
 	for (;;) {
 		if (PROF) t0 = stamp();
 		// ---- refill free slots from the tile queue: K1 and the start-of-ray jitter of K2. The skip to the first
 		// occupied voxel that K2 also does (advance_pos_nerf, :356) is the same loop as K4's and runs below with every
 		// other marching lane -- a ray with nothing in front of it must not stall the 63 other slots of its wave.
-		unsigned long long dead_mask = __ballot(!ray.alive);
+		unsigned long long dead_mask = __ballot(!ray.alive && crole == 0); // (a parked continuation is not a free slot)
 		int n_dead = __popcll(dead_mask);
 		// ---- retire: K7 for the rays that ended since the last refill, all at once (sRGB->linear is three powf and a
 		// frame-buffer read-modify-write; run per round it would execute with one or two live lanes)
@@ -183,36 +225,41 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				finished = false;
 			}
 		}
-		if (!exhausted && n_dead >= F.tune[0]) {
-			if (tile_next >= 64) {
-				uint32_t tq = 0;
-				if (lane == 0) tq = atomicAdd(F.queue, 1u);
-				tq = __builtin_amdgcn_readfirstlane(tq);
-				if (tq >= F.n_local_tiles) {
-					exhausted = true;
-				} else {
-					tile = F.shard_index + F.shard_count * tq;
-					tile_local = tq;
-					tile_next = 0;
-				}
-			}
-			if (!exhausted) {
-				uint32_t slot = tile_next + lanes_below(dead_mask);
+		if (!exhausted && n_dead >= (F.tune[0] > 16 ? F.tune[0] : 16)) {
+			// the queue deals 8x2-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
+			// them, so the last units of a frame (or of a rank's share of it) are small and the waves end together
+			const uint32_t want = (uint32_t)n_dead >> 4, n_strips = F.n_local_tiles * 4u;
+			uint32_t first = 0;
+			if (lane == 0) first = atomicAdd(F.queue, want);
+			first = __builtin_amdgcn_readfirstlane(first);
+			if (first >= n_strips) {
+				exhausted = true;
+			} else {
+				const uint32_t got = n_strips - first < want ? n_strips - first : want;
+				const uint32_t r = lanes_below(dead_mask);
+				const uint32_t strip = first + (r >> 4);
+				const bool take = !ray.alive && r < got * 16u;
+				const uint32_t tile_local = strip >> 2, slot = (strip & 3u) * 16u + (r & 15u);
+				const uint32_t tile = F.shard_index + F.shard_count * tile_local;
 				bool fresh = false;
 				if (PROBE) {
 					uint32_t q = tile * 64u + slot;
-					if (!ray.alive && slot < 64 && q < P.n_rays) {
+					if (take && q < P.n_rays) {
 						init_probe_ray(P, q, ray);
 						fresh = true;
 					}
-				} else if (!ray.alive && slot < 64) {
+				} else if (take) {
 					uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
 					uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
 					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
 						init_ray(M, C, x, y, ray);
 						if (F.packed) ray.out = tile_local * 64u + slot;
-						// src/testbed_nerf.cu:1490-1493
-						if (F.depth_buffer[ray.out] < 0.01f) F.depth_buffer[ray.out] = MAX_DEPTH;
+						if (F.direct) { // CudaRenderBufferView::clear + the untouched pixel's trip through accumulate / tonemap
+							F.frame_buffer[ray.out] = tonemap_pixel(F, 0.f, 0.f, 0.f, 0.f);
+							F.depth_buffer[ray.out] = MAX_DEPTH;
+						} else if (F.depth_buffer[ray.out] < 0.01f) { // src/testbed_nerf.cu:1490-1493
+							F.depth_buffer[ray.out] = MAX_DEPTH;
+						}
 						if (ray.alive) {
 							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
 							fresh = true;
@@ -235,8 +282,50 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					counted = PROBE; // probe rays count as alive from the start (there is no K2 for them)
 					if (PROBE) ++n_alive_init;
 				}
-				uint32_t adv = tile_next + (uint32_t)n_dead;
-				tile_next = adv > 64u ? 64u : adv;
+			}
+		}
+
+		const int max_links = PROBE ? 0 : (exhausted ? F.tune[5] : F.tune[4]) < MAX_CHAIN - 1 ? (exhausted ? F.tune[5] : F.tune[4]) : MAX_CHAIN - 1;
+		if (!PROBE && max_links > 0) {
+			// ---- spawn continuations: the k-th free slot continues the k-th chain tail (a ready sample nobody continues yet)
+			const bool tail = ray.alive && ready && chain_next < 0 && crole < max_links;
+			const bool is_free = !ray.alive && !finished && crole == 0;
+			const unsigned long long tail_mask = __ballot(tail), free_mask = __ballot(is_free);
+			const int n_tail = __popcll(tail_mask), n_free = __popcll(free_mask);
+			const int n_pairs = n_tail < n_free ? n_tail : n_free;
+			if (n_pairs > 0) {
+				const uint32_t tail_rank = lanes_below(tail_mask), free_rank = lanes_below(free_mask);
+				// slot k of each table is written by the k-th tail / k-th free lane (ds_permute pushes along a bijection)
+				const uint32_t tslot = tail ? tail_rank : (uint32_t)n_tail + lanes_below(~tail_mask);
+				const uint32_t fslot = is_free ? free_rank : (uint32_t)n_free + lanes_below(~free_mask);
+				const int tail_of = __builtin_amdgcn_ds_permute((int)(tslot * 4u), lane);
+				const int free_of = __builtin_amdgcn_ds_permute((int)(fslot * 4u), lane);
+				const bool spawned = is_free && free_rank < (uint32_t)n_pairs;
+				const bool continued = tail && tail_rank < (uint32_t)n_pairs;
+				const int parent = __builtin_amdgcn_ds_bpermute((int)(free_rank * 4u), tail_of);
+				const int child = __builtin_amdgcn_ds_bpermute((int)(tail_rank * 4u), free_of);
+				const int src = spawned ? parent : lane;
+				const float pox = __shfl(ray.o.x, src, 64), poy = __shfl(ray.o.y, src, 64), poz = __shfl(ray.o.z, src, 64);
+				const float pdx = __shfl(ray.d.x, src, 64), pdy = __shfl(ray.d.y, src, 64), pdz = __shfl(ray.d.z, src, 64);
+				const float pt_after = __shfl(ray.t, src, 64); // the parent's t is already past its waiting sample
+				const int prole = __shfl(crole, src, 64);
+				if (continued) chain_next = child;
+				if (spawned) {
+					ray.o = mk3(pox, poy, poz);
+					ray.d = mk3(pdx, pdy, pdz);
+					ray.t = pt_after;
+					idir = mk3(1.0f / pdx, 1.0f / pdy, 1.0f / pdz);
+					ray.alive = true;
+					crole = prole + 1;
+					chain_next = -1;
+					ready = false;
+					held = false;
+					skip_i = 1;
+					counted = true;
+					// the direction's SH coefficients (K5c) travel with the ray
+#pragma unroll
+					for (int q = 0; q < 4; ++q) s_sh[threadIdx.x * 4 + q] = s_sh[((threadIdx.x & ~63) + parent) * 4 + q];
+				}
 			}
 		}
 
@@ -253,7 +342,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				if (PROBE && skip_i >= 200) out = true; // the 200-iteration variant of trace_mesh (:497-534)
 				if (out) {
 					ray.alive = false;
-					finished = true;
+					finished = crole == 0; // a continuation that runs out of the box is parked until its chain is composited
 				} else {
 					uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
 					mip = mip > max_cascade ? max_cascade : mip;
@@ -297,12 +386,20 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			++stall;
 			continue;
 		}
+		if (!PROBE && stall < max_links) {
+			// one more round per chain link while there are free slots to continue ready samples
+			const bool can_grow = __any(ray.alive && ready && chain_next < 0 && crole < max_links) && __any(!ray.alive && !finished && crole == 0);
+			if (can_grow || (exhausted && any_marching)) {
+				++stall;
+				continue;
+			}
+		}
 		stall = 0;
 
 		// ---- choose the samples of this phase: while marching lanes can still deliver more, only whole 16-sample
 		// passes run and the remainder waits (first in line next time), so no MFMA pass and no gather runs part-filled
 		int n_run = n_ready;
-		if (any_marching && n_ready > 16 && F.tune[3] < 16) n_run = n_ready & ~15;
+		if (any_marching && n_ready > 16 && F.tune[3] < 16 && max_links == 0) n_run = n_ready & ~15;
 		const unsigned long long held_mask = __ballot(ready && held);
 		const uint32_t rank = (ready && held) ? lanes_below(held_mask) : (uint32_t)__popcll(held_mask) + lanes_below(ready_mask & ~held_mask);
 		const bool run = ready && rank < (uint32_t)n_run;
@@ -369,21 +466,20 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
-		if (run) {
-			ready = false;
+		// one sample (network outputs, warped dt, depth of the sample along the camera axis) onto this lane's ray
+		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth) {
 			++n_samples;
-			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
 			float T = 1.0f - acc.a;
-			float dt = unwarp_dt(wdt);
-			float alpha = 1.0f - expf(-network_to_density((float)o_s, M.density_act) * dt);
+			float dt = unwarp_dt(swdt);
+			float alpha = 1.0f - expf(-network_to_density((float)ss, M.density_act) * dt);
 			float weight = alpha * T;
-			acc.r += network_to_rgb((float)o_r, M.rgb_act) * weight;
-			acc.g += network_to_rgb((float)o_g, M.rgb_act) * weight;
-			acc.b += network_to_rgb((float)o_b, M.rgb_act) * weight;
+			acc.r += network_to_rgb((float)sr, M.rgb_act) * weight;
+			acc.g += network_to_rgb((float)sg, M.rgb_act) * weight;
+			acc.b += network_to_rgb((float)sb, M.rgb_act) * weight;
 			acc.a += weight;
 			if (weight > acc.max_weight) {
 				acc.max_weight = weight;
-				acc.depth = dot3(cam_fwd, sub3(pos, cam_pos));
+				acc.depth = sdepth;
 			}
 			++step;
 			if (acc.a > (1.0f - F.min_transmittance)) {
@@ -393,6 +489,46 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			} else if (step >= MARCH_ITER) {
 				ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
 			}
+		};
+		float my_depth = 0.f;
+		if (run) {
+			ready = false;
+			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
+			my_depth = dot3(cam_fwd, sub3(pos, cam_pos));
+			if (crole == 0) composite(o_r, o_g, o_b, o_s, wdt, my_depth);
+		}
+		if (!PROBE && __any(chain_next >= 0)) {
+			// ---- walk the continuations in order; the walk ends where the ray ends or where a link did not run
+			int cur = (run && crole == 0 && ray.alive) ? chain_next : -1;
+			union { half_t h[2]; int i; } mlo, mhi;
+			mlo.h[0] = o_r; mlo.h[1] = o_g;
+			mhi.h[0] = o_b; mhi.h[1] = o_s;
+			const int link_ok = (run && crole > 0) ? 1 : 0;
+			for (int j = 1; j < MAX_CHAIN; ++j) {
+				if (!__any(cur >= 0)) break;
+				const int src = cur >= 0 ? cur : lane;
+				const int l_ok = __shfl(link_ok, src, 64);
+				union { half_t h[2]; int i; } llo, lhi;
+				llo.i = __shfl(mlo.i, src, 64);
+				lhi.i = __shfl(mhi.i, src, 64);
+				const float l_wdt = __shfl(wdt, src, 64), l_depth = __shfl(my_depth, src, 64), l_t = __shfl(ray.t, src, 64);
+				const int l_next = __shfl(chain_next, src, 64);
+				if (cur >= 0 && l_ok) {
+					composite(llo.h[0], llo.h[1], lhi.h[0], lhi.h[1], l_wdt, l_depth);
+					ray.t = l_t;
+					cur = ray.alive ? l_next : -1;
+				} else {
+					cur = -1;
+				}
+			}
+			// continuations live for one network phase
+			if (crole > 0) {
+				ray.alive = false;
+				ready = false;
+				held = false;
+				crole = 0;
+			}
+			chain_next = -1;
 		}
 		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; }
 	}
@@ -402,6 +538,11 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		atomicAdd(&F.prof[5], p_passes);
 		atomicAdd(&F.prof[6], p_rounds);
 		atomicAdd(&F.prof[7], p_lane_steps);
+		unsigned long long t_end = realtime(), t_first = ~F.prof[8];
+		atomicMax(&F.prof[9], t_end);
+		unsigned long long bucket = (t_end - t_first) / 10000ull; // 100 MHz * 0.1 ms = 10000 ticks
+		if (bucket > 47ull) bucket = 47ull;
+		atomicAdd(&F.prof[16 + bucket], 1ull);
 	}
 
 	// ---- counters (one atomic per wave and counter)
@@ -658,13 +799,30 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 
 // ---------------------------------------------------------------------------------------------------------
 // launchers (called from ngp_api.cpp)
-void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream) {
+// Persistent grids are sized to what is resident at once (workgroups per CU from the occupancy query): a workgroup
+// that only starts when another one has drained would begin its rays late and stretch the frame by a ray lifetime.
+template <typename K>
+static int resident_blocks_per_cu(K kernel) {
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
+	return n;
+}
+void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
 	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
+	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
+	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof);
+	int n_blocks = n_cus * (F.prof ? per_cu_prof : unit ? per_cu_unit : per_cu_generic);
+	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least
+	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 }
-void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream) {
+void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {
+	static const int per_cu = resident_blocks_per_cu(trace_probe_fused);
+	int n_blocks = n_cus * per_cu;
+	const int needed = (int)((F.n_local_tiles + 3) / 4);
+	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, F, P);
 }
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream) {

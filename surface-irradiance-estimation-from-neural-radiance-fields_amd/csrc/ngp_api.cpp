@@ -825,9 +825,9 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	FrameParams F{};
 	F.frame_buffer = ctx->d_frame;
 	F.depth_buffer = d_depth_out ? d_depth_out : ctx->d_depth;
-	F.queue = (uint32_t*)ctx->d_sync;
 	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
 	F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
+	F.queue = (uint32_t*)(F.counters + 3); // every call has its own queue word: frames on different streams may overlap
 	F.tiles_x = (uint32_t)(cam.width + 7) / 8;
 	F.tiles_y = (uint32_t)(cam.height + 7) / 8;
 	const uint32_t n_tiles = F.tiles_x * F.tiles_y;
@@ -839,10 +839,10 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.packed = opts.packed_output ? 1 : 0;
 	F.prof = nullptr;
 	memcpy(F.tune, ctx->tune, sizeof(F.tune));
-	if (const char* t = getenv("NGP_TUNE")) sscanf(t, "%d,%d,%d,%d", &F.tune[0], &F.tune[1], &F.tune[2], &F.tune[3]); // experiments only
+	if (const char* t = getenv("NGP_TUNE")) sscanf(t, "%d,%d,%d,%d,%d,%d", &F.tune[0], &F.tune[1], &F.tune[2], &F.tune[3], &F.tune[4], &F.tune[5]); // experiments only
 	if (getenv("NGP_PROFILE_SECTIONS")) { // diagnostic: per-section cycle sums of the fused kernel, printed by ngp_get_render_stats
-		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 64));
-		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 64, stream));
+		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 512));
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 512, stream));
 		F.prof = ctx->d_prof;
 	}
 	const bool geometry = opts.testbed_mode == NGP_MODE_GEOMETRY;
@@ -856,14 +856,28 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		M.r2l_identity = 1u;
 	}
 
+	// 1 spp and no mesh pass: the fused kernel writes finished pixels (clear + accumulate + tonemap folded in) straight
+	// into the caller's image -- one 32-byte memset and one launch per frame
+	// (a rank's share in image layout keeps the general path: the other ranks' pixels must read as an empty frame)
+	F.direct = (spp == 1 && !have_meshes && !geometry && (shard_count == 1 || opts.packed_output)) ? 1 : 0;
+	F.to_srgb = opts.to_srgb;
+	memcpy(F.background, opts.background, sizeof(F.background));
+	F.exposure_scale = powf(2.0f, opts.exposure);
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 	NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
-	for (int s = 0; s < spp; ++s) {
+	if (F.direct) {
+		F.frame_buffer = d_rgba_out;
+		CameraParams C = make_camera_params(cam, cam.spp_index);
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
+		launch_render_nerf(M, C, F, ctx->n_cus, stream);
+		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
+	}
+	for (int s = 0; s < spp && !F.direct; ++s) {
 		CameraParams C = make_camera_params(cam, cam.spp_index + (uint32_t)s);
 		// CudaRenderBufferView::clear (src/render_buffer.cu:603-607)
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_frame, 0, n_pixels * sizeof(float4), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(F.depth_buffer, 0, n_pixels * sizeof(float), stream));
-		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
+		NGP_HIP_CHECK(hipMemsetAsync(F.queue, 0, 8, stream));
 		const bool last = s == spp - 1;
 		if (have_meshes) {
 			IrradianceMap I{};
@@ -876,11 +890,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 			launch_render_mesh(ctx->mesh_scene, ctx->shade, I, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, F.packed, stream);
 		}
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
-		// persistent grid: 4 workgroups of 4 waves per CU; surplus waves find the queue empty and exit
-		int n_blocks = ctx->n_cus * 4;
-		const int needed = (int)((F.n_local_tiles + 3) / 4);
-		if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-		if (ctx->model_loaded) launch_render_nerf(M, C, F, n_blocks, stream);
+		if (ctx->model_loaded) launch_render_nerf(M, C, F, ctx->n_cus, stream); // persistent grid sized by the launcher
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, last ? d_rgba_out : nullptr, stream);
 	}
@@ -1182,8 +1192,15 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
 		read_history_slot(ctx, ctx->n_calls - 1, out);
 		if (ctx->d_prof && getenv("NGP_PROFILE_SECTIONS")) {
-			unsigned long long p[8];
+			unsigned long long p[64];
 			NGP_HIP_CHECK(hipMemcpy(p, ctx->d_prof, sizeof(p), hipMemcpyDeviceToHost));
+			{ // wave timeline on the 100 MHz chip clock: when the tile queue ran dry, when the last wave left
+				const double us = 0.01, t_first = (double)(~p[8]);
+				fprintf(stderr, "[ngp timeline] kernel %.1f us | queue empty seen first at %.1f us, last at %.1f us | wave exits per 0.1 ms:", ((double)p[9] - t_first) * us,
+				        ((double)(~p[10]) - t_first) * us, ((double)p[11] - t_first) * us);
+				for (int b = 0; b < 48; ++b) fprintf(stderr, " %llu", p[16 + b]);
+				fprintf(stderr, "\n");
+			}
 			double tot = (double)(p[0] + p[1] + p[2] + p[3]);
 			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
 			        100.0 * p[0] / tot, 100.0 * p[1] / tot, 100.0 * p[2] / tot, 100.0 * p[3] / tot, p[4], p[5], tot / (double)p[4], (double)p[2] / (double)p[5], p[6], p[7], (double)p[7] / (double)p[6], (double)p[1] / (double)p[6]);

@@ -24,7 +24,7 @@ namespace ngp {
 	} while (0)
 
 // kernel launchers, nerf_kernels.hip
-void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_blocks, hipStream_t stream);
+void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream);
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream);
 void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream);
@@ -36,7 +36,7 @@ void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, fl
 
 void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
                         uint32_t shard_index, uint32_t shard_count, int packed, hipStream_t stream);
-void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_blocks, hipStream_t stream);
+void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream);
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream);
 void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream);
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream);
@@ -134,7 +134,7 @@ struct ngp_ctx {
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
 	hipStream_t last_stream = nullptr;
 	unsigned long long* d_prof = nullptr;
-	int32_t tune[4] = {32, 4, 32, 1};
+	int32_t tune[6] = {32, 4, 32, 1, 0, 3};
 };
 
 namespace ngp {

@@ -81,7 +81,7 @@ struct CameraParams {
 struct FrameParams {
 	float4* frame_buffer;
 	float* depth_buffer;
-	uint32_t* queue;               // [0]: next local tile
+	uint32_t* queue;               // [0]: next strip (quarter tile) of this rank's share
 	unsigned long long* counters;  // [0] alive after init, [1] hit, [2] samples
 	uint32_t tiles_x, tiles_y;
 	uint32_t n_local_tiles;
@@ -90,7 +90,12 @@ struct FrameParams {
 	int32_t linear_colors;
 	int32_t depth_test;
 	int32_t packed;           // 1: pixel (local tile q, slot s) is written at q*64+s (tile-packed layout for the RCCL gather) instead of x+W*y
-	int32_t tune[4];          // refill_min, skip_steps, go_min, max_stall (nerf_kernels.hip)
+	int32_t tune[6];          // refill_min, skip_steps, go_min, max_stall, chain links while tiles remain / once the queue is empty (nerf_kernels.hip)
+	// direct output (1 spp, no mesh pass): the kernel writes the final pixel -- accumulate_kernel + tonemap_kernel
+	// (src/render_buffer.cu:228-262, 529-561) folded into ray setup / shading -- into frame_buffer = the caller's image
+	int32_t direct, to_srgb;
+	float background[4];
+	float exposure_scale;
 	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums
 };
 

@@ -387,8 +387,8 @@ int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 		hipStream_t stream = ctx->stream;
 		const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
 		FrameParams F{};
-		F.queue = (uint32_t*)ctx->d_sync;
 		F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
+		F.queue = (uint32_t*)(F.counters + 3);
 		F.n_local_tiles = (P.n_rays + 63) / 64;
 		F.shard_index = 0;
 		F.shard_count = 1;
@@ -397,11 +397,9 @@ int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 		memcpy(F.tune, ctx->tune, sizeof(F.tune));
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 		NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
-		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_sync, 0, 64, stream));
 		NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
-		int n_blocks = std::min<int>(ctx->n_cus * 4, (int)((F.n_local_tiles + 3) / 4));
-		launch_trace_probe(ctx->M, F, P, std::max(n_blocks, 1), stream);
+		launch_trace_probe(ctx->M, F, P, ctx->n_cus, stream);
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 		launch_probe_reduce(P, ctx->d_envmap, stream);
 		launch_irradiance(d->n_theta, d->n_phi, ctx->d_envmap, n_texels, nullptr, 1, ctx->d_irradiance, stream);

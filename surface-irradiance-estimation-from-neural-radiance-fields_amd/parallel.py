@@ -69,45 +69,53 @@ def gather_frame(local_img, width, height, rank, world_size, group=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# Tile-packed path (what bench.py uses for N > 1): the renderer writes this rank's tiles straight into the layout the
-# collective moves (ngp_render_opts.packed_output), so a frame costs: fused kernel -> tonemap -> all_gather(rgba),
-# all_gather(depth) -> one index_select each to scatter tiles into the image. The index tables are built once.
+# Tile-packed path (what bench.py uses for N > 1): the renderer writes this rank's finished pixels straight into the
+# buffer the collective moves (ngp_render_opts.packed_output) -- [n x rgba | n x depth], n = slots * 64 pixels -- so
+# a frame costs: fused kernel -> ONE all_gather_into_tensor of 20 B/pixel -> two index_select that scatter the tiles
+# into the image. Index tables and every buffer are built once; gather() allocates nothing, so instances can be
+# used round-robin on different streams (frame i's gather overlaps frame i+1's render).
 class PackedFrameGather:
     def __init__(self, width, height, world_size, device):
         self.w, self.h, self.world = width, height, world_size
         tx, ty = tile_grid(width, height)
         n_tiles = tx * ty
         self.n_slots = (n_tiles + world_size - 1) // world_size
-        # source row (rank, slot, within) of every image pixel
+        n = self.n = self.n_slots * 64
+        # source (rank, slot, within) of every image pixel
         ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
         tile = (ys // TILE) * tx + (xs // TILE)
         rank, slot = tile % world_size, tile // world_size
         within = (xs % TILE) + TILE * (ys % TILE)
-        self.src = ((rank * self.n_slots + slot) * 64 + within).reshape(-1).to(device)
+        self.src = ((rank * self.n_slots + slot) * 64 + within).reshape(-1).to(device)  # rows of [rank][n] tables
+        # the same pixel in the gathered flat buffer: rank r's block starts at float 5 n r
+        self.src_rgba = (rank * (5 * n // 4) + slot * 64 + within).reshape(-1).to(device)   # rows of recv.view(-1, 4)
+        self.src_depth = (rank * (5 * n) + 4 * n + slot * 64 + within).reshape(-1).to(device)
         self.device = device
+        self.send = torch.zeros((5 * n,), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((world_size * 5 * n,), dtype=torch.float32, device=device)
+        self.img = torch.zeros((height * width, 4), dtype=torch.float32, device=device)
+        self.depth = torch.zeros((height * width,), dtype=torch.float32, device=device)
 
     def buffers(self):
-        """(rgba, depth) send buffers for one rank: n_slots*64 pixels each (the tail of a rank with fewer tiles stays 0)."""
-        n = self.n_slots * 64
-        return (torch.zeros((n, 4), dtype=torch.float32, device=self.device), torch.zeros((n,), dtype=torch.float32, device=self.device))
+        """(rgba, depth) views of this rank's send buffer: n_slots*64 pixels each (the tail of a rank with fewer tiles stays 0)."""
+        n = self.n
+        return self.send[: 4 * n].view(n, 4), self.send[4 * n:]
 
-    def gather(self, rgba_packed, depth_packed, group=None):
+    def gather(self, group=None):
+        """All-gather what the renderer wrote into buffers(); returns (image (H, W, 4), depth (H, W)) views of
+        buffers that the next gather() of this instance overwrites."""
         import torch.distributed as dist
 
-        n = self.n_slots * 64
-        g_rgba = rgba_packed.new_empty((self.world * n, 4))
-        g_depth = depth_packed.new_empty((self.world * n,))
         if self.world > 1:
-            h1 = dist.all_gather_into_tensor(g_rgba, rgba_packed, group=group, async_op=True)
-            h2 = dist.all_gather_into_tensor(g_depth, depth_packed, group=group, async_op=True)
-            h1.wait()
-            h2.wait()
+            dist.all_gather_into_tensor(self.recv, self.send, group=group)
         else:
-            g_rgba.copy_(rgba_packed)
-            g_depth.copy_(depth_packed)
-        return self.unpack(g_rgba, g_depth)
+            self.recv.copy_(self.send)
+        torch.index_select(self.recv.view(-1, 4), 0, self.src_rgba, out=self.img)
+        torch.index_select(self.recv, 0, self.src_depth, out=self.depth)
+        return self.img.view(self.h, self.w, 4), self.depth.view(self.h, self.w)
 
     def unpack(self, g_rgba, g_depth):
+        """Scatter concatenated per-rank tables ((world*n, 4), (world*n,)) into the image (tests, tools)."""
         img = g_rgba.index_select(0, self.src).view(self.h, self.w, 4)
         depth = g_depth.index_select(0, self.src).view(self.h, self.w)
         return img, depth

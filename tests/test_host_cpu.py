@@ -212,7 +212,22 @@ def _gloo_worker(rank, world, port, w, h, q):
         y0, x0 = (t // tx) * 8, (t % tx) * 8
         mine[y0:y0 + 8, x0:x0 + 8] = full[y0:y0 + 8, x0:x0 + 8]
     out = par.gather_frame(mine, w, h, rank, world)
-    q.put((rank, bool(torch.equal(out, full))))
+    ok = bool(torch.equal(out, full))
+    # the tile-packed path of bench.py: two gatherers used alternately (two frames in flight), one collective per frame
+    gs = [par.PackedFrameGather(w, h, world, torch.device("cpu")) for _ in range(2)]
+    for frame in range(3):
+        g_ = gs[frame % 2]
+        img_full = full[..., :4] + float(frame)
+        dep_full = full[..., 4] + float(frame)
+        rgba, depth = g_.buffers()
+        for slot, t in enumerate(par.local_tiles(w, h, rank, world).tolist()):  # what the fused kernel writes (packed_output)
+            y0, x0 = (t // tx) * 8, (t % tx) * 8
+            th, tw = min(8, h - y0), min(8, w - x0)
+            rgba.view(-1, 8, 8, 4)[slot, :th, :tw] = img_full[y0:y0 + th, x0:x0 + tw]
+            depth.view(-1, 8, 8)[slot, :th, :tw] = dep_full[y0:y0 + th, x0:x0 + tw]
+        img, dep = g_.gather()
+        ok = ok and bool(torch.equal(img, img_full)) and bool(torch.equal(dep, dep_full))
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 

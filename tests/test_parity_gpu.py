@@ -232,8 +232,8 @@ def test_tile_packed_output_matches_image_layout(gpu_ctx, native, scene_mod, sce
         assert native.load_library().ngp_packed_tiles(w, h, r, world) <= g.n_slots
         gpu_ctx.render_device(cam, native.make_opts(shard_index=r, shard_count=world, packed_output=True), rgba.data_ptr(), depth.data_ptr(), None)
         gpu_ctx.render_stats()  # synchronises the context's stream
-        parts_rgba.append(rgba)
-        parts_depth.append(depth)
+        parts_rgba.append(rgba.clone())
+        parts_depth.append(depth.clone())
     img, dep = g.unpack(torch.cat(parts_rgba), torch.cat(parts_depth))
     assert np.array_equal(img.cpu().numpy(), full)
     assert np.array_equal(dep.cpu().numpy(), full_depth)

@@ -13,3 +13,7 @@ for az in (45.0, 135.0):
     ctx.render(cam)
     st = ctx.render_stats()
     print(az, st)
+# the same for one rank's share of an 8-way sharded frame (tail / fill of a short launch)
+opts = native.make_opts(shard_index=0, shard_count=8)
+ctx.render(native.make_camera(scene.orbit_camera(45.0), w, h, scene.focal_from_fov_x(w, 0.6911)), opts)
+print("shard 0/8", ctx.render_stats())
