@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("NGP_BENCH_INFLIGHT", "2")), help="frames in flight (streams / buffer sets)")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +126,7 @@ def main():
     # Two frames in flight: frame i is rendered (and, for N > 1, gathered) on stream i % 2 into buffer set i % 2, so
     # the drain of one frame's persistent kernel and its all_gather overlap the next frame's render. Every launch,
     # copy and collective of a step is enqueued on that step's stream; fence() joins both.
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.inflight))]
     if world > 1:
         # tile-packed output: the fused kernel writes this rank's tiles in the layout the all_gather moves
         opts = native.make_opts(shard_index=rank, shard_count=world, packed_output=True)

@@ -313,7 +313,6 @@ NGP_DEV void advance_pos(const ModelParams& M, const CameraParams& C, RayState& 
 // dimension d; result[f] += (half)(weight * (float)value[f]) accumulated in fp16).
 struct CornerSet {
 	uint32_t index[8];
-	float weight[8];
 };
 
 struct CellPos {
@@ -343,8 +342,7 @@ NGP_DEV bool level_in_xor_range(const LevelInfo& L, const CellPos& p) {
 }
 
 // tcnn grid_index, byte offsets into ModelParams::grid -- any position, any level shape
-NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, CornerSet& cs) {
-	CellPos p = level_cell(L, x, y, z);
+NGP_DEV void level_corners(const LevelInfo& L, const CellPos& p, CornerSet& cs) {
 	uint32_t ix[2], iy[2], iz[2];
 	if (L.hashed) {
 		ix[0] = p.gx;               ix[1] = p.gx + 1u;
@@ -363,7 +361,6 @@ NGP_DEV void level_corners(const LevelInfo& L, float x, float y, float z, Corner
 		idx = L.mask ? (idx & L.mask) : (idx % L.size);
 		cs.index[c] = (L.offset + idx) * 8u; // byte offset of the 4 x fp16 entry
 	}
-	corner_weights(p, cs.weight);
 }
 
 // The same 8 entries through the xor layout (byte offsets into ModelParams::xgrid): 2 multiplies, 3 adds and per
@@ -378,24 +375,20 @@ NGP_DEV void level_corners_xor(const LevelInfo& L, const CellPos& p, CornerSet& 
 		int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
 		cs.index[c] = ((ix[bx] ^ iy[by] ^ iz[bz]) & L.mask8) | L.base8;
 	}
-	corner_weights(p, cs.weight);
 }
 
 // Corner offsets + weights of the two levels a lane owns, and which table they index. Every render sample lies in
 // the xor layout's range; positions outside [0, 1] (possible through ngp_grid_encode / a render box larger than the
 // training box) take the tcnn-order table for the whole wave.
-NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y,
-                                       float z, CornerSet& c0, CornerSet& c1) {
-	const LevelInfo& L0 = lv[h];
-	const LevelInfo& L1 = lv[h + 4];
-	CellPos p0 = level_cell(L0, x, y, z), p1 = level_cell(L1, x, y, z);
+NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo& L0, const LevelInfo& L1, const CellPos& p0,
+                                       const CellPos& p1, CornerSet& c0, CornerSet& c1) {
 	if (__all((int)level_in_xor_range(L0, p0) & (int)level_in_xor_range(L1, p1))) {
 		level_corners_xor(L0, p0, c0);
 		level_corners_xor(L1, p1, c1);
 		return xgrid;
 	}
-	level_corners(L0, x, y, z, c0);
-	level_corners(L1, x, y, z, c1);
+	level_corners(L0, p0, c0);
+	level_corners(L1, p1, c1);
 	return (const char*)grid;
 }
 
@@ -431,55 +424,47 @@ NGP_DEV void store_features(const FeatureAcc& lo, const FeatureAcc& hi, half8& o
 // lane (h, c) of a 16-sample pass encodes levels h and h+4: B-fragment element j<4 is feature j of level h,
 // element j>=4 is feature j-4 of level h+4 (the K permutation n(s,h,j) = 32s + 16(j>>2) + 4h + (j&3) that the
 // host applied to every weight matrix, see ngp_api.cpp build_weight_fragments).
-NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z) {
-	CornerSet c0, c1;
-	// 32-bit byte offsets: both tables are below 4 GiB (checked by the host)
-	const char* base = level_pair_corners(grid, xgrid, lv, h, x, y, z, c0, c1);
-	uint2 v0[8], v1[8];
-#pragma unroll
-	for (int c = 0; c < 8; ++c) v0[c] = *(const uint2*)(base + c0.index[c]);
-#pragma unroll
-	for (int c = 0; c < 8; ++c) v1[c] = *(const uint2*)(base + c1.index[c]);
-	FeatureAcc lo = {{0, 0}, {0, 0}}, hi = {{0, 0}, {0, 0}};
-#pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(v0[c], c0.weight[c], lo);
-#pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(v1[c], c1.weight[c], hi);
-	half8 out;
-	store_features(lo, hi, out);
-	return out;
-}
-
-// The same encode split in two so that a wave can keep the gathers of two 16-sample passes (32 loads per lane) in
-// flight before it consumes either: issue computes the 16 addresses / weights and starts the loads, finish
-// accumulates. The values returned are identical to encode_level_pair's.
+// The encode is split in two so that a wave can keep the gathers of two 16-sample passes (32 loads per lane) in
+// flight before it consumes either: issue computes the 16 addresses and starts the loads, finish forms the 16
+// trilinear weights (from the 6 cell fractions kept meanwhile) and accumulates.
 struct EncodeInFlight {
 	uint2 v[16];
-	float w[16];
+	float wx[2], wy[2], wz[2];
 };
 NGP_DEV void encode_issue(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
+	const LevelInfo& L0 = lv[h];
+	const LevelInfo& L1 = lv[h + 4];
+	const CellPos p0 = level_cell(L0, x, y, z), p1 = level_cell(L1, x, y, z);
 	CornerSet c0, c1;
-	const char* base = level_pair_corners(grid, xgrid, lv, h, x, y, z, c0, c1);
+	// 32-bit byte offsets: both tables are below 4 GiB (checked by the host)
+	const char* base = level_pair_corners(grid, xgrid, L0, L1, p0, p1, c0, c1);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		e.v[c] = *(const uint2*)(base + c0.index[c]);
-		e.w[c] = c0.weight[c];
-	}
+	for (int c = 0; c < 8; ++c) e.v[c] = *(const uint2*)(base + c0.index[c]);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		e.v[8 + c] = *(const uint2*)(base + c1.index[c]);
-		e.w[8 + c] = c1.weight[c];
-	}
+	for (int c = 0; c < 8; ++c) e.v[8 + c] = *(const uint2*)(base + c1.index[c]);
+	e.wx[0] = p0.wx; e.wy[0] = p0.wy; e.wz[0] = p0.wz;
+	e.wx[1] = p1.wx; e.wy[1] = p1.wy; e.wz[1] = p1.wz;
 }
 NGP_DEV half8 encode_finish(const EncodeInFlight& e) {
-	FeatureAcc lo = {{0, 0}, {0, 0}}, hi = {{0, 0}, {0, 0}};
+	FeatureAcc acc[2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[c], e.w[c], lo);
+	for (int l = 0; l < 2; ++l) {
+		CellPos p;
+		p.gx = p.gy = p.gz = 0;
+		p.wx = e.wx[l]; p.wy = e.wy[l]; p.wz = e.wz[l];
+		float w[8];
+		corner_weights(p, w);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) accumulate_corner(e.v[8 + c], e.w[8 + c], hi);
+		for (int c = 0; c < 8; ++c) accumulate_corner(e.v[8 * l + c], w[c], acc[l]);
+	}
 	half8 out;
-	store_features(lo, hi, out);
+	store_features(acc[0], acc[1], out);
 	return out;
+}
+NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z) {
+	EncodeInFlight e;
+	encode_issue(grid, xgrid, lv, h, x, y, z, e);
+	return encode_finish(e);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -202,7 +202,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	// wave-uniform tile reservoir
 	bool exhausted = false;
 	int stall = 0;
-	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
+	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0; // wave-uniform (ballot counts)
 	unsigned long long pt[4] = {0, 0, 0, 0}, p_iters = 0, p_passes = 0, p_rounds = 0, p_lane_steps = 0, t0 = 0, t1 = 0;
 
 	unsigned long long rt_start = 0;
@@ -220,10 +220,12 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// ---- retire: K7 for the rays that ended since the last refill, all at once (sRGB->linear is three powf and a
 		// frame-buffer read-modify-write; run per round it would execute with one or two live lanes)
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
+			bool hit = false;
 			if (finished) {
-				n_hit += shade_ray<PROBE>(F, P, ray.out, acc) ? 1u : 0u;
+				hit = shade_ray<PROBE>(F, P, ray.out, acc);
 				finished = false;
 			}
+			n_hit += (uint32_t)__popcll(__ballot(hit));
 		}
 		if (!exhausted && n_dead >= (F.tune[0] > 16 ? F.tune[0] : 16)) {
 			// the queue deals 8x2-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
@@ -280,8 +282,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					ready = false;
 					held = false;
 					counted = PROBE; // probe rays count as alive from the start (there is no K2 for them)
-					if (PROBE) ++n_alive_init;
 				}
+				if (PROBE) n_alive_init += (uint32_t)__popcll(__ballot(fresh));
 			}
 		}
 
@@ -336,6 +338,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			const bool marching = ray.alive && !ready;
 			if (!__any(marching)) break;
 			if (PROF) { ++p_rounds; p_lane_steps += (unsigned long long)__popcll(__ballot(marching)); }
+			bool newly_counted = false;
 			if (marching) {
 				f3 pos = add3(ray.o, scale3(ray.d, ray.t));
 				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
@@ -357,7 +360,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 						ray.t = ray.t + dt;
 						ready = true;
 						skip_i = 1;
-						if (!counted) { counted = true; ++n_alive_init; }
+						newly_counted = !counted;
+						counted = true;
 					} else {
 						// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
 						// the cell, so the block summary of the final level is looked up again
@@ -372,6 +376,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					}
 				}
 			}
+			n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
 		}
 		unsigned long long ready_mask = __ballot(ready);
 		int n_ready = __popcll(ready_mask);
@@ -468,7 +473,6 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
 		// one sample (network outputs, warped dt, depth of the sample along the camera axis) onto this lane's ray
 		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth) {
-			++n_samples;
 			float T = 1.0f - acc.a;
 			float dt = unwarp_dt(swdt);
 			float alpha = 1.0f - expf(-network_to_density((float)ss, M.density_act) * dt);
@@ -497,6 +501,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			my_depth = dot3(cam_fwd, sub3(pos, cam_pos));
 			if (crole == 0) composite(o_r, o_g, o_b, o_s, wdt, my_depth);
 		}
+		n_samples += (uint32_t)__popcll(__ballot(run && crole == 0));
 		if (!PROBE && __any(chain_next >= 0)) {
 			// ---- walk the continuations in order; the walk ends where the ray ends or where a link did not run
 			int cur = (run && crole == 0 && ray.alive) ? chain_next : -1;
@@ -513,6 +518,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				lhi.i = __shfl(mhi.i, src, 64);
 				const float l_wdt = __shfl(wdt, src, 64), l_depth = __shfl(my_depth, src, 64), l_t = __shfl(ray.t, src, 64);
 				const int l_next = __shfl(chain_next, src, 64);
+				n_samples += (uint32_t)__popcll(__ballot(cur >= 0 && l_ok != 0));
 				if (cur >= 0 && l_ok) {
 					composite(llo.h[0], llo.h[1], lhi.h[0], lhi.h[1], l_wdt, l_depth);
 					ray.t = l_t;
@@ -546,11 +552,6 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	}
 
 	// ---- counters (one atomic per wave and counter)
-	for (int off = 32; off > 0; off >>= 1) {
-		n_alive_init += __shfl_down(n_alive_init, off, 64);
-		n_hit += __shfl_down(n_hit, off, 64);
-		n_samples += __shfl_down(n_samples, off, 64);
-	}
 	if (lane == 0) {
 		atomicAdd(&F.counters[0], (unsigned long long)n_alive_init);
 		atomicAdd(&F.counters[1], (unsigned long long)n_hit);

@@ -872,6 +872,11 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		launch_render_nerf(M, C, F, ctx->n_cus, stream);
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 	}
+	if (!F.direct && ctx->n_calls > 0 && ctx->last_stream && ctx->last_stream != stream) {
+		// the general path goes through the context's own frame / accumulate buffers: a frame on another stream must
+		// have left them (only direct-output frames may overlap each other)
+		NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_frame1[(ctx->n_calls - 1) % ngp_ctx::HISTORY], 0));
+	}
 	for (int s = 0; s < spp && !F.direct; ++s) {
 		CameraParams C = make_camera_params(cam, cam.spp_index + (uint32_t)s);
 		// CudaRenderBufferView::clear (src/render_buffer.cu:603-607)

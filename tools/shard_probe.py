@@ -12,20 +12,23 @@ ctx = native.Context(0)
 ctx.set_model(sc)
 w, h = 1920, 1080
 cams = [native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(w, 0.6911)) for az in (0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0)]
-stream = torch.cuda.Stream()
-rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-depth = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+INFLIGHT = int(os.environ.get("NGP_BENCH_INFLIGHT", "1"))
+streams = [torch.cuda.Stream() for _ in range(INFLIGHT)]
+bufs = [(torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"), torch.zeros((h, w), dtype=torch.float32, device="cuda")) for _ in streams]
 for n in (1, 2, 4, 8):
     worst = 0.0
     for r in range(n):
         opts = native.make_opts(shard_index=r, shard_count=n, packed_output=n > 1)
+        def go(i):
+            rgba, depth = bufs[i % INFLIGHT]
+            ctx.render_device(cams[i % 8], opts, rgba.data_ptr(), depth.data_ptr(), streams[i % INFLIGHT].cuda_stream)
         for i in range(4):
-            ctx.render_device(cams[i % 8], opts, rgba.data_ptr(), depth.data_ptr(), stream.cuda_stream)
+            go(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        K = 16
+        K = 32
         for i in range(K):
-            ctx.render_device(cams[i % 8], opts, rgba.data_ptr(), depth.data_ptr(), stream.cuda_stream)
+            go(i)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / K * 1e3
         hist = ctx.render_history(K)
