@@ -611,12 +611,16 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 
 // ---------------------------------------------------------------------------------------------------------
 // activations, nerf_device.cuh:203-263
-NGP_DEV float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The reference is built with --use_fast_math: its expf is __expf (ex2.approx of x * log2 e) and its divisions are
+// approximate. v_exp_f32 / v_rcp_f32 are the gfx950 counterparts (1 ulp); the oracle uses libm, the difference is
+// ~1e-7 relative per sample, far inside the image tolerance.
+NGP_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+NGP_DEV float logistic(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 NGP_DEV float network_to_rgb(float v, uint32_t act) {
 	switch (act) {
 		case 1: return v > 0.0f ? v : 0.0f;
 		case 2: return logistic(v);
-		case 3: return expf(fminf(fmaxf(v, -10.0f), 10.0f));
+		case 3: return fast_exp(fminf(fmaxf(v, -10.0f), 10.0f));
 		default: return v;
 	}
 }
@@ -624,7 +628,7 @@ NGP_DEV float network_to_density(float v, uint32_t act) {
 	switch (act) {
 		case 1: return v > 0.0f ? v : 0.0f;
 		case 2: return logistic(v);
-		case 3: return expf(v);
+		case 3: return fast_exp(v);
 		default: return v;
 	}
 }

@@ -475,7 +475,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth) {
 			float T = 1.0f - acc.a;
 			float dt = unwarp_dt(swdt);
-			float alpha = 1.0f - expf(-network_to_density((float)ss, M.density_act) * dt);
+			float alpha = 1.0f - fast_exp(-network_to_density((float)ss, M.density_act) * dt);
 			float weight = alpha * T;
 			acc.r += network_to_rgb((float)sr, M.rgb_act) * weight;
 			acc.g += network_to_rgb((float)sg, M.rgb_act) * weight;
