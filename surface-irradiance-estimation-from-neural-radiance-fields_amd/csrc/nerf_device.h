@@ -395,24 +395,30 @@ NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const cha
 // result[f] += (half)(weight * (float)value[f]) with tcnn's roundings: the fp32 product is rounded to fp32, THEN
 // to fp16, then added in fp16. hipcc would fuse the first two steps into v_fma_mix*_f16, which rounds the exact
 // product once -- more accurate, but a different number in ~2e-5 of the cases (tools/micro/mix_probe.hip) -- so the
-// product is pinned as an fp32 value of its own. Features are accumulated as packed pairs (v_pk_add_f16).
+// product is formed as an fp32 value of its own (v_fma_mix_f32). Features are accumulated as packed pairs
+// (v_cvt_pk_f16_f32 + v_pk_add_f16): 8 instructions per corner.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 struct FeatureAcc {
 	half2_t f01, f23;
 };
-NGP_DEV float pinned_product(float w, half_t v) {
-	float p = w * (float)v;
-	asm("" : "+v"(p));
+// fp32 product of an fp32 weight and one half of a packed fp16 pair, rounded to fp32: v_fma_mix_f32 reads the fp16
+// operand directly (no v_cvt_f32_f16) and, with an fp32 destination, rounds exactly like v_mul_f32
+NGP_DEV float product_lo(float w, uint32_t packed) {
+	float p;
+	asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(p) : "v"(w), "v"(packed));
+	return p;
+}
+NGP_DEV float product_hi(float w, uint32_t packed) {
+	float p;
+	asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(p) : "v"(w), "v"(packed));
 	return p;
 }
 NGP_DEV void accumulate_corner(uint2 v, float w, FeatureAcc& r) {
-	union { uint2 u; half_t h[4]; } cv;
-	cv.u = v;
 	half2_t a, b;
-	a[0] = (half_t)pinned_product(w, cv.h[0]);
-	a[1] = (half_t)pinned_product(w, cv.h[1]);
-	b[0] = (half_t)pinned_product(w, cv.h[2]);
-	b[1] = (half_t)pinned_product(w, cv.h[3]);
+	a[0] = (half_t)product_lo(w, v.x);
+	a[1] = (half_t)product_hi(w, v.x);
+	b[0] = (half_t)product_lo(w, v.y);
+	b[1] = (half_t)product_hi(w, v.y);
 	r.f01 = r.f01 + a;
 	r.f23 = r.f23 + b;
 }
