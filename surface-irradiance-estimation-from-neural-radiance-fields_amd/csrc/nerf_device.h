@@ -638,13 +638,14 @@ NGP_DEV float network_to_density(float v, uint32_t act) {
 		default: return v;
 	}
 }
+// powf under the reference's --use_fast_math: exp2(y * log2 x), x > 0
+NGP_DEV float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 NGP_DEV float srgb_to_linear(float s) { // common_device.cuh:34-40
-	return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f);
+	return s <= 0.04045f ? s / 12.92f : fast_pow((s + 0.055f) / 1.055f, 2.4f);
 }
 NGP_DEV float linear_to_srgb(float l) { // common_device.cuh:58-64
-	return l < 0.0031308f ? 12.92f * l : 1.055f * powf(l, 0.41666f) - 0.055f;
+	return l < 0.0031308f ? 12.92f * l : 1.055f * fast_pow(l, 0.41666f) - 0.055f;
 }
-
 NGP_DEV uint32_t lanes_below(unsigned long long mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }

@@ -34,12 +34,12 @@ struct Accum {
 // rays with alpha > 0.001.
 // accumulate_kernel with sample_count 0 (the mean of one sample is the sample) + tonemap_kernel, colour space Linear,
 // tonemap curve Identity: background blend, exposure, optional sRGB (src/render_buffer.cu:228-262, 529-561)
-NGP_DEV float4 tonemap_pixel(const FrameParams& F, float r, float g, float b, float a) {
+NGP_DEV float4 tonemap_pixel(const FrameParams& F, f3 bg_linear, float r, float g, float b, float a) {
 	float4 tmp = make_float4(r / 1.0f, g / 1.0f, b / 1.0f, a / 1.0f);
 	float weight = (1.0f - tmp.w) * F.background[3];
-	tmp.x += srgb_to_linear(F.background[0]) * weight;
-	tmp.y += srgb_to_linear(F.background[1]) * weight;
-	tmp.z += srgb_to_linear(F.background[2]) * weight;
+	tmp.x += bg_linear.x * weight;
+	tmp.y += bg_linear.y * weight;
+	tmp.z += bg_linear.z * weight;
 	tmp.w += weight;
 	tmp.x *= F.exposure_scale;
 	tmp.y *= F.exposure_scale;
@@ -53,7 +53,7 @@ NGP_DEV float4 tonemap_pixel(const FrameParams& F, float r, float g, float b, fl
 }
 
 template <bool PROBE>
-NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, uint32_t idx, const Accum& acc) {
+NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc) {
 	if (!(acc.a > 0.001f)) return false;
 	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
@@ -67,7 +67,7 @@ NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, uint32_t idx,
 		return true;
 	}
 	if (F.direct) { // the frame buffer would hold zeros: tmp + 0 * (1 - a) == tmp
-		F.frame_buffer[idx] = tonemap_pixel(F, r, g, b, a);
+		F.frame_buffer[idx] = tonemap_pixel(F, bg_linear, r, g, b, a);
 		if (a > 0.2f) F.depth_buffer[idx] = acc.depth;
 		return true;
 	}
@@ -168,6 +168,9 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const int lane = threadIdx.x & 63;
 	const int c = lane & 15;
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
+	// direct output: the background's trip through the tonemap is the same for every pixel
+	const f3 bg_linear = (!PROBE && F.direct) ? mk3(srgb_to_linear(F.background[0]), srgb_to_linear(F.background[1]), srgb_to_linear(F.background[2])) : mk3(0.f, 0.f, 0.f);
+	const float4 empty_pixel = (!PROBE && F.direct) ? tonemap_pixel(F, bg_linear, 0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
 	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
 	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
@@ -222,7 +225,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
 			bool hit = false;
 			if (finished) {
-				hit = shade_ray<PROBE>(F, P, ray.out, acc);
+				hit = shade_ray<PROBE>(F, P, bg_linear, ray.out, acc);
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -257,7 +260,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 						init_ray(M, C, x, y, ray);
 						if (F.packed) ray.out = tile_local * 64u + slot;
 						if (F.direct) { // CudaRenderBufferView::clear + the untouched pixel's trip through accumulate / tonemap
-							F.frame_buffer[ray.out] = tonemap_pixel(F, 0.f, 0.f, 0.f, 0.f);
+							F.frame_buffer[ray.out] = empty_pixel;
 							F.depth_buffer[ray.out] = MAX_DEPTH;
 						} else if (F.depth_buffer[ray.out] < 0.01f) { // src/testbed_nerf.cu:1490-1493
 							F.depth_buffer[ray.out] = MAX_DEPTH;
