@@ -277,3 +277,43 @@ def test_errors_are_reported(gpu_ctx, native, scene_unit):
     with pytest.raises(RuntimeError, match="msgpack|snapshot"):
         ctx2.load_snapshot_bytes(b"\x81\xa1a\x01")
     ctx2.close()
+
+
+def test_direct_output_matches_general_path_and_oracle(gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """1 spp without meshes takes the direct-output path (clear + accumulate + tonemap folded into the fused kernel);
+    geometry mode without meshes renders the same frame through the general path (separate clear / tonemap passes)."""
+    w, h = 136, 77
+    gpu_ctx.set_model(scene_unit)
+    gpu_ctx.clear_meshes()
+    mat = scene_mod.orbit_camera(75.0)
+    focal = scene_mod.focal_from_fov_x(w, 0.6911)
+    cam = native.make_camera(mat, w, h, focal)
+    kw = dict(to_srgb=True, background=(0.3, 0.5, 0.1, 0.8), exposure=-0.25)
+    direct, d_depth = gpu_ctx.render(cam, native.make_opts(**kw), want_depth=True)
+    m = oracle.make_model(scene_unit)
+    fb, db, _ = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal))
+    oracle.release(m)
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0), kw["background"], kw["exposure"], True).reshape(h, w, 4)
+    assert_image_close(direct, ref, 48.0, tol=2e-2)
+    assert np.median(np.abs(d_depth - db.reshape(h, w))) < 1e-4
+    general, g_depth = gpu_ctx.render(cam, native.make_opts(testbed_mode=native.MODE_GEOMETRY, **kw), want_depth=True)  # no meshes: same frame, general path
+    assert np.abs(general - direct).max() < 1e-6 and np.array_equal(g_depth, d_depth)
+
+
+def test_frames_on_two_streams_overlap_safely(gpu_ctx, native, scene_mod, scene_unit):
+    """bench.py keeps two frames in flight (streams i % 2, own output buffers): every frame must equal its serial render."""
+    import torch
+
+    w, h, n = 256, 144, 6
+    gpu_ctx.set_model(scene_unit)
+    cams = [native.make_camera(scene_mod.orbit_camera(30.0 + 50.0 * i), w, h, scene_mod.focal_from_fov_x(w, 0.6911)) for i in range(n)]
+    serial = [gpu_ctx.render(c, native.make_opts(), want_depth=True) for c in cams]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(torch.zeros((h, w, 4), device="cuda"), torch.zeros((h, w), device="cuda")) for _ in range(n)]
+    for i, c in enumerate(cams):
+        gpu_ctx.render_device(c, native.make_opts(), outs[i][0].data_ptr(), outs[i][1].data_ptr(), streams[i % 2].cuda_stream)
+    torch.cuda.synchronize()
+    hist = gpu_ctx.render_history(n)
+    for i in range(n):
+        assert np.array_equal(outs[i][0].cpu().numpy(), serial[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), serial[i][1])
+        assert hist[i]["n_samples"] > 0 and hist[i]["n_rays"] == ((w + 7) // 8) * ((h + 7) // 8) * 64
