@@ -150,13 +150,13 @@ NGP_DEV unsigned long long stamp() {
 // UNIT: unit-cube scenes (aabb_scale 1 => one cascade, cone angle 0 => fixed step sqrt(3)/1024; load_nerf_post,
 // src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
 // exponential-stepping branches; the arithmetic that remains is the same expression for expression.
-template <bool PROBE, bool PROF = false, bool UNIT = false>
+template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES)>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
 	__shared__ uint4 s_w[N_FRAGS * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
-	__shared__ uint32_t s_coarse[(UNIT ? 1 : NERF_CASCADES) * COARSE_WORDS_PER_MIP]; // 4 KB per cascade: empty-space summary of the occupancy grid
+	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade in use: empty-space summary of the occupancy grid (the host picks an instantiation with MIPS > max_cascade)
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
 	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
 	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
@@ -570,6 +570,11 @@ __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelPa
 	ProbeParams P{};
 	fused_body<false, false, true>(M, C, F, P);
 }
+// scenes of up to 5 cascades (aabb_scale <= 16: fox, garden): 20 KB of occupancy summaries instead of 32 leave room for a third workgroup per CU
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, 5>(M, C, F, P);
+}
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
@@ -813,13 +818,15 @@ static int resident_blocks_per_cu(K kernel) {
 }
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
 	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
+	const bool c5 = !unit && M.max_cascade < 5;
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
-	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof);
-	int n_blocks = n_cus * (F.prof ? per_cu_prof : unit ? per_cu_unit : per_cu_generic);
+	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5);
+	int n_blocks = n_cus * (F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic);
 	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+	else if (c5) hipLaunchKernelGGL(render_nerf_fused_c5, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
 }
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {

@@ -124,13 +124,19 @@ def mesh_config(ctx, sc):
 
 
 if __name__ == "__main__":
+    only = set(os.environ.get("RUN_ONLY", "1,2,3,4,5").split(","))
     az8 = (0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0)
-    ctx, sc = nerf_config("2: Lego-shaped (aabb 1, T19, b=2.0), 1080p", synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19), 1920, 1080, az8)
-    mesh_config(ctx, sc)
-    ctx.close()
-    ctx, _ = nerf_config("4: fox-shaped (aabb 4, cone 1/256, 3 cascades, upstream b=2.44), 4K", synthetic.make_scene(aabb_scale=4, seed=7, log2_hashmap_size=19, pls_rule="upstream"), 3840, 2160, az8)
-    ctx.close()
-    ctx, _ = nerf_config("5: garden-shaped (aabb 16, 5 cascades, upstream b=2.97), 1080p", synthetic.make_scene(aabb_scale=16, seed=11, log2_hashmap_size=19, pls_rule="upstream"), 1920, 1080, az8)
-    ctx.close()
-    ctx, _ = nerf_config("1: fox-shaped plumbing case, 256x256", synthetic.make_scene(aabb_scale=4, seed=7, log2_hashmap_size=19, pls_rule="fork"), 256, 256, (45.0,), check_wh=(256, 256))
-    ctx.close()
+    if "2" in only or "3" in only:
+        ctx, sc = nerf_config("2: Lego-shaped (aabb 1, T19, b=2.0), 1080p", synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19), 1920, 1080, az8)
+        if "3" in only:
+            mesh_config(ctx, sc)
+        ctx.close()
+    if "4" in only:
+        ctx, _ = nerf_config("4: fox-shaped (aabb 4, cone 1/256, 3 cascades, upstream b=2.44), 4K", synthetic.make_scene(aabb_scale=4, seed=7, log2_hashmap_size=19, pls_rule="upstream"), 3840, 2160, az8)
+        ctx.close()
+    if "5" in only:
+        ctx, _ = nerf_config("5: garden-shaped (aabb 16, 5 cascades, upstream b=2.97), 1080p", synthetic.make_scene(aabb_scale=16, seed=11, log2_hashmap_size=19, pls_rule="upstream"), 1920, 1080, az8)
+        ctx.close()
+    if "1" in only:
+        ctx, _ = nerf_config("1: fox-shaped plumbing case, 256x256", synthetic.make_scene(aabb_scale=4, seed=7, log2_hashmap_size=19, pls_rule="fork"), 256, 256, (45.0,), check_wh=(256, 256))
+        ctx.close()
