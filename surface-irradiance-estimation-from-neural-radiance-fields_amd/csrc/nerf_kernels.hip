@@ -206,6 +206,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	bool exhausted = false;
 	int stall = 0;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0; // wave-uniform (ballot counts)
+	unsigned long long p_skip[3] = {0, 0, 0};
 	unsigned long long pt[4] = {0, 0, 0, 0}, p_iters = 0, p_passes = 0, p_rounds = 0, p_lane_steps = 0, t0 = 0, t1 = 0;
 
 	unsigned long long rt_start = 0;
@@ -374,6 +375,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 							++mip;
 							empty = e;
 						}
+						if (PROF) p_skip[empty == 16u ? 2 : (empty == 4u ? 1 : 0)] += 1ull;
 						ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
 						++skip_i;
 					}
@@ -541,7 +543,12 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		}
 		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; }
 	}
+	if (PROF) { // per-lane skip steps by jump size: reduce over the wave first
+		for (int k = 0; k < 3; ++k)
+			for (int off = 32; off > 0; off >>= 1) p_skip[k] += __shfl_down(p_skip[k], off, 64);
+	}
 	if (PROF && lane == 0 && F.prof) {
+		for (int k = 0; k < 3; ++k) atomicAdd(&F.prof[12 + k], p_skip[k]);
 		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], pt[k]);
 		atomicAdd(&F.prof[4], p_iters);
 		atomicAdd(&F.prof[5], p_passes);

@@ -1204,7 +1204,7 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 				fprintf(stderr, "[ngp timeline] kernel %.1f us | queue empty seen first at %.1f us, last at %.1f us | wave exits per 0.1 ms:", ((double)p[9] - t_first) * us,
 				        ((double)(~p[10]) - t_first) * us, ((double)p[11] - t_first) * us);
 				for (int b = 0; b < 48; ++b) fprintf(stderr, " %llu", p[16 + b]);
-				fprintf(stderr, "\n");
+				fprintf(stderr, "\n[ngp skips] lane-steps that left an empty cell %llu, an empty 4^3 block %llu, an empty 16^3 block %llu\n", p[12], p[13], p[14]);
 			}
 			double tot = (double)(p[0] + p[1] + p[2] + p[3]);
 			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
