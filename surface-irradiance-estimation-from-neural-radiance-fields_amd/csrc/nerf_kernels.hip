@@ -828,7 +828,12 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	const bool c5 = !unit && M.max_cascade < 5;
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
 	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5);
-	int n_blocks = n_cus * (F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic);
+	int per_cu = F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic;
+	// a rank of a sharded frame leaves a third of every CU to the collective's kernels and to the next frame's launch
+	// (measured on one GPU with two frames in flight: 2 per CU is as fast as 3 from N = 2 on, tools/shard_probe.py)
+	if (F.shard_count > 1 && per_cu > 2) per_cu = 2;
+	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
+	int n_blocks = n_cus * per_cu;
 	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
