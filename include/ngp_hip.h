@@ -161,6 +161,15 @@ NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16
 NGP_API int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16);
 /* K8/K9 update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:2863-2880): the bitfield in use, 8 x 128^3 / 8 bytes */
 NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean);
+/* Testbed::update_density_grid_nerf (src/testbed_nerf.cu:2772-2861; kernels :185-232, :253-276): refresh the occupancy
+ * grid from the density network -- n_uniform samples in random cells + n_nonuniform samples in cells above
+ * NERF_MIN_OPTICAL_THICKNESS, density MLP, max-splat, decayed maximum into the grid -- n_iterations times, then the
+ * mean / bitfield / max-pool of K8/K9. The generator (pcg32, seeded like reset_network does, testbed.cu:3848-3861) and
+ * the EMA step counter live in the context. n_uniform = n_nonuniform = 0 selects training_prep_nerf's schedule
+ * (:3432-3446): 128^3 x cascades uniform samples for the first 256 steps, then a quarter of that of each kind. */
+NGP_API int ngp_update_density_grid(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations);
+/* the float density grid in use: (max_cascade + 1) x 128^3 values, Morton order per cascade */
+NGP_API int ngp_get_density_grid(ngp_ctx* ctx, float* out, uint64_t n);
 /* K1+K2 init_rays_with_payload_kernel_nerf + advance_pos_nerf_kernel (src/testbed_nerf.cu:1428-1544,333-381):
  * out: W*H NerfPayload records of 40 bytes (nerf_device.cuh:144-152) */
 NGP_API int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out);

@@ -105,6 +105,15 @@ void orc_nerf_network(const orc_nerf_model* m, uint32_t n, const float* pos01, c
 /* K8/K9: density grid (float, Morton order, (max_cascade+1) x 128^3) -> bitfield (8 x 128^3 / 8 bytes) */
 void orc_density_grid_to_bitfield(const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* out_mean);
 
+/* Density-grid refresh from the network: one iteration of Testbed::update_density_grid_nerf (src/testbed_nerf.cu:2772-2861)
+ * on `grid` ((max_cascade + 1) x 128^3 floats, Morton order), without the mean / bitfield step. */
+typedef struct orc_pcg32 { uint64_t state, inc; } orc_pcg32;
+void orc_pcg32_seed(orc_pcg32* r, uint64_t initstate, uint64_t initseq);
+uint32_t orc_pcg32_next_uint(orc_pcg32* r);
+void orc_pcg32_advance(orc_pcg32* r, uint64_t delta);
+void orc_update_density_grid(const orc_nerf_model* m, float* grid, uint32_t max_cascade, orc_pcg32* rng, uint32_t* ema_step, float decay, uint32_t n_uniform,
+                             uint32_t n_nonuniform);
+
 /* sampling sequences, random_val.cuh:207-370 */
 float orc_ld_random_val(uint32_t index, uint32_t seed, uint32_t dim);
 void orc_ld_random_pixel_offset(uint32_t spp, float* out2);

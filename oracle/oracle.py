@@ -227,6 +227,26 @@ class Oracle:
         self.lib.orc_density_grid_to_bitfield(_ptr(grid), max_cascade, _ptr(bf), C.byref(mean))
         return bf, mean.value
 
+    def update_density_grid(self, m, grid, max_cascade, rng, ema_step, decay=0.95, n_uniform=0, n_nonuniform=0):
+        """One iteration of update_density_grid_nerf on a float grid; rng = [state, inc] (mutated), returns (grid, ema_step)."""
+        g = np.ascontiguousarray(grid, np.float32).copy()
+        assert g.size == 128 ** 3 * (max_cascade + 1)
+        r = (C.c_uint64 * 2)(rng[0], rng[1])
+        step = C.c_uint32(ema_step)
+        self.lib.orc_update_density_grid(C.byref(m), _ptr(g), max_cascade, r, C.byref(step), C.c_float(decay), n_uniform, n_nonuniform)
+        rng[0], rng[1] = r[0], r[1]
+        return g, step.value
+
+    def grid_rng(self, seed=1337):
+        """m_nerf.training.density_grid_rng after reset_network: pcg32(pcg32(seed).next_uint())"""
+        a = (C.c_uint64 * 2)()
+        self.lib.orc_pcg32_seed(a, C.c_uint64(seed), C.c_uint64(1))
+        self.lib.orc_pcg32_next_uint.restype = C.c_uint32
+        first = self.lib.orc_pcg32_next_uint(a)
+        b = (C.c_uint64 * 2)()
+        self.lib.orc_pcg32_seed(b, C.c_uint64(first), C.c_uint64(1))
+        return [int(b[0]), int(b[1])]
+
     def ld_random_val(self, index, seed, dim=0):
         return self.lib.orc_ld_random_val(index & 0xFFFFFFFF, seed & 0xFFFFFFFF, dim)
 

@@ -733,3 +733,105 @@ void orc_tonemap(uint32_t n_pixels, const float* accumulate_buffer, const float*
 		for (int k = 0; k < 4; ++k) rgba_out[4 * i + k] = c[k];
 	}
 }
+
+
+/* ------------------------------------------------------------------ density-grid refresh
+ * Testbed::update_density_grid_nerf, src/testbed_nerf.cu:2772-2861; kernels :185-232 (sample generation, splat)
+ * and :253-276 (decayed maximum). default_rng_t is pcg32 from tiny-cuda-nn's dependencies/pcg32/pcg32.h (an
+ * un-vendored submodule, absent from the mount): restated here from the published generator -- 64-bit LCG
+ * (multiplier 0x5851f42d4c957f2d), XSH-RR output, skip-ahead in log time, next_float from the top 23 bits. */
+static uint32_t pcg32_next_uint(orc_pcg32* r) {
+	uint64_t oldstate = r->state;
+	r->state = oldstate * 0x5851f42d4c957f2dULL + r->inc;
+	uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+	uint32_t rot = (uint32_t)(oldstate >> 59u);
+	return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+}
+void orc_pcg32_seed(orc_pcg32* r, uint64_t initstate, uint64_t initseq) {
+	r->state = 0u;
+	r->inc = (initseq << 1u) | 1u;
+	pcg32_next_uint(r);
+	r->state += initstate;
+	pcg32_next_uint(r);
+}
+uint32_t orc_pcg32_next_uint(orc_pcg32* r) { return pcg32_next_uint(r); }
+static float pcg32_next_float(orc_pcg32* r) {
+	union { uint32_t u; float f; } x;
+	x.u = (pcg32_next_uint(r) >> 9) | 0x3f800000u;
+	return x.f - 1.0f;
+}
+void orc_pcg32_advance(orc_pcg32* r, uint64_t delta) {
+	uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = r->inc, acc_mult = 1u, acc_plus = 0u;
+	while (delta > 0) {
+		if (delta & 1) {
+			acc_mult *= cur_mult;
+			acc_plus = acc_plus * cur_mult + cur_plus;
+		}
+		cur_plus = (cur_mult + 1) * cur_plus;
+		cur_mult *= cur_mult;
+		delta >>= 1;
+	}
+	r->state = acc_mult * r->state + acc_plus;
+}
+
+/* generate_grid_samples_nerf_nonuniform (:185-213) + NerfNetwork::density + splat_..._max_nearest_neighbor (:215-232) */
+static void grid_samples_splat(const orc_nerf_model* m, const prepared_t* p, uint32_t n_samples, orc_pcg32 rng0, uint32_t step, uint32_t n_cascades, float thresh,
+                               const float* grid_in, float* grid_tmp) {
+#pragma omp parallel for schedule(dynamic, 4096)
+	for (int64_t ii = 0; ii < (int64_t)n_samples; ++ii) {
+		const uint32_t i = (uint32_t)ii;
+		orc_pcg32 rng = rng0;
+		orc_pcg32_advance(&rng, (uint64_t)i * 4u);
+		uint32_t level = (uint32_t)(pcg32_next_float(&rng) * (float)n_cascades) % n_cascades;
+		uint32_t idx = 0;
+		for (uint32_t j = 0; j < 10; ++j) {
+			idx = ((i + step * n_samples) * 56924617u + j * 19349663u + 96925573u) % NERF_GRID_N_CELLS;
+			idx += level * NERF_GRID_N_CELLS;
+			if (grid_in[idx] > thresh) break;
+		}
+		uint32_t pos_idx = idx % NERF_GRID_N_CELLS;
+		float x = (float)morton3D_invert(pos_idx >> 0), y = (float)morton3D_invert(pos_idx >> 1), z = (float)morton3D_invert(pos_idx >> 2);
+		float rx = pcg32_next_float(&rng), ry = pcg32_next_float(&rng), rz = pcg32_next_float(&rng);
+		float scale = scalbnf(1.0f, (int)level);
+		float pos[3] = {((x + rx) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f, ((y + ry) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f,
+		                ((z + rz) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f};
+		float pos01[3];
+		for (int d = 0; d < 3; ++d) { /* warp_position */
+			float lo = d == 0 ? p->aabb.min.x : (d == 1 ? p->aabb.min.y : p->aabb.min.z);
+			float hi = d == 0 ? p->aabb.max.x : (d == 1 ? p->aabb.max.y : p->aabb.max.z);
+			pos01[d] = (pos[d] - lo) / (hi - lo);
+		}
+		uint16_t enc_h[ORC_MAX_LEVELS * 8];
+		float enc[ORC_MAX_LEVELS * 8], dens_f[64];
+		uint16_t dens_h[32];
+		grid_encode_one(m, p, pos01, enc_h);
+		for (uint32_t k = 0; k < p->enc_dims; ++k) enc[k] = orc_half_to_float(enc_h[k]);
+		mlp_forward(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens_f, dens_h);
+		float thickness = network_to_density(orc_half_to_float(dens_h[0]), m->density_activation) * MIN_CONE_STEPSIZE();
+		/* atomicMax on the bit pattern: positive floats order like unsigned ints */
+		union { float f; uint32_t u; } nv, ov;
+		nv.f = thickness;
+#pragma omp critical(orc_grid_splat)
+		{
+			ov.f = grid_tmp[idx];
+			if (nv.u > ov.u) grid_tmp[idx] = nv.f;
+		}
+	}
+}
+
+void orc_update_density_grid(const orc_nerf_model* m, float* grid, uint32_t max_cascade, orc_pcg32* rng, uint32_t* ema_step, float decay, uint32_t n_uniform,
+                             uint32_t n_nonuniform) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+	const uint32_t n_cascades = max_cascade + 1, n_elements = NERF_GRID_N_CELLS * n_cascades;
+	float* tmp = (float*)calloc(n_elements, sizeof(float));
+	grid_samples_splat(m, p, n_uniform, *rng, *ema_step, n_cascades, -0.01f, grid, tmp);
+	orc_pcg32_advance(rng, 1ull << 32);
+	grid_samples_splat(m, p, n_nonuniform, *rng, *ema_step, n_cascades, NERF_MIN_OPTICAL_THICKNESS, grid, tmp);
+	orc_pcg32_advance(rng, 1ull << 32);
+	for (uint32_t i = 0; i < n_elements; ++i) { /* ema_grid_samples_nerf */
+		float prev = grid[i];
+		grid[i] = prev < 0.f ? prev : fmaxf(prev * decay, tmp[i]);
+	}
+	++*ema_step;
+	free(tmp);
+}

@@ -572,6 +572,18 @@ NGP_DEV Sh4 sh4_from_dir(int h, float dx01, float dy01, float dz01) {
 	return r;
 }
 
+// density head alone (NerfNetwork::density, nerf_network.h): the logit of sample c in lanes 0..15
+NGP_DEV half_t density_pass(const uint4* s_w, int lane, half8 enc) {
+	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
+	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
+	floatx4 d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
+	floatx4 d3 = mfma16(ld_frag(s_w, FRAG_D0 + 3, lane), enc, zero);
+	half8 b0 = relu_pack(d0, d1), b1 = relu_pack(d2, d3);
+	floatx4 dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
+	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
+	return (half_t)dens[0];
+}
 NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 	// density head: 32 -> 64 (ReLU) -> 16

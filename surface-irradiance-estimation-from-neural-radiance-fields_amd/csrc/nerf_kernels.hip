@@ -13,6 +13,7 @@
 // Every iteration the live slots are compacted (ds_permute) onto 16-sample MFMA passes: 4 lanes cooperate on one
 // sample's hash-grid levels (2 levels each) and the MLPs run with samples on the MFMA N axis (nerf_device.h).
 #include "nerf_device.h"
+#include "pcg32.h"
 
 namespace ngp {
 
@@ -690,6 +691,59 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Density-grid refresh: generate_grid_samples_nerf_nonuniform + NerfNetwork::density +
+// splat_grid_samples_nerf_max_nearest_neighbor in one kernel (src/testbed_nerf.cu:185-232, 2812-2852). A wave owns
+// 64 samples: every lane draws its sample (cell, position), then four 16-sample passes run the hash-grid encode and
+// the density head on MFMA exactly like the render kernel, and lanes 0..15 splat their pass's results.
+__global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const ModelParams M, uint32_t n_samples, Pcg32 rng, uint32_t step, uint32_t n_cascades,
+                                                                     float thresh, const float* __restrict__ grid_in, float* __restrict__ grid_tmp) {
+	__shared__ uint4 s_w[N_FRAGS * 64];
+	__shared__ LevelInfo s_lv[N_LEVELS];
+	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, c = lane & 15;
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	const bool valid = i < n_samples;
+	// 1 random number to select the level, 3 to select the position
+	rng.advance((uint64_t)i * 4u);
+	const uint32_t level = (uint32_t)(rng.next_float() * (float)n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) { // a grid cell that has density
+		idx = ((i + step * n_samples) * 56924617u + j * 19349663u + 96925573u) % NERF_GRID_N_CELLS;
+		idx += level * NERF_GRID_N_CELLS;
+		if (!valid || grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % NERF_GRID_N_CELLS;
+	const float x = (float)morton3D_invert(pos_idx >> 0), y = (float)morton3D_invert(pos_idx >> 1), z = (float)morton3D_invert(pos_idx >> 2);
+	const float rx = rng.next_float(), ry = rng.next_float(), rz = rng.next_float();
+	const float scale = __builtin_ldexpf(1.0f, (int)level);
+	f3 pos = mk3(((x + rx) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f, ((y + ry) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f,
+	             ((z + rz) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f);
+	f3 w = div3(sub3(pos, mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2])), mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2])); // warp_position
+	for (int p = 0; p < 4; ++p) {
+		const int src = 16 * p + c;
+		const float sx = __shfl(w.x, src, 64), sy = __shfl(w.y, src, 64), sz = __shfl(w.z, src, 64);
+		const uint32_t s_idx = (uint32_t)__shfl((int)idx, src, 64);
+		const int s_valid = __shfl(valid ? 1 : 0, src, 64);
+		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, lane >> 4, sx, sy, sz);
+		half_t logit = density_pass(s_w, lane, enc);
+		if (lane < 16 && s_valid) {
+			// optical thickness of the smallest step (level 0, :218); positive floats order like their bit patterns
+			float thickness = network_to_density((float)logit, M.density_act) * stepsize();
+			atomicMax((unsigned int*)&grid_tmp[s_idx], __float_as_uint(thickness));
+		}
+	}
+}
+// ema_grid_samples_nerf (:253-276): a decayed maximum, cells marked negative stay
+__global__ void density_grid_ema_kernel(uint32_t n_elements, float decay, float* __restrict__ grid, const float* __restrict__ grid_tmp) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	float prev = grid[i];
+	grid[i] = prev < 0.f ? prev : fmaxf(prev * decay, grid_tmp[i]);
+}
+
 __global__ void init_rays_kernel(const ModelParams M, const CameraParams C, NerfPayload* __restrict__ payloads) {
 	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x;
 	uint32_t y = threadIdx.y + blockDim.y * blockIdx.y;
@@ -862,6 +916,13 @@ void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, ui
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream) {
 	uint32_t n_waves = (n + 63) / 64;
 	hipLaunchKernelGGL(network_inference_kernel, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+}
+void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
+                                float* grid_tmp, hipStream_t stream) {
+	if (n_samples) hipLaunchKernelGGL(density_grid_samples_kernel, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, grid_tmp);
+}
+void launch_density_grid_ema(uint32_t n_elements, float decay, float* grid, const float* grid_tmp, hipStream_t stream) {
+	hipLaunchKernelGGL(density_grid_ema_kernel, dim3((n_elements + 255) / 256), dim3(256), 0, stream, n_elements, decay, grid, grid_tmp);
 }
 void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream) {
 	dim3 threads(16, 8, 1);

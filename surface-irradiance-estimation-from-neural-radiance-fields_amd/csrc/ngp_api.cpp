@@ -253,6 +253,8 @@ void free_model(ngp_ctx* ctx) {
 	if (ctx->d_density_f16) (void)hipFree(ctx->d_density_f16);
 	if (ctx->d_density_f32) (void)hipFree(ctx->d_density_f32);
 	if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+	if (ctx->d_density_tmp) (void)hipFree(ctx->d_density_tmp);
+	ctx->d_density_tmp = nullptr;
 	ctx->d_params = nullptr;
 	ctx->d_wfrags = nullptr;
 	ctx->d_bitfield = nullptr;
@@ -295,6 +297,16 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	ctx->desc.density_grid_fp16 = nullptr;
 	ctx->max_cascade = max_cascade;
 	ctx->have_desc = true;
+	{ // reset_network: m_rng = default_rng_t{m_seed}; density_grid_rng = default_rng_t{m_rng.next_uint()} (testbed.cu:3848-3861, m_seed = 1337)
+		Pcg32 rng;
+		rng.seed(1337u);
+		Pcg32 grid_rng;
+		grid_rng.seed(rng.next_uint());
+		ctx->grid_rng_state = grid_rng.state;
+		ctx->grid_rng_inc = grid_rng.inc;
+		ctx->grid_ema_step = 0;
+		ctx->grid_updates = 0;
+	}
 	if (ctx->device < 0) return; // host-only context: the model is parsed and validated, nothing can be rendered
 
 	// grid table
@@ -1271,6 +1283,59 @@ int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (out) NGP_HIP_CHECK(hipMemcpy(out, ctx->d_bitfield, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, hipMemcpyDeviceToHost));
 		if (out_mean) *out_mean = ctx->bitfield_mean;
+	});
+}
+
+int ngp_update_density_grid(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		const uint32_t n_cascades = ctx->max_cascade + 1;
+		const uint32_t n_elements = NERF_GRID_N_CELLS * n_cascades;
+		hipStream_t stream = ctx->stream;
+		if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream)); // frames in flight read the bitfield
+		if (!ctx->d_density_tmp) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_tmp, (size_t)n_elements * sizeof(float)));
+		Pcg32 rng;
+		rng.state = ctx->grid_rng_state;
+		rng.inc = ctx->grid_rng_inc;
+		for (uint32_t it = 0; it < n_iterations; ++it) {
+			uint32_t nu = n_uniform, nn = n_nonuniform;
+			if (nu == 0 && nn == 0) { // training_prep_nerf's schedule (src/testbed_nerf.cu:3441-3445)
+				if (ctx->grid_updates < 256) nu = NERF_GRID_N_CELLS * n_cascades;
+				else nu = nn = NERF_GRID_N_CELLS / 4 * n_cascades;
+			}
+			NGP_HIP_CHECK(hipMemsetAsync(ctx->d_density_tmp, 0, (size_t)n_elements * sizeof(float), stream));
+			launch_density_grid_update(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, stream);
+			rng.advance();
+			launch_density_grid_update(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f /* NERF_MIN_OPTICAL_THICKNESS */, ctx->d_density_f32, ctx->d_density_tmp, stream);
+			rng.advance();
+			launch_density_grid_ema(n_elements, decay, ctx->d_density_f32, ctx->d_density_tmp, stream);
+			++ctx->grid_ema_step;
+			++ctx->grid_updates;
+		}
+		ctx->grid_rng_state = rng.state;
+		ctx->grid_rng_inc = rng.inc;
+		// update_density_grid_mean_and_bitfield (:2863-2880) + the block summaries the march reads
+		launch_density_grid_to_bitfield(nullptr, 0, ctx->max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield, &ctx->bitfield_mean, stream);
+		launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, stream);
+		// keep the snapshot copy (fp16, as the reference serialises it) in step
+		std::vector<float> grid(n_elements);
+		NGP_HIP_CHECK(hipMemcpyAsync(grid.data(), ctx->d_density_f32, (size_t)n_elements * sizeof(float), hipMemcpyDeviceToHost, stream));
+		NGP_HIP_CHECK(hipStreamSynchronize(stream));
+		NGP_HIP_CHECK(hipGetLastError());
+		ctx->density_grid.resize(n_elements);
+		for (uint32_t i = 0; i < n_elements; ++i) ctx->density_grid[i] = float_to_half(grid[i]);
+		ctx->desc.n_density_grid = n_elements;
+	});
+}
+
+int ngp_get_density_grid(ngp_ctx* ctx, float* out, uint64_t n) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		const uint64_t n_elements = (uint64_t)NERF_GRID_N_CELLS * (ctx->max_cascade + 1);
+		if (!out || n != n_elements) throw std::runtime_error("density grid holds " + std::to_string(n_elements) + " values");
+		NGP_HIP_CHECK(hipMemcpy(out, ctx->d_density_f32, n_elements * sizeof(float), hipMemcpyDeviceToHost));
 	});
 }
 

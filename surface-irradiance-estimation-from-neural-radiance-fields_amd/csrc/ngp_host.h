@@ -4,6 +4,7 @@
 #include "../../include/ngp_hip.h"
 #include "minijson.h"
 #include "ngp_kernels.h"
+#include "pcg32.h"
 
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,9 @@ namespace ngp {
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream);
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream);
+void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
+                                float* grid_tmp, hipStream_t stream);
+void launch_density_grid_ema(uint32_t n_elements, float decay, float* grid, const float* grid_tmp, hipStream_t stream);
 void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream);
 void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_grid, uint32_t max_cascade, float* d_grid_f32, double* d_partial,
                                      uint8_t* d_bitfield, float* out_mean, hipStream_t stream);
@@ -92,6 +96,9 @@ struct ngp_ctx {
 	uint4* d_wfrags = nullptr;
 	uint8_t* d_bitfield = nullptr;
 	uint32_t* d_coarse = nullptr;
+	float* d_density_tmp = nullptr; // density_grid_tmp of update_density_grid_nerf
+	uint64_t grid_rng_state = 0, grid_rng_inc = 0; // m_nerf.training.density_grid_rng
+	uint32_t grid_ema_step = 0, grid_updates = 0;
 	uint16_t* d_density_f16 = nullptr;
 	float* d_density_f32 = nullptr;
 	double* d_partial = nullptr;

@@ -99,6 +99,10 @@ public:
 		(void)include_optimizer_state; // inference state only
 		check(ngp_save_snapshot_file(m_ctx, path.c_str(), compress ? 1 : 0));
 	}
+	// src/testbed_nerf.cu:2772 (the stream argument is the context's); n = 0 / 0 selects training_prep_nerf's schedule
+	void update_density_grid_nerf(float decay, uint32_t n_uniform_density_grid_samples, uint32_t n_nonuniform_density_grid_samples) {
+		check(ngp_update_density_grid(m_ctx, decay, n_uniform_density_grid_samples, n_nonuniform_density_grid_samples, 1));
+	}
 	void load_file(const std::string& path) { // src/testbed.cu:319-395
 		auto ends = [&](const char* e) { size_t n = strlen(e); return path.size() >= n && strcasecmp(path.c_str() + path.size() - n, e) == 0; };
 		if (ends(".ingp") || ends(".msgpack")) { load_snapshot(path); return; }

@@ -107,6 +107,8 @@ def load_library():
     L.ngp_load_snapshot_file.argtypes = [vp, C.c_char_p]
     L.ngp_save_snapshot_file.argtypes = [vp, C.c_char_p, ip]
     L.ngp_get_model.argtypes = [vp, C.POINTER(ModelDesc)]
+    L.ngp_update_density_grid.argtypes = [vp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.ngp_get_density_grid.argtypes = [vp, vp, C.c_uint64]
     L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
     L.ngp_n_training_views.argtypes = [vp]
@@ -381,6 +383,15 @@ class Context:
         mean = C.c_float(0)
         self._check(self.L.ngp_get_density_bitfield(self.h, _p(bf), C.addressof(mean)))
         return bf, mean.value
+
+    def update_density_grid(self, decay=0.95, n_uniform=0, n_nonuniform=0, n_iterations=1):
+        """Testbed::update_density_grid_nerf: refresh the occupancy grid from the density network (0/0 = training_prep_nerf's schedule)."""
+        self._check(self.L.ngp_update_density_grid(self.h, decay, n_uniform, n_nonuniform, n_iterations))
+
+    def density_grid(self, max_cascade):
+        out = np.zeros(128 ** 3 * (max_cascade + 1), np.float32)
+        self._check(self.L.ngp_get_density_grid(self.h, _p(out), out.size))
+        return out
 
     def init_rays(self, cam):
         pl = np.zeros(cam.width * cam.height, PAYLOAD_DTYPE)

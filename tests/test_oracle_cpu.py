@@ -269,3 +269,40 @@ def test_post_pass(oracle):
     back = np.array([[oracle.lib.orc_srgb_to_linear(float(v)) for v in row[:3]] for row in srgb])
     assert np.allclose(back, lin[:, :3], rtol=2e-3, atol=1e-4)  # the reference's 0.41666 exponent is not the exact inverse
     assert np.allclose(lin[:, :3], acc[:, :3] * 2.0)
+
+
+def test_pcg32_known_answers(oracle):
+    """pcg32 (the reference's default_rng_t) restated in the oracle: the published generator's first outputs for the demo
+    seeding pcg32(42, 54) -- the known-answer vector of the PCG reference implementation -- and skip-ahead == stepping."""
+    import ctypes as C
+
+    L = oracle.lib
+    L.orc_pcg32_next_uint.restype = C.c_uint32
+    r = (C.c_uint64 * 2)()
+    L.orc_pcg32_seed(r, C.c_uint64(42), C.c_uint64(54))
+    got = [L.orc_pcg32_next_uint(r) for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    a = (C.c_uint64 * 2)()
+    b = (C.c_uint64 * 2)()
+    L.orc_pcg32_seed(a, C.c_uint64(1337), C.c_uint64(1))
+    L.orc_pcg32_seed(b, C.c_uint64(1337), C.c_uint64(1))
+    for _ in range(1000):
+        L.orc_pcg32_next_uint(a)
+    L.orc_pcg32_advance(b, C.c_uint64(1000))
+    assert (a[0], a[1]) == (b[0], b[1])
+
+
+def test_density_grid_refresh_oracle(oracle, scene_unit):
+    """update_density_grid_nerf on the oracle: cells the synthetic occupancy marks empty but where the network is dense
+    get switched on, touched cells hold MIN_CONE_STEPSIZE * exp(logit) > 0, untouched cells only decay."""
+    m = oracle.make_model(scene_unit)
+    grid0 = np.asarray(scene_unit["density_grid"], np.float16).astype(np.float32)
+    rng = oracle.grid_rng()
+    g1, step = oracle.update_density_grid(m, grid0, scene_unit["max_cascade"], rng, 0, 0.95, 50000, 20000)
+    oracle.release(m)
+    assert step == 1
+    touched = g1 != np.float32(0.95) * grid0
+    assert 30000 < touched.sum() <= 70000
+    assert np.all(g1 >= np.float32(0.95) * grid0 - 1e-6) and np.all(g1[touched] > 0)
+    # the non-uniform half only lands in cells that were above the optical-thickness threshold
+    assert np.isfinite(g1).all()

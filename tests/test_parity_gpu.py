@@ -317,3 +317,46 @@ def test_frames_on_two_streams_overlap_safely(gpu_ctx, native, scene_mod, scene_
     for i in range(n):
         assert np.array_equal(outs[i][0].cpu().numpy(), serial[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), serial[i][1])
         assert hist[i]["n_samples"] > 0 and hist[i]["n_rays"] == ((w + 7) // 8) * ((h + 7) // 8) * 64
+
+
+def test_density_grid_refresh_parity(native, oracle, scene_mod, scene_unit):
+    """ngp_update_density_grid vs the oracle's update_density_grid_nerf: the same cells are sampled (pcg32 stream, cell
+    hash and positions are bit-exact), their optical thickness agrees to the fp16 network tolerance, and the rebuilt
+    bitfield differs only where a cell sits on the threshold. Rendering afterwards still matches the oracle."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    mc = scene_unit["max_cascade"]
+    grid0 = ctx.density_grid(mc)
+    assert np.array_equal(grid0, np.asarray(scene_unit["density_grid"], np.float16).astype(np.float32))
+    ctx.update_density_grid(0.95, 60000, 30000, 2)
+    got = ctx.density_grid(mc)
+    m = oracle.make_model(scene_unit)
+    rng = oracle.grid_rng()
+    ref, step = oracle.update_density_grid(m, grid0, mc, rng, 0, 0.95, 60000, 30000)
+    ref, step = oracle.update_density_grid(m, ref, mc, rng, step, 0.95, 60000, 30000)
+    decayed = np.float32(0.95) * (np.float32(0.95) * grid0)
+    assert np.array_equal(got != decayed, ref != decayed)  # exactly the same cells were touched
+    touched = ref != decayed
+    assert touched.sum() > 50000
+    rel = np.abs(got[touched] - ref[touched]) / np.maximum(ref[touched], 1e-12)
+    assert np.median(rel) < 2e-3 and (rel < 5e-2).mean() > 0.999  # exp(logit): one fp16 ulp of the logit is 0.1 %..1.6 %
+    bf, mean = ctx.density_bitfield()
+    obf, omean = oracle.density_grid_to_bitfield(ref, mc)
+    assert abs(mean - omean) <= 2e-3 * omean
+    assert np.unpackbits(bf ^ obf).sum() <= 1e-4 * 128 ** 3
+    # the refreshed grid renders like the oracle with the oracle's refreshed grid
+    sc = dict(scene_unit)
+    sc["density_grid_bitfield"] = obf
+    m2 = oracle.make_model(sc)
+    w, h = 128, 72
+    cam, ocam = _cam_pair(native, oracle, scene_mod, w, h, az=100.0)
+    img = ctx.render(cam)
+    fb, _, _ = oracle.render_nerf(m2, ocam)
+    refimg = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    oracle.release(m)
+    oracle.release(m2)
+    assert_image_close(img, refimg, 45.0, tol=2e-2)
+    # schedule form (0, 0): the first 256 updates sample 128^3 cells per cascade uniformly
+    ctx.update_density_grid(0.95, 0, 0, 1)
+    assert np.isfinite(ctx.density_grid(mc)).all()
+    ctx.close()
