@@ -29,7 +29,12 @@ enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, 
 /* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
 enum ngp_render_mode {
 	NGP_RENDER_SHADE = 0,
-	NGP_RENDER_SHADE_ENVMAP = 1 /* ERenderMode::ShadeEnvMap: meshes lit by the NeRF-derived irradiance probe (ngp_compute_envmap) */
+	NGP_RENDER_SHADE_ENVMAP = 1, /* ERenderMode::ShadeEnvMap: meshes lit by the NeRF-derived irradiance probe (ngp_compute_envmap) */
+	/* G-buffer modes of composite_kernel_nerf (src/testbed_nerf.cu:689-702): the per-sample colour is replaced, the compositing is unchanged,
+	 * and shade_kernel_nerf skips the sRGB -> linear conversion (:1393). NeRF mode only. */
+	NGP_RENDER_AO = 2,        /* rgb = alpha of the sample */
+	NGP_RENDER_POSITIONS = 3, /* rgb = (pos - 0.5) / 2 + 0.5 */
+	NGP_RENDER_DEPTH = 4      /* rgb = dot(cam_fwd, pos - ray origin) * depth_scale */
 };
 
 /* ETestbedMode subset (common.h:35-43): Nerf, and the fork's Geometry mode (meshes + NeRF, depth composited) */
@@ -91,6 +96,7 @@ typedef struct ngp_render_opts {
 	 * slot (x&7) + 8*(y&7); buffers hold 64 * ngp_packed_tiles(...) pixels. This is the layout the per-frame RCCL
 	 * all_gather moves, so no pack pass is needed on the sending side. */
 	int32_t packed_output;
+	float depth_scale;        /* NGP_RENDER_DEPTH: 1 / dataset scale in the reference (src/testbed_nerf.cu:2478); 0 selects 1 / 0.33 (NERF_SCALE) */
 } ngp_render_opts;
 
 /* BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir (testbed.h:875-876) used by shade_kernel_mesh_geometry */

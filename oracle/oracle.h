@@ -67,6 +67,8 @@ typedef struct orc_render_opts {
 	int32_t depth_test;           /* 1: shade_kernel_nerf_geometry depth test against depth_buffer */
 	int32_t capped_skip;          /* 1: the 200-iteration skip of nerf_device.cuh:497-534 (trace_mesh) */
 	int32_t n_threads;            /* OpenMP threads, <=0: all */
+	int32_t render_mode;          /* 0/1 Shade; 2 AO, 3 Positions, 4 Depth (composite_kernel_nerf, testbed_nerf.cu:689-702) */
+	float depth_scale;            /* Depth mode: 1 / dataset scale */
 } orc_render_opts;
 
 typedef struct orc_render_stats {

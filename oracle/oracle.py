@@ -73,6 +73,8 @@ class RenderOpts(C.Structure):
         ("depth_test", C.c_int32),
         ("capped_skip", C.c_int32),
         ("n_threads", C.c_int32),
+        ("render_mode", C.c_int32),
+        ("depth_scale", C.c_float),
     ]
 
 
@@ -273,13 +275,15 @@ class Oracle:
         return cam
 
     @staticmethod
-    def make_opts(min_transmittance=0.01, linear_colors=False, depth_test=False, capped_skip=False, n_threads=0):
+    def make_opts(min_transmittance=0.01, linear_colors=False, depth_test=False, capped_skip=False, n_threads=0, render_mode=0, depth_scale=1.0 / 0.33):
         o = RenderOpts()
         o.min_transmittance = min_transmittance
         o.train_in_linear_colors = int(linear_colors)
         o.depth_test = int(depth_test)
         o.capped_skip = int(capped_skip)
         o.n_threads = n_threads
+        o.render_mode = render_mode
+        o.depth_scale = depth_scale
         return o
 
     def init_rays(self, m, cam, advance=True):

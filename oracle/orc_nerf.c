@@ -621,6 +621,13 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 		float r = network_to_rgb(orc_half_to_float(out4[0]), m->rgb_activation);
 		float g = network_to_rgb(orc_half_to_float(out4[1]), m->rgb_activation);
 		float b = network_to_rgb(orc_half_to_float(out4[2]), m->rgb_activation);
+		if (o->render_mode == 2) { /* ERenderMode::AO, testbed_nerf.cu:700-702 */
+			r = g = b = alpha;
+		} else if (o->render_mode == 3) { /* Positions :694-695 */
+			r = (pos.x - 0.5f) / 2.0f + 0.5f; g = (pos.y - 0.5f) / 2.0f + 0.5f; b = (pos.z - 0.5f) / 2.0f + 0.5f;
+		} else if (o->render_mode == 4) { /* Depth :698-699 */
+			r = g = b = v3_dot(cam_fwd, v3_sub(pos, origin)) * o->depth_scale;
+		}
 		lr += r * weight; lg += g * weight; lb += b * weight; la += weight;
 		if (weight > payload->max_weight) {
 			payload->max_weight = weight;
@@ -644,7 +651,7 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 static void shade_one(const orc_render_opts* o, const float* rgba, float depth, uint32_t idx, float* frame_buffer, float* depth_buffer) {
 	if (o->depth_test && depth > depth_buffer[idx]) return;
 	float tmp[4] = {rgba[0], rgba[1], rgba[2], rgba[3]};
-	if (!o->train_in_linear_colors) {
+	if (!o->train_in_linear_colors && o->render_mode <= 1) { /* only ERenderMode::Shade converts, :1393 */
 		tmp[0] = orc_srgb_to_linear(tmp[0]);
 		tmp[1] = orc_srgb_to_linear(tmp[1]);
 		tmp[2] = orc_srgb_to_linear(tmp[2]);

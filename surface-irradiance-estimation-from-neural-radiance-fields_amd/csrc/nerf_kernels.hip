@@ -58,7 +58,7 @@ NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear,
 	if (!(acc.a > 0.001f)) return false;
 	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
-	if (!F.linear_colors) {
+	if (!F.linear_colors && (PROBE || F.render_mode <= 1)) { // only ERenderMode::Shade accumulates in linear colours (:1393)
 		r = srgb_to_linear(r);
 		g = srgb_to_linear(g);
 		b = srgb_to_linear(b);
@@ -292,7 +292,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 		}
 
-		const int max_links = PROBE ? 0 : (exhausted ? F.tune[5] : F.tune[4]) < MAX_CHAIN - 1 ? (exhausted ? F.tune[5] : F.tune[4]) : MAX_CHAIN - 1;
+		const int want_links = (PROBE || F.render_mode > 1) ? 0 : (exhausted ? F.tune[5] : F.tune[4]); // (the G-buffer modes composite per-sample positions: no chains)
+		const int max_links = want_links < MAX_CHAIN - 1 ? want_links : MAX_CHAIN - 1;
 		if (!PROBE && max_links > 0) {
 			// ---- spawn continuations: the k-th free slot continues the k-th chain tail (a ready sample nobody continues yet)
 			const bool tail = ray.alive && ready && chain_next < 0 && crole < max_links;
@@ -478,14 +479,24 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
 		// one sample (network outputs, warped dt, depth of the sample along the camera axis) onto this lane's ray
-		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth) {
+		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth, f3 spos) {
 			float T = 1.0f - acc.a;
 			float dt = unwarp_dt(swdt);
 			float alpha = 1.0f - fast_exp(-network_to_density((float)ss, M.density_act) * dt);
 			float weight = alpha * T;
-			acc.r += network_to_rgb((float)sr, M.rgb_act) * weight;
-			acc.g += network_to_rgb((float)sg, M.rgb_act) * weight;
-			acc.b += network_to_rgb((float)sb, M.rgb_act) * weight;
+			float cr = network_to_rgb((float)sr, M.rgb_act), cg = network_to_rgb((float)sg, M.rgb_act), cb = network_to_rgb((float)sb, M.rgb_act);
+			if (!PROBE && F.render_mode > 1) { // src/testbed_nerf.cu:689-702
+				if (F.render_mode == 2) {
+					cr = cg = cb = alpha;
+				} else if (F.render_mode == 3) {
+					cr = (spos.x - 0.5f) / 2.0f + 0.5f; cg = (spos.y - 0.5f) / 2.0f + 0.5f; cb = (spos.z - 0.5f) / 2.0f + 0.5f;
+				} else {
+					cr = cg = cb = dot3(cam_fwd, sub3(spos, ray.o)) * F.depth_scale;
+				}
+			}
+			acc.r += cr * weight;
+			acc.g += cg * weight;
+			acc.b += cb * weight;
 			acc.a += weight;
 			if (weight > acc.max_weight) {
 				acc.max_weight = weight;
@@ -505,7 +516,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			ready = false;
 			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
 			my_depth = dot3(cam_fwd, sub3(pos, cam_pos));
-			if (crole == 0) composite(o_r, o_g, o_b, o_s, wdt, my_depth);
+			if (crole == 0) composite(o_r, o_g, o_b, o_s, wdt, my_depth, pos);
 		}
 		n_samples += (uint32_t)__popcll(__ballot(run && crole == 0));
 		if (!PROBE && __any(chain_next >= 0)) {
@@ -526,7 +537,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				const int l_next = __shfl(chain_next, src, 64);
 				n_samples += (uint32_t)__popcll(__ballot(cur >= 0 && l_ok != 0));
 				if (cur >= 0 && l_ok) {
-					composite(llo.h[0], llo.h[1], lhi.h[0], lhi.h[1], l_wdt, l_depth);
+					composite(llo.h[0], llo.h[1], lhi.h[0], lhi.h[1], l_wdt, l_depth, mk3(0.f, 0.f, 0.f));
 					ray.t = l_t;
 					cur = ray.alive ? l_next : -1;
 				} else {

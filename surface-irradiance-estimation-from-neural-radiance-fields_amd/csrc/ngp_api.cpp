@@ -824,7 +824,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
-	if (opts.render_mode != NGP_RENDER_SHADE && opts.render_mode != NGP_RENDER_SHADE_ENVMAP) throw std::runtime_error("only render modes Shade and ShadeEnvMap are implemented");
+	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_DEPTH) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, AO, Positions, Depth");
+	if (opts.render_mode > NGP_RENDER_SHADE_ENVMAP && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth) apply to NeRF mode");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
@@ -873,6 +874,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	// (a rank's share in image layout keeps the general path: the other ranks' pixels must read as an empty frame)
 	F.direct = (spp == 1 && !have_meshes && !geometry && (shard_count == 1 || opts.packed_output)) ? 1 : 0;
 	F.to_srgb = opts.to_srgb;
+	F.render_mode = opts.render_mode;
+	F.depth_scale = opts.depth_scale != 0.f ? opts.depth_scale : 1.0f / 0.33f;
 	memcpy(F.background, opts.background, sizeof(F.background));
 	F.exposure_scale = powf(2.0f, opts.exposure);
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));

@@ -158,7 +158,8 @@ public:
 	void render_to_cpu(float* out, int width, int height, int spp, bool linear, float start_time = -1.f, float end_time = -1.f, float fps = 30.f, float shutter_fraction = 1.0f, float* depth_out = nullptr) {
 		(void)fps; (void)shutter_fraction;
 		if (start_time >= 0.f || end_time >= 0.f) throw std::runtime_error("camera-path rendering (start_t/end_t) is not supported by the MI355X renderer");
-		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap) throw std::runtime_error("only render modes Shade and ShadeEnvMap are supported (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
+		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth;
+		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, AO, Positions, Depth (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
 		ngp_camera cam{};
 		memcpy(cam.matrix, m_camera.data(), sizeof(cam.matrix));
 		cam.width = width;
@@ -172,7 +173,8 @@ public:
 		cam.snap_to_pixel_centers = m_snap_to_pixel_centers ? 1 : 0;
 		cam.near_distance = m_render_near_distance;
 		ngp_render_opts o{};
-		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : NGP_RENDER_SHADE;
+		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
+		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : NGP_RENDER_SHADE;
 		o.min_transmittance = nerf.render_min_transmittance;
 		memcpy(o.background, m_background_color.data(), sizeof(o.background));
 		o.exposure = m_exposure;

@@ -51,7 +51,7 @@ class Camera(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [
         ("render_mode", C.c_int32), ("min_transmittance", C.c_float), ("background", C.c_float * 4), ("exposure", C.c_float),
-        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32), ("packed_output", C.c_int32),
+        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32), ("packed_output", C.c_int32), ("depth_scale", C.c_float),
     ]
 
 
@@ -70,7 +70,7 @@ class ProbeDesc(C.Structure):
 
 
 MODE_NERF, MODE_GEOMETRY = 0, 1
-RENDER_SHADE, RENDER_SHADE_ENVMAP = 0, 1
+RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH = 0, 1, 2, 3, 4
 PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
@@ -161,7 +161,7 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
 
 
 def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1,
-              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE, packed_output=False):
+              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE, packed_output=False, depth_scale=0.0):
     o = RenderOpts()
     o.render_mode = render_mode
     o.min_transmittance = min_transmittance
@@ -173,6 +173,7 @@ def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=
     o.shard_index, o.shard_count = shard_index, shard_count
     o.testbed_mode = testbed_mode
     o.packed_output = int(packed_output)
+    o.depth_scale = depth_scale
     return o
 
 

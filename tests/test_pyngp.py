@@ -95,5 +95,5 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     with pytest.raises(RuntimeError, match="does not exist"):
         testbed.load_training_data(str(tmp_path / "nope"))
     testbed.render_mode = pyngp.RenderMode.Normals
-    with pytest.raises(RuntimeError, match="only render modes"):
+    with pytest.raises(RuntimeError, match="render modes supported"):
         testbed.render(8, 8, 1, True)
