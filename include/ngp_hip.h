@@ -97,6 +97,8 @@ typedef struct ngp_render_opts {
 	 * all_gather moves, so no pack pass is needed on the sending side. */
 	int32_t packed_output;
 	float depth_scale;        /* NGP_RENDER_DEPTH: 1 / dataset scale in the reference (src/testbed_nerf.cu:2478); 0 selects 1 / 0.33 (NERF_SCALE) */
+	int32_t color_space;      /* EColorSpace in which samples are averaged and the background is blended: 0 Linear, 1 SRGB
+	                           * (accumulate_kernel / tonemap_kernel, src/render_buffer.cu:241-248, 324-340, 537-541; run.py --nerf_compatibility) */
 } ngp_render_opts;
 
 /* BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir (testbed.h:875-876) used by shade_kernel_mesh_geometry */
@@ -167,6 +169,8 @@ NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16
 NGP_API int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16);
 /* K8/K9 update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:2863-2880): the bitfield in use, 8 x 128^3 / 8 bytes */
 NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean);
+/* m_nerf.cone_angle_constant (python_api.cu: testbed.nerf.cone_angle_constant, run.py:167): 0 = fixed step size */
+NGP_API int ngp_set_cone_angle_constant(ngp_ctx* ctx, float cone_angle_constant);
 /* Testbed::update_density_grid_nerf (src/testbed_nerf.cu:2772-2861; kernels :185-232, :253-276): refresh the occupancy
  * grid from the density network -- n_uniform samples in random cells + n_nonuniform samples in cells above
  * NERF_MIN_OPTICAL_THICKNESS, density MLP, max-splat, decayed maximum into the grid -- n_iterations times, then the

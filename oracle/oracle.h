@@ -140,6 +140,10 @@ void orc_trace_payloads(const orc_nerf_model* m, const float* cam_matrix, const 
 /* P1: accumulate (linear colour space) + tonemap (identity curve) -> rgba_out (W*H*4) */
 void orc_accumulate(uint32_t n_pixels, const float* frame_buffer, float* accumulate_buffer, float sample_count);
 void orc_tonemap(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, float* rgba_out);
+/* the same with EColorSpace: 0 Linear (as above), 1 SRGB (samples averaged as sRGB values, src/render_buffer.cu:241-248, 324-340, 537-541) */
+void orc_accumulate_cs(uint32_t n_pixels, const float* frame_buffer, float* accumulate_buffer, float sample_count, int32_t color_space);
+void orc_tonemap_cs(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, int32_t color_space,
+                    float* rgba_out);
 
 float orc_srgb_to_linear(float v);
 float orc_linear_to_srgb(float v);

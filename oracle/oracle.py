@@ -316,17 +316,17 @@ class Oracle:
         self.lib.orc_trace_payloads(C.byref(m), _ptr(cm), C.byref(opts), n, _ptr(payloads), _ptr(rgba), _ptr(depth), C.byref(st))
         return rgba, depth, {k: getattr(st, k) for k, _ in RenderStats._fields_}
 
-    def accumulate(self, frame_buffer, accumulate_buffer, sample_count):
+    def accumulate(self, frame_buffer, accumulate_buffer, sample_count, color_space=0):
         fb = np.ascontiguousarray(frame_buffer, np.float32)
         acc = np.ascontiguousarray(accumulate_buffer, np.float32).copy()
-        self.lib.orc_accumulate(fb.size // 4, _ptr(fb), _ptr(acc), float(sample_count))
+        self.lib.orc_accumulate_cs(fb.size // 4, _ptr(fb), _ptr(acc), C.c_float(sample_count), int(color_space))
         return acc
 
-    def tonemap(self, accumulate_buffer, background=(0, 0, 0, 1), exposure=0.0, to_srgb=False):
+    def tonemap(self, accumulate_buffer, background=(0, 0, 0, 1), exposure=0.0, to_srgb=False, color_space=0):
         acc = np.ascontiguousarray(accumulate_buffer, np.float32)
         bg = np.asarray(background, np.float32)
         out = np.zeros_like(acc)
-        self.lib.orc_tonemap(acc.size // 4, _ptr(acc), _ptr(bg), float(exposure), int(to_srgb), _ptr(out))
+        self.lib.orc_tonemap_cs(acc.size // 4, _ptr(acc), _ptr(bg), C.c_float(exposure), int(to_srgb), int(color_space), _ptr(out))
         return out
 
     # ------------------------------------------------------------------ mesh (orc_mesh.c)

@@ -724,6 +724,36 @@ void orc_accumulate(uint32_t n_pixels, const float* frame_buffer, float* accumul
 	}
 }
 
+/* accumulate_kernel / tonemap_kernel with EColorSpace::SRGB (src/render_buffer.cu:241-248, 537-541, 324-340): samples are
+ * averaged as sRGB values, the background stays sRGB, the result is linearised before exposure. color_space 0 = Linear. */
+void orc_accumulate_cs(uint32_t n_pixels, const float* frame_buffer, float* accumulate_buffer, float sample_count, int32_t color_space) {
+	for (size_t i = 0; i < (size_t)n_pixels; ++i) {
+		for (int k = 0; k < 4; ++k) {
+			float c = frame_buffer[4 * i + k];
+			if (color_space == 1 && k < 3) c = orc_linear_to_srgb(c);
+			accumulate_buffer[4 * i + k] = (accumulate_buffer[4 * i + k] * sample_count + c) / (sample_count + 1.0f);
+		}
+	}
+}
+void orc_tonemap_cs(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, int32_t color_space,
+                    float* rgba_out) {
+	float bg[4] = {background_rgba[0], background_rgba[1], background_rgba[2], background_rgba[3]};
+	if (color_space != 1) for (int k = 0; k < 3; ++k) bg[k] = orc_srgb_to_linear(bg[k]);
+	float scale = powf(2.0f, exposure);
+	for (size_t i = 0; i < (size_t)n_pixels; ++i) {
+		float c[4] = {accumulate_buffer[4 * i], accumulate_buffer[4 * i + 1], accumulate_buffer[4 * i + 2], accumulate_buffer[4 * i + 3]};
+		float weight = (1.0f - c[3]) * bg[3];
+		for (int k = 0; k < 3; ++k) c[k] += bg[k] * weight;
+		c[3] += weight;
+		for (int k = 0; k < 3; ++k) {
+			if (color_space == 1) c[k] = orc_srgb_to_linear(c[k]);
+			c[k] *= scale;
+			if (to_srgb) c[k] = orc_linear_to_srgb(c[k]);
+		}
+		for (int k = 0; k < 4; ++k) rgba_out[4 * i + k] = c[k];
+	}
+}
+
 void orc_tonemap(uint32_t n_pixels, const float* accumulate_buffer, const float* background_rgba, float exposure, int32_t to_srgb, float* rgba_out) {
 	/* colour space is Linear, so the sRGB background colour is linearised first */
 	float bg[4] = {orc_srgb_to_linear(background_rgba[0]), orc_srgb_to_linear(background_rgba[1]), orc_srgb_to_linear(background_rgba[2]), background_rgba[3]};

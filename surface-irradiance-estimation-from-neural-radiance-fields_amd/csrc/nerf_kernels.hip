@@ -36,12 +36,22 @@ struct Accum {
 // accumulate_kernel with sample_count 0 (the mean of one sample is the sample) + tonemap_kernel, colour space Linear,
 // tonemap curve Identity: background blend, exposure, optional sRGB (src/render_buffer.cu:228-262, 529-561)
 NGP_DEV float4 tonemap_pixel(const FrameParams& F, f3 bg_linear, float r, float g, float b, float a) {
+	if (F.color_space == 1) { // EColorSpace::SRGB: the sample is averaged as an sRGB value (:245)
+		r = linear_to_srgb(r);
+		g = linear_to_srgb(g);
+		b = linear_to_srgb(b);
+	}
 	float4 tmp = make_float4(r / 1.0f, g / 1.0f, b / 1.0f, a / 1.0f);
 	float weight = (1.0f - tmp.w) * F.background[3];
 	tmp.x += bg_linear.x * weight;
 	tmp.y += bg_linear.y * weight;
 	tmp.z += bg_linear.z * weight;
 	tmp.w += weight;
+	if (F.color_space == 1) { // back to linear before exposure (:326-328)
+		tmp.x = srgb_to_linear(tmp.x);
+		tmp.y = srgb_to_linear(tmp.y);
+		tmp.z = srgb_to_linear(tmp.z);
+	}
 	tmp.x *= F.exposure_scale;
 	tmp.y *= F.exposure_scale;
 	tmp.z *= F.exposure_scale;
@@ -170,7 +180,10 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const int c = lane & 15;
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
 	// direct output: the background's trip through the tonemap is the same for every pixel
-	const f3 bg_linear = (!PROBE && F.direct) ? mk3(srgb_to_linear(F.background[0]), srgb_to_linear(F.background[1]), srgb_to_linear(F.background[2])) : mk3(0.f, 0.f, 0.f);
+	// (the background colour is sRGB: linearised unless the frame is averaged in sRGB, src/render_buffer.cu:537-541)
+	const f3 bg_linear = (PROBE || !F.direct) ? mk3(0.f, 0.f, 0.f)
+	                     : F.color_space == 1 ? mk3(F.background[0], F.background[1], F.background[2])
+	                                          : mk3(srgb_to_linear(F.background[0]), srgb_to_linear(F.background[1]), srgb_to_linear(F.background[2]));
 	const float4 empty_pixel = (!PROBE && F.direct) ? tonemap_pixel(F, bg_linear, 0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
 	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
@@ -850,10 +863,15 @@ __global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __r
 // P1: accumulate_kernel + tonemap_kernel (src/render_buffer.cu:228-262, 529-561), fused: colour space Linear,
 // tonemap curve Identity, no DLSS. rgba_out may alias nothing else.
 __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __restrict__ frame_buffer, float4* __restrict__ accumulate_buffer,
-                                          float sample_count, float4 background, float exposure_scale, int to_srgb, float4* __restrict__ rgba_out) {
+                                          float sample_count, float4 background, float exposure_scale, int to_srgb, int color_space, float4* __restrict__ rgba_out) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_pixels) return;
 	float4 color = frame_buffer[i];
+	if (color_space == 1) { // EColorSpace::SRGB (:245)
+		color.x = linear_to_srgb(color.x);
+		color.y = linear_to_srgb(color.y);
+		color.z = linear_to_srgb(color.z);
+	}
 	float4 tmp = sample_count > 0.f ? accumulate_buffer[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 	tmp.x = (tmp.x * sample_count + color.x) / (sample_count + 1.0f);
 	tmp.y = (tmp.y * sample_count + color.y) / (sample_count + 1.0f);
@@ -861,12 +879,22 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 	tmp.w = (tmp.w * sample_count + color.w) / (sample_count + 1.0f);
 	accumulate_buffer[i] = tmp;
 	if (!rgba_out) return;
-	float bgr = srgb_to_linear(background.x), bgg = srgb_to_linear(background.y), bgb = srgb_to_linear(background.z);
+	float bgr = background.x, bgg = background.y, bgb = background.z;
+	if (color_space != 1) { // the background colour is sRGB (:537-541)
+		bgr = srgb_to_linear(bgr);
+		bgg = srgb_to_linear(bgg);
+		bgb = srgb_to_linear(bgb);
+	}
 	float weight = (1.0f - tmp.w) * background.w;
 	tmp.x += bgr * weight;
 	tmp.y += bgg * weight;
 	tmp.z += bgb * weight;
 	tmp.w += weight;
+	if (color_space == 1) { // :326-328
+		tmp.x = srgb_to_linear(tmp.x);
+		tmp.y = srgb_to_linear(tmp.y);
+		tmp.z = srgb_to_linear(tmp.z);
+	}
 	tmp.x *= exposure_scale;
 	tmp.y *= exposure_scale;
 	tmp.z *= exposure_scale;
@@ -965,10 +993,10 @@ void launch_coarse_occupancy(const uint8_t* bitfield, uint32_t* coarse, hipStrea
 	hipLaunchKernelGGL(coarse16_occupancy_kernel, dim3(1), dim3(128), 0, stream, coarse);
 }
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
-                               float exposure, int to_srgb, float4* rgba_out, hipStream_t stream) {
+                               float exposure, int to_srgb, int color_space, float4* rgba_out, hipStream_t stream) {
 	float4 bg = make_float4(background[0], background[1], background[2], background[3]);
 	hipLaunchKernelGGL(accumulate_tonemap_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, n_pixels, frame_buffer, accumulate_buffer, sample_count,
-	                   bg, powf(2.0f, exposure), to_srgb, rgba_out);
+	                   bg, powf(2.0f, exposure), to_srgb, color_space, rgba_out);
 }
 
 } // namespace ngp

@@ -875,6 +875,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.direct = (spp == 1 && !have_meshes && !geometry && (shard_count == 1 || opts.packed_output)) ? 1 : 0;
 	F.to_srgb = opts.to_srgb;
 	F.render_mode = opts.render_mode;
+	F.color_space = opts.color_space;
+	if (opts.color_space != 0 && opts.color_space != 1) throw std::runtime_error("color_space: 0 (Linear) or 1 (SRGB)");
 	F.depth_scale = opts.depth_scale != 0.f ? opts.depth_scale : 1.0f / 0.33f;
 	memcpy(F.background, opts.background, sizeof(F.background));
 	F.exposure_scale = powf(2.0f, opts.exposure);
@@ -912,7 +914,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
 		if (ctx->model_loaded) launch_render_nerf(M, C, F, ctx->n_cus, stream); // persistent grid sized by the launcher
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
-		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, last ? d_rgba_out : nullptr, stream);
+		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, opts.color_space, last ? d_rgba_out : nullptr, stream);
 	}
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame1[slot], stream));
 	NGP_HIP_CHECK(hipGetLastError());
@@ -1286,6 +1288,16 @@ int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 		if (out) NGP_HIP_CHECK(hipMemcpy(out, ctx->d_bitfield, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, hipMemcpyDeviceToHost));
 		if (out_mean) *out_mean = ctx->bitfield_mean;
+	});
+}
+
+int ngp_set_cone_angle_constant(ngp_ctx* ctx, float cone_angle_constant) {
+	return guarded(ctx, [&] {
+		if (!ctx->have_desc) throw std::runtime_error("No network available.");
+		if (!(cone_angle_constant >= 0.f)) throw std::runtime_error("cone_angle_constant must be >= 0");
+		if (ctx->last_stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+		ctx->desc.cone_angle_constant = cone_angle_constant;
+		ctx->M.cone_angle = cone_angle_constant;
 	});
 }
 

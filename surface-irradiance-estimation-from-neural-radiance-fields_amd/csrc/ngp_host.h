@@ -36,7 +36,7 @@ void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_gri
                                      uint8_t* d_bitfield, float* out_mean, hipStream_t stream);
 void launch_coarse_occupancy(const uint8_t* bitfield, uint32_t* coarse, hipStream_t stream);
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
-                               float exposure, int to_srgb, float4* rgba_out, hipStream_t stream);
+                               float exposure, int to_srgb, int color_space, float4* rgba_out, hipStream_t stream);
 
 void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, const IrradianceMap& I, const CameraParams& C, float4* frame_buffer, float* depth_buffer,
                         uint32_t shard_index, uint32_t shard_count, int packed, hipStream_t stream);

@@ -95,7 +95,7 @@ struct FrameParams {
 	// (src/render_buffer.cu:228-262, 529-561) folded into ray setup / shading -- into frame_buffer = the caller's image
 	int32_t render_mode;      // ngp_render_mode: 0/1 Shade, 2 AO, 3 Positions, 4 Depth (composite_kernel_nerf :689-702)
 	float depth_scale;
-	int32_t direct, to_srgb;
+	int32_t direct, to_srgb, color_space;
 	float background[4];
 	float exposure_scale;
 	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums

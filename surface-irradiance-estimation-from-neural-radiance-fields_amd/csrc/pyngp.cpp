@@ -34,6 +34,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.export_values();
 	// the reference registers the name "Shade" twice (python_api.cu:284-294), which pybind11 rejects at import;
 	// ShadeNerf keeps its own name here
+	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).value("VisPosNeg", EColorSpace::VisPosNeg).export_values();
 	py::enum_<ERenderMode>(m, "RenderMode")
 		.value("AO", ERenderMode::AO).value("Shade", ERenderMode::Shade).value("Normals", ERenderMode::Normals)
 		.value("Positions", ERenderMode::Positions).value("Depth", ERenderMode::Depth).value("Distortion", ERenderMode::Distortion)
@@ -56,10 +57,14 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("offset", &Testbed::NerfDatasetView::offset);
 	py::class_<Testbed::Nerf::Training>(testbed, "NerfTraining")
 		.def_readonly("dataset", &Testbed::Nerf::Training::dataset)
-		.def_readwrite("view", &Testbed::Nerf::Training::view);
+		.def_readwrite("view", &Testbed::Nerf::Training::view)
+		.def_readwrite("random_bg_color", &Testbed::Nerf::Training::random_bg_color)
+		.def_readwrite("near_distance", &Testbed::Nerf::Training::near_distance);
 	py::class_<Testbed::Nerf>(testbed, "Nerf")
 		.def_readwrite("render_min_transmittance", &Testbed::Nerf::render_min_transmittance)
-		.def_readonly("cone_angle_constant", &Testbed::Nerf::cone_angle_constant)
+		.def_readwrite("cone_angle_constant", &Testbed::Nerf::cone_angle_constant)
+		.def_readwrite("sharpen", &Testbed::Nerf::sharpen)
+		.def_readwrite("render_with_lens_distortion", &Testbed::Nerf::render_with_lens_distortion)
 		.def_readonly("training", &Testbed::Nerf::training);
 	py::class_<Testbed::BRDFParams>(testbed, "BRDFParams")
 		.def_readwrite("metallic", &Testbed::BRDFParams::metallic).def_readwrite("subsurface", &Testbed::BRDFParams::subsurface)
@@ -102,6 +107,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("snap_to_pixel_centers", &Testbed::m_snap_to_pixel_centers)
 		.def_readwrite("exposure", &Testbed::m_exposure)
 		.def_readwrite("render_mode", &Testbed::m_render_mode)
+		.def_readwrite("color_space", &Testbed::m_color_space)
+		.def_readwrite("render_ground_truth", &Testbed::m_render_ground_truth)
 		.def_readwrite("render_near_distance", &Testbed::m_render_near_distance)
 		.def_readwrite("sun_dir", &Testbed::m_sun_dir)
 		.def_readwrite("up_dir", &Testbed::m_up_dir)

@@ -17,6 +17,7 @@
 namespace ngp {
 
 enum class ETestbedMode : int { Nerf, Sdf, Image, Volume, Geometry, None }; // common.h:35-43
+enum class EColorSpace : int { Linear, SRGB, VisPosNeg }; // common.h
 enum class ERenderMode : int { AO, Shade, Normals, Positions, Depth, Distortion, Cost, Slice, ShadeNerf, ShadeEnvMap, ShadeGridEnvMap, EncodingVis }; // common.h:58-72
 
 class Testbed {
@@ -36,10 +37,14 @@ public:
 	};
 	struct Nerf {
 		float render_min_transmittance = 0.01f; // nerf.h:172
-		float cone_angle_constant = 0.f;
+		float cone_angle_constant = 0.f;        // written through set_cone_angle_constant (run.py:167)
+		float sharpen = 0.f;                    // training-image sharpening (nerf.h): accepted, no effect on inference
+		bool render_with_lens_distortion = false; // accepted; only perspective (undistorted) lenses are rendered
 		struct Training {
 			NerfDatasetView dataset;
 			int view = 0;
+			bool random_bg_color = true; // training-only settings run.py touches: accepted, no effect on inference
+			float near_distance = 0.1f;
 		} training;
 	} nerf;
 
@@ -184,6 +189,13 @@ public:
 		o.shard_count = 1;
 		o.testbed_mode = m_testbed_mode == ETestbedMode::Geometry ? NGP_MODE_GEOMETRY : NGP_MODE_NERF;
 		o.packed_output = 0;
+		if (m_color_space == EColorSpace::VisPosNeg) throw std::runtime_error("color space VisPosNeg is not supported");
+		o.color_space = m_color_space == EColorSpace::SRGB ? 1 : 0;
+		if (nerf.cone_angle_constant != m_pushed_cone_angle) {
+			check(ngp_set_cone_angle_constant(m_ctx, nerf.cone_angle_constant));
+			m_pushed_cone_angle = nerf.cone_angle_constant;
+		}
+		if (m_render_ground_truth) throw std::runtime_error("render_ground_truth shows the training images, which this build does not decode");
 		ngp_geometry_opts g{};
 		memcpy(g.sun_dir, m_sun_dir.data(), 12);
 		memcpy(g.up_dir, m_up_dir.data(), 12);
@@ -224,6 +236,9 @@ public:
 	float m_exposure = 0.f;
 	// The fork defaults to ShadeGridEnvMap, for which the reference has no kernel; every BASELINE run pins Shade.
 	ERenderMode m_render_mode = ERenderMode::Shade;
+	EColorSpace m_color_space = EColorSpace::Linear; // testbed.color_space (run.py:160)
+	bool m_render_ground_truth = false;
+	float m_pushed_cone_angle = 0.f; // what the context holds; testbed.nerf.cone_angle_constant is pushed at the next render
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.f;
 	bool m_train = false;
@@ -256,7 +271,7 @@ private:
 		if (ngp_get_model(m_ctx, &d) == 0) {
 			memcpy(m_aabb.data(), d.aabb_min, 12); memcpy(m_aabb.data() + 3, d.aabb_max, 12);
 			memcpy(m_render_aabb.data(), d.render_aabb_min, 12); memcpy(m_render_aabb.data() + 3, d.render_aabb_max, 12);
-			nerf.cone_angle_constant = d.cone_angle_constant;
+			nerf.cone_angle_constant = m_pushed_cone_angle = d.cone_angle_constant;
 		}
 		sync_dataset();
 	}

@@ -51,7 +51,7 @@ class Camera(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [
         ("render_mode", C.c_int32), ("min_transmittance", C.c_float), ("background", C.c_float * 4), ("exposure", C.c_float),
-        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32), ("packed_output", C.c_int32), ("depth_scale", C.c_float),
+        ("to_srgb", C.c_int32), ("spp", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("testbed_mode", C.c_int32), ("packed_output", C.c_int32), ("depth_scale", C.c_float), ("color_space", C.c_int32),
     ]
 
 
@@ -109,6 +109,7 @@ def load_library():
     L.ngp_get_model.argtypes = [vp, C.POINTER(ModelDesc)]
     L.ngp_update_density_grid.argtypes = [vp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
     L.ngp_get_density_grid.argtypes = [vp, vp, C.c_uint64]
+    L.ngp_set_cone_angle_constant.argtypes = [vp, C.c_float]
     L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
     L.ngp_n_training_views.argtypes = [vp]
@@ -161,7 +162,7 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
 
 
 def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, to_srgb=False, spp=1, shard_index=0, shard_count=1,
-              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE, packed_output=False, depth_scale=0.0):
+              testbed_mode=MODE_NERF, render_mode=RENDER_SHADE, packed_output=False, depth_scale=0.0, color_space=0):
     o = RenderOpts()
     o.render_mode = render_mode
     o.min_transmittance = min_transmittance
@@ -174,6 +175,7 @@ def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=
     o.testbed_mode = testbed_mode
     o.packed_output = int(packed_output)
     o.depth_scale = depth_scale
+    o.color_space = color_space
     return o
 
 
@@ -384,6 +386,9 @@ class Context:
         mean = C.c_float(0)
         self._check(self.L.ngp_get_density_bitfield(self.h, _p(bf), C.addressof(mean)))
         return bf, mean.value
+
+    def set_cone_angle_constant(self, value):
+        self._check(self.L.ngp_set_cone_angle_constant(self.h, value))
 
     def update_density_grid(self, decay=0.95, n_uniform=0, n_nonuniform=0, n_iterations=1):
         """Testbed::update_density_grid_nerf: refresh the occupancy grid from the density network (0/0 = training_prep_nerf's schedule)."""

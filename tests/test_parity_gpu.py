@@ -384,3 +384,48 @@ def test_gbuffer_render_modes(mode, gpu_ctx, oracle, native, scene_mod, scene_un
         assert np.abs(img[..., 0] - img[..., 1]).max() < 1e-6 and np.abs(img[..., 0] - img[..., 2]).max() < 1e-6  # grey
     with pytest.raises(RuntimeError, match="NeRF mode"):
         gpu_ctx.render(cam, native.make_opts(render_mode=rm, testbed_mode=native.MODE_GEOMETRY))
+
+
+@pytest.mark.parametrize("spp", [1, 3])
+def test_srgb_color_space_accumulation(spp, gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """EColorSpace::SRGB (run.py --nerf_compatibility): samples are averaged as sRGB values and blended with the sRGB
+    background, then linearised (src/render_buffer.cu:241-248, 324-340, 537-541). spp 1 takes the direct-output path."""
+    w, h = 96, 54
+    gpu_ctx.set_model(scene_unit)
+    gpu_ctx.clear_meshes()
+    m = oracle.make_model(scene_unit)
+    mat = scene_mod.orbit_camera(250.0)
+    focal = scene_mod.focal_from_fov_x(w, 0.6911)
+    bg = (0.25, 0.5, 0.75, 1.0)
+    img = gpu_ctx.render(native.make_camera(mat, w, h, focal, snap=False), native.make_opts(spp=spp, color_space=1, background=bg, exposure=0.3))
+    lin = gpu_ctx.render(native.make_camera(mat, w, h, focal, snap=False), native.make_opts(spp=spp, color_space=0, background=bg, exposure=0.3))
+    acc = np.zeros((w * h, 4), np.float32)
+    for s in range(spp):
+        fb, _, _ = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal, spp_index=s, snap=False))
+        acc = oracle.accumulate(fb.reshape(-1, 4), acc, s, color_space=1)
+    ref = oracle.tonemap(acc, bg, 0.3, False, color_space=1).reshape(h, w, 4)
+    oracle.release(m)
+    assert_image_close(img, ref, 48.0, tol=2e-2)
+    assert np.abs(img - lin).max() > 1e-2  # blending with the background in sRGB is visibly different from linear
+
+
+def test_cone_angle_override(native, oracle, scene_mod, scene_big):
+    """testbed.nerf.cone_angle_constant = 0 (run.py:167): the fox-shaped model marched with the fixed step."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_big)
+    w, h = 128, 72
+    cam, ocam = _cam_pair(native, oracle, scene_mod, w, h, az=120.0)
+    before = ctx.render(cam)
+    ctx.set_cone_angle_constant(0.0)
+    img = ctx.render(cam)
+    st = ctx.render_stats()
+    sc = dict(scene_big)
+    sc["cone_angle_constant"] = 0.0
+    m = oracle.make_model(sc)
+    fb, _, ost = oracle.render_nerf(m, ocam)
+    oracle.release(m)
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    assert abs(int(st["n_samples"]) - int(ost["n_samples"])) <= 1e-3 * ost["n_samples"]
+    assert_image_close(img, ref, 48.0, tol=2e-2)
+    assert st["n_samples"] > 0 and np.abs(img - before).max() > 1e-3
+    ctx.close()

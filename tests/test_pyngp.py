@@ -94,6 +94,27 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     assert np.array_equal(t2.render(160, 90, 1, True), image2)
     with pytest.raises(RuntimeError, match="does not exist"):
         testbed.load_training_data(str(tmp_path / "nope"))
+    # the attributes scripts/run.py:133-170 pokes before rendering exist and are writable
+    assert testbed.mode == pyngp.TestbedMode.Nerf
+    testbed.nerf.sharpen = 0.0
+    testbed.nerf.render_with_lens_distortion = True
+    testbed.nerf.training.random_bg_color = False
+    testbed.nerf.training.near_distance = 0.2
+    lin = testbed.render(64, 36, 1, True)
+    testbed.color_space = pyngp.ColorSpace.SRGB
+    testbed.background_color = [0.3, 0.3, 0.3, 1.0]
+    srgb_frame = testbed.render(64, 36, 1, True)
+    testbed.color_space = pyngp.ColorSpace.Linear
+    lin_bg = testbed.render(64, 36, 1, True)
+    assert np.abs(srgb_frame - lin_bg).max() > 1e-3 and lin.shape == srgb_frame.shape
+    testbed.nerf.cone_angle_constant = 1.0 / 256.0
+    coned = testbed.render(64, 36, 1, True)
+    testbed.nerf.cone_angle_constant = 0.0
+    assert np.abs(coned - lin_bg).max() > 1e-4 and np.array_equal(testbed.render(64, 36, 1, True), lin_bg)
+    testbed.render_ground_truth = True
+    with pytest.raises(RuntimeError, match="training images"):
+        testbed.render(8, 8, 1, True)
+    testbed.render_ground_truth = False
     testbed.render_mode = pyngp.RenderMode.Normals
     with pytest.raises(RuntimeError, match="render modes supported"):
         testbed.render(8, 8, 1, True)
