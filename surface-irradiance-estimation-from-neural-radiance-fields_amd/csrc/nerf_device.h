@@ -212,6 +212,27 @@ NGP_DEV float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f
 	t_target = to_stepping_space(t_target, cone_angle);
 	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
 }
+// A render box larger than the occupancy grid (geometry mode: the inflated scene box, load_scene) puts marching rays
+// outside the outermost cascade, where the reference steps one virtual cell at a time through space that cannot
+// hold a sample. Distance along the ray from `pos` (outside the cube [0.5 - h, 0.5 + h]^3) to that cube; < 0: the ray
+// misses it. Every cell on the way is empty, so one step to the entry lands on the same lattice point.
+NGP_DEV float grid_cube_entry(f3 pos, f3 idir, float h) {
+	const float lo = 0.5f - h, hi = 0.5f + h;
+	float tx0 = (lo - pos.x) * idir.x, tx1 = (hi - pos.x) * idir.x;
+	float ty0 = (lo - pos.y) * idir.y, ty1 = (hi - pos.y) * idir.y;
+	float tz0 = (lo - pos.z) * idir.z, tz1 = (hi - pos.z) * idir.z;
+	float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+	float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+	tmin = fmaxf(tmin, 0.0f);
+	return tmax >= tmin ? tmin : -1.0f;
+}
+// the whole-step rounding of advance_to_next_voxel for a given distance to the target
+NGP_DEV float advance_by_distance(float t, float cone_angle, float distance) {
+	float t_target = t + distance;
+	t = to_stepping_space(t, cone_angle);
+	t_target = to_stepping_space(t_target, cone_angle);
+	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+}
 NGP_DEV uint32_t mip_from_pos(f3 pos, uint32_t max_cascade) {
 	int exponent;
 	float maxval = fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f));

@@ -161,7 +161,8 @@ NGP_DEV unsigned long long stamp() {
 // UNIT: unit-cube scenes (aabb_scale 1 => one cascade, cone angle 0 => fixed step sqrt(3)/1024; load_nerf_post,
 // src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
 // exponential-stepping branches; the arithmetic that remains is the same expression for expression.
-template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES)>
+// OUTSIDE: the render box may reach beyond the occupancy grid (geometry mode, a hand-set render box)
+template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
@@ -391,7 +392,18 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 							empty = e;
 						}
 						if (PROF) p_skip[empty == 16u ? 2 : (empty == 4u ? 1 : 0)] += 1ull;
-						ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
+						const float grid_half = 0.5f * (float)(1u << max_cascade);
+						const bool outside = OUTSIDE && !PROBE && empty == 1u && mip == max_cascade &&
+						                     fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f)) > grid_half;
+						const float to_grid = outside ? grid_cube_entry(pos, idir, grid_half) : 0.0f;
+						if (outside && to_grid < 0.0f) { // the ray never reaches the occupancy grid: it would leave the render box without a sample
+							ray.alive = false;
+							finished = crole == 0;
+						} else if (outside && to_grid > 0.0f) {
+							ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
+						} else {
+							ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
+						}
 						++skip_i;
 					}
 				}
@@ -602,10 +614,11 @@ __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelPa
 	ProbeParams P{};
 	fused_body<false, false, true>(M, C, F, P);
 }
-// scenes of up to 5 cascades (aabb_scale <= 16: fox, garden): 20 KB of occupancy summaries instead of 32 leave room for a third workgroup per CU
+// scenes of up to 5 cascades (aabb_scale <= 16: fox, garden) rendered inside their occupancy grid: 20 KB of occupancy summaries instead of 32
+// leave room for a third workgroup per CU
 __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	fused_body<false, false, false, 5>(M, C, F, P);
+	fused_body<false, false, false, 5, false>(M, C, F, P);
 }
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
@@ -918,7 +931,7 @@ static int resident_blocks_per_cu(K kernel) {
 }
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
 	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
-	const bool c5 = !unit && M.max_cascade < 5;
+	const bool c5 = !unit && M.max_cascade < 5 && !F.outside_possible;
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
 	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5);
 	int per_cu = F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic;

@@ -880,6 +880,12 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.depth_scale = opts.depth_scale != 0.f ? opts.depth_scale : 1.0f / 0.33f;
 	memcpy(F.background, opts.background, sizeof(F.background));
 	F.exposure_scale = powf(2.0f, opts.exposure);
+	{ // a render box inside the outermost cascade's cube never puts a ray outside the occupancy grid (kernel selection)
+		const float h = 0.5f * (float)(1u << M.max_cascade);
+		bool inside = M.r2l_identity != 0;
+		for (int i = 0; i < 3; ++i) inside = inside && M.raabb_min[i] >= 0.5f - h && M.raabb_max[i] <= 0.5f + h;
+		F.outside_possible = inside ? 0 : 1;
+	}
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 	NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
 	if (F.direct) {

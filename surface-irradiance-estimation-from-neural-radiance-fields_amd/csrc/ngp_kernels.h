@@ -93,6 +93,7 @@ struct FrameParams {
 	int32_t tune[6];          // refill_min, skip_steps, go_min, max_stall, chain links while tiles remain / once the queue is empty (nerf_kernels.hip)
 	// direct output (1 spp, no mesh pass): the kernel writes the final pixel -- accumulate_kernel + tonemap_kernel
 	// (src/render_buffer.cu:228-262, 529-561) folded into ray setup / shading -- into frame_buffer = the caller's image
+	int32_t outside_possible; // the render box is not contained in the outermost cascade's cube (kernel selection)
 	int32_t render_mode;      // ngp_render_mode: 0/1 Shade, 2 AO, 3 Positions, 4 Depth (composite_kernel_nerf :689-702)
 	float depth_scale;
 	int32_t direct, to_srgb, color_space;
