@@ -27,6 +27,9 @@ typedef struct ngp_ctx ngp_ctx;
 enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
 
 /* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
+/* ELensMode, common.h:223-230 (FTheta is not implemented) */
+enum ngp_lens_mode { NGP_LENS_PERSPECTIVE = 0, NGP_LENS_OPENCV = 1, NGP_LENS_FTHETA = 2, NGP_LENS_LATLONG = 3, NGP_LENS_OPENCV_FISHEYE = 4, NGP_LENS_EQUIRECTANGULAR = 5 };
+
 enum ngp_render_mode {
 	NGP_RENDER_SHADE = 0,
 	NGP_RENDER_SHADE_ENVMAP = 1, /* ERenderMode::ShadeEnvMap: meshes lit by the NeRF-derived irradiance probe (ngp_compute_envmap) */
@@ -79,6 +82,10 @@ typedef struct ngp_camera {
 	uint32_t spp_index;     /* render_buffer.spp() */
 	int32_t snap_to_pixel_centers;
 	float near_distance;    /* m_render_near_distance */
+	/* m_nerf.render_lens when m_nerf.render_with_lens_distortion (uv_to_ray, common_device.cuh:416-483): ngp_lens_mode +
+	 * parameters (OpenCV: k1 k2 p1 p2; OpenCVFisheye: k1 k2 k3 k4). All zero = perspective. */
+	int32_t lens_mode;
+	float lens_params[7];
 } ngp_camera;
 
 typedef struct ngp_render_opts {
@@ -143,6 +150,8 @@ NGP_API int ngp_load_training_data(ngp_ctx* ctx, const char* path);
 NGP_API int ngp_n_training_views(const ngp_ctx* ctx);
 /* per-view: ngp-space camera matrix (nerf_matrix_to_ngp applied), resolution, focal length (pixels), principal point */
 NGP_API int ngp_get_training_view(const ngp_ctx* ctx, int view, float* matrix12, int32_t* resolution2, float* focal_length2, float* principal_point2);
+/* the view's lens (read_lens, src/nerf_loader.cu:175-240): ngp_lens_mode and 7 parameters */
+NGP_API int ngp_get_training_view_lens(const ngp_ctx* ctx, int view, int32_t* lens_mode, float* lens_params7);
 NGP_API int ngp_get_dataset_info(const ngp_ctx* ctx, int32_t* aabb_scale, float* scale, float* offset3, int32_t* is_hdr);
 
 /* --- render: Testbed::render_frame (src/testbed.cu:4694-4721) = clear + render_nerf (src/testbed_nerf.cu:2328-2488)

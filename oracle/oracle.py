@@ -63,6 +63,8 @@ class Camera(C.Structure):
         ("spp_index", C.c_uint32),
         ("snap_to_pixel_centers", C.c_int32),
         ("near_distance", C.c_float),
+        ("lens_mode", C.c_int32),
+        ("lens_params", C.c_float * 7),
     ]
 
 
@@ -258,7 +260,7 @@ class Oracle:
         return out
 
     @staticmethod
-    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0):
+    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=()):
         """matrix_4x3: numpy (3,4) [R|t] camera-to-world in NGP convention."""
         cam = Camera()
         mat = np.asarray(matrix_4x3, np.float32)
@@ -272,6 +274,9 @@ class Oracle:
         cam.spp_index = spp_index
         cam.snap_to_pixel_centers = 1 if snap else 0
         cam.near_distance = near
+        cam.lens_mode = lens_mode
+        for i, q in enumerate(lens_params):
+            cam.lens_params[i] = q
         return cam
 
     @staticmethod

@@ -351,8 +351,9 @@ void orc_render_mesh(const orc_mesh_scene* s, const orc_camera* cam, const orc_m
 		/* M1: init_rays_with_payload_kernel_mesh_geometry (:488-579) */
 		float u = ((float)x + off[0]) / (float)cam->width;
 		float v = ((float)y + off[1]) / (float)cam->height;
-		v3 dir = v3_make((u - cam->screen_center[0]) * (float)cam->width / cam->focal_length[0],
-		                 (v - cam->screen_center[1]) * (float)cam->height / cam->focal_length[1], 1.0f);
+		float d3[3];
+		orc_lens_direction(cam, u, v, d3);
+		v3 dir = v3_make(d3[0], d3[1], d3[2]);
 		dir = m3_mulv(cam->matrix, dir);
 		v3 origin = v3_add(cam_pos, v3_scale(dir, cam->near_distance));
 		depth_buffer[i] = ORC_MAX_DEPTH;

@@ -503,6 +503,78 @@ static float if_unoccupied_advance_to_next_occupied_voxel(float t, float cone_an
  * Restated for: no foveation, no hidden-area mask, Perspective lens, no distortion map, zero parallax
  * shift, zero aperture, plane_z >= 0, render mode Shade, no env map, static camera (camera0 == camera1,
  * so the per-pixel camera_slerp of get_xform_given_rolling_shutter is the identity up to rounding). */
+/* lenses of uv_to_ray, common_device.cuh:249-338 (OpenCV / fisheye distortion, Newton undistortion), :375-391 (lat-long,
+ * equirectangular), :441-462 */
+static void opencv_delta(const float* q, float u, float v, float* du, float* dv) {
+	const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	*du = u * radial + 2.0f * p1 * uv + p2 * (r2 + 2.0f * u2);
+	*dv = v * radial + 2.0f * p2 * uv + p1 * (r2 + 2.0f * v2);
+}
+static void fisheye_delta(const float* q, float u, float v, float* du, float* dv) {
+	const float k1 = q[0], k2 = q[1], k3 = q[2], k4 = q[3];
+	const float r = sqrtf(u * u + v * v);
+	if (r > (float)2.220446049250313e-16) {
+		const float theta = atanf(r);
+		const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+		const float thetad = theta * (1.0f + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+		*du = u * thetad / r - u;
+		*dv = v * thetad / r - v;
+	} else {
+		*du = 0.0f;
+		*dv = 0.0f;
+	}
+}
+static v3 lens_direction(const orc_camera* cam, float u, float v);
+static void lens_undistort(int fisheye, const float* q, float* u, float* v) {
+	void (*delta)(const float*, float, float, float*, float*) = fisheye ? fisheye_delta : opencv_delta;
+	const float x0 = *u, y0 = *v;
+	float x = x0, y = y0;
+	for (uint32_t i = 0; i < 100u; ++i) {
+		const float step0 = fmaxf(1.1920929e-07f, fabsf(1e-6f * x));
+		const float step1 = fmaxf(1.1920929e-07f, fabsf(1e-6f * y));
+		float dx0, dx1, b0, b1, f0, f1, c0, c1, g0, g1;
+		delta(q, x, y, &dx0, &dx1);
+		delta(q, x - step0, y, &b0, &b1);
+		delta(q, x + step0, y, &f0, &f1);
+		delta(q, x, y - step1, &c0, &c1);
+		delta(q, x, y + step1, &g0, &g1);
+		const float j00 = 1.0f + (f0 - b0) / (2.0f * step0), j10 = (g0 - c0) / (2.0f * step1);
+		const float j01 = (f1 - b1) / (2.0f * step0), j11 = 1.0f + (g1 - c1) / (2.0f * step1);
+		const float rx = x + dx0 - x0, ry = y + dx1 - y0;
+		const float det = j00 * j11 - j10 * j01;
+		const float sx = (j11 * rx - j10 * ry) / det, sy = (-j01 * rx + j00 * ry) / det;
+		x -= sx;
+		y -= sy;
+		if (sx * sx + sy * sy < 1e-10f) break;
+	}
+	*u = x;
+	*v = y;
+}
+void orc_lens_direction(const orc_camera* cam, float u, float v, float* dir3) {
+	v3 d = lens_direction(cam, u, v);
+	dir3[0] = d.x; dir3[1] = d.y; dir3[2] = d.z;
+}
+static v3 lens_direction(const orc_camera* cam, float u, float v) {
+	const float PI = 3.14159265358979323846f;
+	if (cam->lens_mode == 3) {
+		float theta = (v - 0.5f) * PI, phi = (u - 0.5f) * PI * 2.0f;
+		return v3_make(sinf(phi) * cosf(theta), sinf(theta), cosf(phi) * cosf(theta));
+	}
+	if (cam->lens_mode == 5) {
+		float ct = (v - 0.5f) * 2.0f;
+		float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+		float phi = (u - 0.5f) * PI * 2.0f;
+		return v3_make(sinf(phi) * st, ct, cosf(phi) * st);
+	}
+	v3 dir = v3_make((u - cam->screen_center[0]) * (float)cam->width / cam->focal_length[0],
+	                 (v - cam->screen_center[1]) * (float)cam->height / cam->focal_length[1], 1.0f);
+	if (cam->lens_mode == 1) lens_undistort(0, cam->lens_params, &dir.x, &dir.y);
+	else if (cam->lens_mode == 4) lens_undistort(1, cam->lens_params, &dir.x, &dir.y);
+	return dir;
+}
+
 void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload) {
 	const prepared_t* p = (const prepared_t*)m->prepared;
 	uint32_t idx = x + (uint32_t)cam->width * y;
@@ -510,8 +582,7 @@ void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, ui
 	orc_ld_random_pixel_offset(cam->snap_to_pixel_centers ? 0u : cam->spp_index, off);
 	float u = ((float)x + off[0]) / (float)cam->width;
 	float v = ((float)y + off[1]) / (float)cam->height;
-	v3 dir = v3_make((u - cam->screen_center[0]) * (float)cam->width / cam->focal_length[0],
-	                 (v - cam->screen_center[1]) * (float)cam->height / cam->focal_length[1], 1.0f);
+	v3 dir = lens_direction(cam, u, v);
 	dir = m3_mulv(cam->matrix, dir);
 	v3 origin = v3_make(cam->matrix[9], cam->matrix[10], cam->matrix[11]);
 	origin = v3_add(origin, v3_scale(dir, cam->near_distance));

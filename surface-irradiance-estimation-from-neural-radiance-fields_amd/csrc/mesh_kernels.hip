@@ -184,7 +184,8 @@ __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams
 	// M1: init_rays_with_payload_kernel_mesh_geometry (:488-579)
 	float u = ((float)x + C.pixel_offset[0]) / (float)C.width;
 	float v = ((float)y + C.pixel_offset[1]) / (float)C.height;
-	f3 dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
+	f3 dir;
+	lens_direction(C, u, v, dir);
 	dir = m3_mulv(C.m, dir);
 	f3 origin = add3(cam_pos, scale3(dir, C.near_distance));
 	depth_buffer[idx] = MAX_DEPTH;

@@ -297,12 +297,89 @@ struct RayState {
 	bool alive;
 };
 
+// ---- lenses of uv_to_ray (common_device.cuh:249-338, 375-391, 441-462)
+NGP_DEV void opencv_lens_distortion_delta(const float* q, float u, float v, float* du, float* dv) {
+	const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	*du = u * radial + 2.0f * p1 * uv + p2 * (r2 + 2.0f * u2);
+	*dv = v * radial + 2.0f * p2 * uv + p1 * (r2 + 2.0f * v2);
+}
+NGP_DEV void opencv_fisheye_lens_distortion_delta(const float* q, float u, float v, float* du, float* dv) {
+	const float k1 = q[0], k2 = q[1], k3 = q[2], k4 = q[3];
+	const float r = __builtin_sqrtf(u * u + v * v);
+	if (r > (float)2.220446049250313e-16) {
+		const float theta = atanf(r);
+		const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+		const float thetad = theta * (1.0f + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+		*du = u * thetad / r - u;
+		*dv = v * thetad / r - v;
+	} else {
+		*du = 0.0f;
+		*dv = 0.0f;
+	}
+}
+// iterative_lens_undistortion: Newton iteration with central differences, at most 100 steps
+template <bool FISHEYE>
+NGP_DEV void iterative_lens_undistortion(const float* q, float* u, float* v) {
+	auto delta = [&](float a, float b, float* da, float* db) {
+		if (FISHEYE) opencv_fisheye_lens_distortion_delta(q, a, b, da, db);
+		else opencv_lens_distortion_delta(q, a, b, da, db);
+	};
+	const float x0 = *u, y0 = *v;
+	float x = x0, y = y0;
+	for (uint32_t i = 0; i < 100u; ++i) {
+		const float step0 = fmaxf(1.1920929e-07f, __builtin_fabsf(1e-6f * x));
+		const float step1 = fmaxf(1.1920929e-07f, __builtin_fabsf(1e-6f * y));
+		float dx0, dx1, b0, b1, f0, f1, c0, c1, g0, g1;
+		delta(x, y, &dx0, &dx1);
+		delta(x - step0, y, &b0, &b1);
+		delta(x + step0, y, &f0, &f1);
+		delta(x, y - step1, &c0, &c1);
+		delta(x, y + step1, &g0, &g1);
+		// J is column-major in the reference: J[col][row]
+		const float j00 = 1.0f + (f0 - b0) / (2.0f * step0), j10 = (g0 - c0) / (2.0f * step1);
+		const float j01 = (f1 - b1) / (2.0f * step0), j11 = 1.0f + (g1 - c1) / (2.0f * step1);
+		const float rx = x + dx0 - x0, ry = y + dx1 - y0;
+		// inverse(J) * r with J = [[j00, j10], [j01, j11]] (row, col)
+		const float det = j00 * j11 - j10 * j01;
+		const float sx = (j11 * rx - j10 * ry) / det, sy = (-j01 * rx + j00 * ry) / det;
+		x -= sx;
+		y -= sy;
+		if (sx * sx + sy * sy < 1e-10f) break;
+	}
+	*u = x;
+	*v = y;
+}
+// the camera-space direction of uv under the frame's lens; false: no ray for this pixel
+NGP_DEV bool lens_direction(const CameraParams& C, float u, float v, f3& dir) {
+	const float PI = 3.14159265358979323846f;
+	if (C.lens_mode == 3) { // LatLong
+		float theta = (v - 0.5f) * PI, phi = (u - 0.5f) * PI * 2.0f;
+		float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+		dir = mk3(sp * ct, st, cp * ct);
+		return true;
+	}
+	if (C.lens_mode == 5) { // Equirectangular
+		float ct = (v - 0.5f) * 2.0f;
+		float st = __builtin_sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+		float phi = (u - 0.5f) * PI * 2.0f;
+		dir = mk3(sinf(phi) * st, ct, cosf(phi) * st);
+		return true;
+	}
+	dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
+	if (C.lens_mode == 1) iterative_lens_undistortion<false>(C.lens_params, &dir.x, &dir.y);
+	else if (C.lens_mode == 4) iterative_lens_undistortion<true>(C.lens_params, &dir.x, &dir.y);
+	return true;
+}
+
 NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
 	r.idx = x + (uint32_t)C.width * y;
 	r.out = r.idx;
 	float u = ((float)x + C.pixel_offset[0]) / (float)C.width;
 	float v = ((float)y + C.pixel_offset[1]) / (float)C.height;
-	f3 dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
+	f3 dir;
+	lens_direction(C, u, v, dir);
 	dir = m3_mulv(C.m, dir);
 	f3 origin = mk3(C.m[9], C.m[10], C.m[11]);
 	origin = add3(origin, scale3(dir, C.near_distance));

@@ -408,6 +408,49 @@ mj::Value write_mat(const float* m, int n_cols, int n_rows) {
 	return a;
 }
 
+// Lens <-> json, json_binding.h:37-93
+void lens_from_json(const mj::Value& j, TrainingView& v) {
+	auto num = [&](const char* k) { return (float)j.at(k).num(); };
+	if (j.contains("k1")) {
+		if (j.value("is_fisheye", false)) {
+			v.lens_mode = NGP_LENS_OPENCV_FISHEYE;
+			v.lens_params[0] = num("k1"); v.lens_params[1] = num("k2"); v.lens_params[2] = num("k3"); v.lens_params[3] = num("k4");
+		} else {
+			v.lens_mode = NGP_LENS_OPENCV;
+			v.lens_params[0] = num("k1"); v.lens_params[1] = num("k2"); v.lens_params[2] = num("p1"); v.lens_params[3] = num("p2");
+		}
+	} else if (j.contains("ftheta_p0")) {
+		v.lens_mode = NGP_LENS_FTHETA;
+		const char* keys[7] = {"ftheta_p0", "ftheta_p1", "ftheta_p2", "ftheta_p3", "ftheta_p4", "w", "h"};
+		for (int i = 0; i < 7; ++i) v.lens_params[i] = num(keys[i]);
+	} else if (j.contains("latlong")) {
+		v.lens_mode = NGP_LENS_LATLONG;
+	} else if (j.contains("equirectangular")) {
+		v.lens_mode = NGP_LENS_EQUIRECTANGULAR;
+	} else {
+		v.lens_mode = NGP_LENS_PERSPECTIVE;
+	}
+}
+mj::Value lens_to_json(const TrainingView& v) {
+	mj::Value j = mj::Value::make_object();
+	auto put = [&](const char* k, float x) { j[k] = mj::Value::make_float(x); };
+	if (v.lens_mode == NGP_LENS_OPENCV) {
+		j["is_fisheye"] = mj::Value::make_bool(false);
+		put("k1", v.lens_params[0]); put("k2", v.lens_params[1]); put("p1", v.lens_params[2]); put("p2", v.lens_params[3]);
+	} else if (v.lens_mode == NGP_LENS_OPENCV_FISHEYE) {
+		j["is_fisheye"] = mj::Value::make_bool(true);
+		put("k1", v.lens_params[0]); put("k2", v.lens_params[1]); put("k3", v.lens_params[2]); put("k4", v.lens_params[3]);
+	} else if (v.lens_mode == NGP_LENS_FTHETA) {
+		const char* keys[7] = {"ftheta_p0", "ftheta_p1", "ftheta_p2", "ftheta_p3", "ftheta_p4", "w", "h"};
+		for (int i = 0; i < 7; ++i) put(keys[i], v.lens_params[i]);
+	} else if (v.lens_mode == NGP_LENS_LATLONG) {
+		j["latlong"] = mj::Value::make_bool(true);
+	} else if (v.lens_mode == NGP_LENS_EQUIRECTANGULAR) {
+		j["equirectangular"] = mj::Value::make_bool(true);
+	}
+	return j;
+}
+
 void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-183
 	size_t n = (size_t)j.at("n_images").integer();
 	ds.views.assign(n, TrainingView{});
@@ -428,6 +471,7 @@ void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-
 			v.resolution[1] = (int)r[1];
 			read_vec(ji.at("focal_length"), v.focal_length, 2);
 			read_vec(ji.at("principal_point"), v.principal_point, 2);
+			if (ji.contains("lens")) lens_from_json(ji.at("lens"), v);
 		}
 		if (j.contains("paths") && i < j.at("paths").size()) v.path = j.at("paths").at(i).str();
 	}
@@ -453,7 +497,7 @@ mj::Value dataset_to_json(const Dataset& ds) { // json_binding.h:94-119
 		paths.push(mj::Value::make_string(v.path));
 		mj::Value m = mj::Value::make_object();
 		m["focal_length"] = write_vec(v.focal_length, 2);
-		m["lens"] = mj::Value::make_object();
+		m["lens"] = lens_to_json(v);
 		m["principal_point"] = write_vec(v.principal_point, 2);
 		float rs[4] = {0, 0, 0, 0};
 		m["rolling_shutter"] = write_vec(rs, 4);
@@ -755,8 +799,35 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			if (j.contains("cy")) pp[1] = (float)j.at("cy").num() / (float)j.at("h").num();
 		};
 		read_pp(json, pp);
+		// read_lens (src/nerf_loader.cu:175-240): OpenCV parameters switch the mode on when one of them is non-zero; an
+		// outer (file-level) lens is kept unless the frame names its own
+		auto read_lens = [](const mj::Value& j, TrainingView& v) {
+			int mode = NGP_LENS_PERSPECTIVE;
+			const int opencv_mode = j.value("is_fisheye", false) ? NGP_LENS_OPENCV_FISHEYE : NGP_LENS_OPENCV;
+			auto rd = [&](const char* name, int idx) {
+				if (j.contains(name)) {
+					v.lens_params[idx] = (float)j.at(name).num();
+					if (v.lens_params[idx] != 0.f) mode = opencv_mode;
+				}
+			};
+			rd("k1", 0); rd("k2", 1); rd("k3", 2); rd("k4", 3);
+			rd("p1", 2); rd("p2", 3);
+			if (j.contains("ftheta_p0")) {
+				const char* keys[7] = {"ftheta_p0", "ftheta_p1", "ftheta_p2", "ftheta_p3", "ftheta_p4", "w", "h"};
+				for (int i = 0; i < 7; ++i) v.lens_params[i] = (float)j.at(keys[i]).num();
+				mode = NGP_LENS_FTHETA;
+			}
+			if (j.contains("latlong")) mode = NGP_LENS_LATLONG;
+			if (j.contains("equirectangular")) mode = NGP_LENS_EQUIRECTANGULAR;
+			if (mode != NGP_LENS_PERSPECTIVE) v.lens_mode = mode;
+		};
+		TrainingView file_lens;
+		read_lens(json, file_lens);
 		for (const mj::Value& frame : frames) {
 			TrainingView v;
+			v.lens_mode = file_lens.lens_mode;
+			memcpy(v.lens_params, file_lens.lens_params, sizeof(v.lens_params));
+			read_lens(frame, v);
 			v.path = frame.at("file_path").str();
 			std::replace(v.path.begin(), v.path.end(), '\\', '/');
 			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
@@ -815,6 +886,9 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 	C.screen_center[1] = cam.screen_center[1];
 	C.spp = spp_index;
 	C.near_distance = cam.near_distance;
+	if (cam.lens_mode == NGP_LENS_FTHETA || cam.lens_mode < 0 || cam.lens_mode > NGP_LENS_EQUIRECTANGULAR) throw std::runtime_error("lens mode not supported (Perspective, OpenCV, OpenCVFisheye, LatLong, Equirectangular are)");
+	C.lens_mode = cam.lens_mode;
+	memcpy(C.lens_params, cam.lens_params, sizeof(C.lens_params));
 	ld_random_pixel_offset(cam.snap_to_pixel_centers ? 0u : spp_index, C.pixel_offset);
 	return C;
 }
@@ -1151,6 +1225,14 @@ int ngp_load_training_data(ngp_ctx* ctx, const char* path) {
 		ctx->error = e.what();
 		return -1;
 	}
+}
+
+int ngp_get_training_view_lens(const ngp_ctx* ctx, int view, int32_t* lens_mode, float* lens_params7) {
+	if (!ctx || view < 0 || (size_t)view >= ctx->dataset.views.size()) return 1;
+	const TrainingView& v = ctx->dataset.views[(size_t)view];
+	if (lens_mode) *lens_mode = v.lens_mode;
+	if (lens_params7) memcpy(lens_params7, v.lens_params, sizeof(v.lens_params));
+	return 0;
 }
 
 int ngp_n_training_views(const ngp_ctx* ctx) { return ctx ? (int)ctx->dataset.views.size() : -1; }

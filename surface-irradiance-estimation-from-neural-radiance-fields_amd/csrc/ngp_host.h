@@ -60,6 +60,8 @@ struct TrainingView {
 	int32_t resolution[2];
 	float focal_length[2];
 	float principal_point[2];
+	int32_t lens_mode = 0; // ELensMode
+	float lens_params[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	std::string path;
 };
 struct Dataset {

@@ -76,6 +76,8 @@ struct CameraParams {
 	float pixel_offset[2]; // ld_random_pixel_offset(snap ? 0 : spp), per-frame constant
 	uint32_t spp;
 	float near_distance;
+	int32_t lens_mode; // ELensMode: 0 Perspective, 1 OpenCV, 3 LatLong, 4 OpenCVFisheye, 5 Equirectangular
+	float lens_params[7];
 };
 
 struct FrameParams {

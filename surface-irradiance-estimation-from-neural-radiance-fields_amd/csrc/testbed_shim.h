@@ -26,6 +26,8 @@ public:
 		std::array<int, 2> resolution;
 		std::array<float, 2> focal_length;
 		std::array<float, 2> principal_point;
+		int32_t lens_mode = 0;             // ELensMode
+		std::array<float, 7> lens_params{}; // Lens::params
 	};
 	struct NerfDatasetView { // testbed.nerf.training.dataset
 		size_t n_images = 0;
@@ -151,6 +153,9 @@ public:
 		const auto& md = ds.metadata[(size_t)trainview];
 		for (int i = 0; i < 2; ++i) m_relative_focal_length[i] = md.focal_length[i] / (float)md.resolution[m_fov_axis];
 		m_screen_center = {1.0f - md.principal_point[0], 1.0f - md.principal_point[1]};
+		nerf.render_with_lens_distortion = true; // src/testbed.cu:486-487
+		m_render_lens_mode = md.lens_mode;
+		m_render_lens_params = md.lens_params;
 		nerf.training.view = trainview;
 	}
 	float fov() const { return 2.0f * 180.0f / 3.14159265358979323846f * std::atan(1.0f / (m_relative_focal_length[m_fov_axis] * 2.0f)); }
@@ -177,6 +182,10 @@ public:
 		cam.spp_index = 0;
 		cam.snap_to_pixel_centers = m_snap_to_pixel_centers ? 1 : 0;
 		cam.near_distance = m_render_near_distance;
+		if (nerf.render_with_lens_distortion) { // m_nerf.render_lens, src/testbed_nerf.cu render_nerf
+			cam.lens_mode = m_render_lens_mode;
+			memcpy(cam.lens_params, m_render_lens_params.data(), sizeof(cam.lens_params));
+		}
 		ngp_render_opts o{};
 		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
 		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : NGP_RENDER_SHADE;
@@ -237,6 +246,8 @@ public:
 	// The fork defaults to ShadeGridEnvMap, for which the reference has no kernel; every BASELINE run pins Shade.
 	ERenderMode m_render_mode = ERenderMode::Shade;
 	EColorSpace m_color_space = EColorSpace::Linear; // testbed.color_space (run.py:160)
+	int32_t m_render_lens_mode = 0;                  // m_nerf.render_lens
+	std::array<float, 7> m_render_lens_params{};
 	bool m_render_ground_truth = false;
 	float m_pushed_cone_angle = 0.f; // what the context holds; testbed.nerf.cone_angle_constant is pushed at the next render
 	bool m_snap_to_pixel_centers = false;
@@ -260,6 +271,7 @@ private:
 		for (size_t i = 0; i < ds.n_images; ++i) {
 			int32_t res[2];
 			ngp_get_training_view(m_ctx, (int)i, ds.xforms[i].data(), res, ds.metadata[i].focal_length.data(), ds.metadata[i].principal_point.data());
+			ngp_get_training_view_lens(m_ctx, (int)i, &ds.metadata[i].lens_mode, ds.metadata[i].lens_params.data());
 			ds.metadata[i].resolution = {res[0], res[1]};
 		}
 		int32_t aabb_scale = 1, is_hdr = 0;

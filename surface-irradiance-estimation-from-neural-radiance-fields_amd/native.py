@@ -45,6 +45,7 @@ class Camera(C.Structure):
     _fields_ = [
         ("matrix", C.c_float * 12), ("width", C.c_int32), ("height", C.c_int32), ("focal_length", C.c_float * 2),
         ("screen_center", C.c_float * 2), ("spp_index", C.c_uint32), ("snap_to_pixel_centers", C.c_int32), ("near_distance", C.c_float),
+        ("lens_mode", C.c_int32), ("lens_params", C.c_float * 7),
     ]
 
 
@@ -114,6 +115,7 @@ def load_library():
     L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
     L.ngp_n_training_views.argtypes = [vp]
     L.ngp_get_training_view.argtypes = [vp, ip, vp, vp, vp, vp]
+    L.ngp_get_training_view_lens.argtypes = [vp, ip, vp, vp]
     L.ngp_get_dataset_info.argtypes = [vp, vp, vp, vp, vp]
     L.ngp_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp]
     L.ngp_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp, vp]
@@ -145,7 +147,10 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0):
+LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR = range(6)
+
+
+def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=()):
     cam = Camera()
     mat = np.asarray(matrix_3x4, np.float32)
     assert mat.shape == (3, 4)
@@ -158,6 +163,9 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
     cam.spp_index = spp_index
     cam.snap_to_pixel_centers = 1 if snap else 0
     cam.near_distance = near
+    cam.lens_mode = lens_mode
+    for i, q in enumerate(lens_params):
+        cam.lens_params[i] = q
     return cam
 
 
@@ -265,7 +273,9 @@ class Context:
         m = np.zeros(12, np.float32); res = np.zeros(2, np.int32); fl = np.zeros(2, np.float32); pp = np.zeros(2, np.float32)
         if self.L.ngp_get_training_view(self.h, i, _p(m), _p(res), _p(fl), _p(pp)) != 0:
             raise IndexError(i)
-        return {"matrix": m.reshape(4, 3).T.copy(), "resolution": res, "focal_length": fl, "principal_point": pp}
+        mode = C.c_int32(0); lp = np.zeros(7, np.float32)
+        self.L.ngp_get_training_view_lens(self.h, i, C.addressof(mode), _p(lp))
+        return {"matrix": m.reshape(4, 3).T.copy(), "resolution": res, "focal_length": fl, "principal_point": pp, "lens_mode": mode.value, "lens_params": lp}
 
     def dataset_info(self):
         a = C.c_int32(0); s = C.c_float(0); off = np.zeros(3, np.float32); hdr = C.c_int32(0)

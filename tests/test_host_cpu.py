@@ -20,6 +20,9 @@ def test_library_exports_every_declared_symbol(native):
     assert len(names) >= 20 and "ngp_render" in names and "ngp_load_snapshot" in names and "ngp_load_training_data" in names
     for n in names:
         assert hasattr(L, n), f"libngp_hip.so does not export {n}"
+        # every entry point the binding calls must declare its argument types: ctypes would otherwise pass the 64-bit
+        # context handle as a C int
+        assert n == "ngp_version" or getattr(L, n).argtypes is not None, f"native.py declares no argtypes for {n}"
     assert b"gfx950" in L.ngp_version()
 
 
@@ -99,11 +102,45 @@ def test_reference_datasets_load(native):
     v = ctx.training_view(0)
     assert v["resolution"].tolist() == [1080, 1920] and abs(v["focal_length"][0] - 1375.52) < 1e-2
     assert np.allclose(v["principal_point"], [554.558 / 1080, 965.268 / 1920], atol=1e-6)
+    # read_lens (src/nerf_loader.cu:175-240): fox carries OpenCV distortion coefficients
+    assert v["lens_mode"] == native.LENS_OPENCV and np.allclose(v["lens_params"][:4], [0.0578421, -0.0805099, -0.000980296, 0.00015575], rtol=1e-6)
     ctx.load_training_data(os.path.join(REF, "data/test3/images/transforms_train.json"))
     assert ctx.n_training_views() == 150
+    assert ctx.training_view(3)["lens_mode"] == native.LENS_PERSPECTIVE
     info = ctx.dataset_info()
     assert info["aabb_scale"] == 1 and np.allclose(info["offset"], [0.5, 0.5, 0.0])
     ctx.close()
+
+
+def test_lens_undistortion_inverts_the_distortion(oracle):
+    """iterative_lens_undistortion (common_device.cuh:300-329): x + delta(x) == x0 after the Newton iteration, for the fox
+    dataset's OpenCV coefficients and for a fisheye lens."""
+    import ctypes as C
+
+    for mode, q in ((1, (0.0578421, -0.0805099, -0.000980296, 0.00015575)), (4, (0.05, -0.01, 0.003, -0.0005))):
+        cam = oracle.make_camera(np.eye(3, 4, dtype=np.float32), 1000, 1000, (1000.0, 1000.0), lens_mode=mode, lens_params=q)
+        persp = oracle.make_camera(np.eye(3, 4, dtype=np.float32), 1000, 1000, (1000.0, 1000.0))
+        d = (C.c_float * 3)()
+        p = (C.c_float * 3)()
+        for u, v in ((0.5, 0.5), (0.1, 0.9), (0.95, 0.3), (0.0, 0.0)):
+            oracle.lib.orc_lens_direction(C.byref(cam), C.c_float(u), C.c_float(v), d)
+            oracle.lib.orc_lens_direction(C.byref(persp), C.c_float(u), C.c_float(v), p)
+            x, y = d[0], d[1]
+            if mode == 1:
+                k1, k2, p1, p2 = q
+                r2 = x * x + y * y
+                rad = k1 * r2 + k2 * r2 * r2
+                dx = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+                dy = y * rad + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+            else:
+                r = float(np.hypot(x, y))
+                if r > 1e-12:
+                    th = np.arctan(r)
+                    thd = th * (1 + q[0] * th ** 2 + q[1] * th ** 4 + q[2] * th ** 6 + q[3] * th ** 8)
+                    dx, dy = x * thd / r - x, y * thd / r - y
+                else:
+                    dx = dy = 0.0
+            assert abs(x + dx - p[0]) < 2e-5 and abs(y + dy - p[1]) < 2e-5 and d[2] == 1.0
 
 
 def test_snapshot_formats_roundtrip(tmp_path, native):

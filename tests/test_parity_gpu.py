@@ -429,3 +429,27 @@ def test_cone_angle_override(native, oracle, scene_mod, scene_big):
     assert_image_close(img, ref, 48.0, tol=2e-2)
     assert st["n_samples"] > 0 and np.abs(img - before).max() > 1e-3
     ctx.close()
+
+
+@pytest.mark.parametrize("lens", ["opencv", "fisheye", "latlong", "equirectangular"])
+def test_lens_models(lens, gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """uv_to_ray's lenses (common_device.cuh:441-462): OpenCV / OpenCV-fisheye undistortion (Newton), lat-long, equirectangular."""
+    w, h = 112, 64
+    gpu_ctx.set_model(scene_unit)
+    gpu_ctx.clear_meshes()
+    kw = {"opencv": dict(lens_mode=native.LENS_OPENCV, lens_params=(0.0578421, -0.0805099, -0.000980296, 0.00015575)),
+          "fisheye": dict(lens_mode=native.LENS_OPENCV_FISHEYE, lens_params=(0.05, -0.01, 0.003, -0.0005)),
+          "latlong": dict(lens_mode=native.LENS_LATLONG), "equirectangular": dict(lens_mode=native.LENS_EQUIRECTANGULAR)}[lens]
+    mat = scene_mod.orbit_camera(20.0, 20.0, 2.2 if lens in ("opencv", "fisheye") else 0.9)
+    focal = scene_mod.focal_from_fov_x(w, 1.2)
+    img = gpu_ctx.render(native.make_camera(mat, w, h, focal, **kw))
+    plain = gpu_ctx.render(native.make_camera(mat, w, h, focal))
+    m = oracle.make_model(scene_unit)
+    fb, _, ost = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal, **kw))
+    oracle.release(m)
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    assert ost["n_rays_hit"] > 500
+    assert_image_close(img, ref, 45.0, tol=2e-2)
+    assert np.abs(img - plain).max() > 0.05  # the lens changes the picture
+    with pytest.raises(RuntimeError, match="lens mode not supported"):
+        gpu_ctx.render(native.make_camera(mat, w, h, focal, lens_mode=native.LENS_FTHETA))
