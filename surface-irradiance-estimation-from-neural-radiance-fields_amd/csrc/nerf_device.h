@@ -352,27 +352,35 @@ NGP_DEV void iterative_lens_undistortion(const float* q, float* u, float* v) {
 	*v = y;
 }
 // the camera-space direction of uv under the frame's lens; false: no ray for this pixel
-NGP_DEV bool lens_direction(const CameraParams& C, float u, float v, f3& dir) {
+// (out of line: the perspective case must not carry the Newton iteration's registers into the persistent kernel)
+__device__ __attribute__((noinline)) void lens_direction_general(int lens_mode, const float* lens_params, float u, float v, float sx, float sy, float* out) {
 	const float PI = 3.14159265358979323846f;
-	if (C.lens_mode == 3) { // LatLong
+	f3 dir;
+	if (lens_mode == 3) { // LatLong
 		float theta = (v - 0.5f) * PI, phi = (u - 0.5f) * PI * 2.0f;
-		float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
-		dir = mk3(sp * ct, st, cp * ct);
-		return true;
-	}
-	if (C.lens_mode == 5) { // Equirectangular
+		dir = mk3(sinf(phi) * cosf(theta), sinf(theta), cosf(phi) * cosf(theta));
+	} else if (lens_mode == 5) { // Equirectangular
 		float ct = (v - 0.5f) * 2.0f;
 		float st = __builtin_sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
 		float phi = (u - 0.5f) * PI * 2.0f;
 		dir = mk3(sinf(phi) * st, ct, cosf(phi) * st);
-		return true;
+	} else {
+		dir = mk3(sx, sy, 1.0f);
+		if (lens_mode == 1) iterative_lens_undistortion<false>(lens_params, &dir.x, &dir.y);
+		else if (lens_mode == 4) iterative_lens_undistortion<true>(lens_params, &dir.x, &dir.y);
 	}
+	out[0] = dir.x; out[1] = dir.y; out[2] = dir.z;
+}
+NGP_DEV bool lens_direction(const CameraParams& C, float u, float v, f3& dir) {
 	dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
-	if (C.lens_mode == 1) iterative_lens_undistortion<false>(C.lens_params, &dir.x, &dir.y);
-	else if (C.lens_mode == 4) iterative_lens_undistortion<true>(C.lens_params, &dir.x, &dir.y);
+	if (C.lens_mode != 0) {
+		float q[7], o[3];
+		for (int i = 0; i < 7; ++i) q[i] = C.lens_params[i];
+		lens_direction_general(C.lens_mode, q, u, v, dir.x, dir.y, o);
+		dir = mk3(o[0], o[1], o[2]);
+	}
 	return true;
 }
-
 NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
 	r.idx = x + (uint32_t)C.width * y;
 	r.out = r.idx;
