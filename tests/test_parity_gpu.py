@@ -49,6 +49,9 @@ def test_grid_encode_bit_exact(which, gpu_ctx, oracle, scene_unit, scene_big):
     rng = np.random.default_rng(5)
     pos = rng.uniform(0, 1, (20000, 3)).astype(np.float32)
     pos[:8] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.999999, 0.999999, 0.999999], [1e-7, 1e-7, 1e-7]]
+    # positions outside [0, 1] leave the xor layout's range: the wave takes the tcnn-order table (wrap / hash of any coordinate)
+    pos[8:16] = [[1.5, 0.2, 0.3], [-0.25, 0.5, 0.5], [0.3, 2.75, 0.1], [0.9, 0.9, -1.5], [3.0, 3.0, 3.0], [-0.01, -0.01, -0.01], [1.0001, 0.5, 0.5], [0.5, 0.5, 1.2]]
+    pos[4000:4064] = rng.uniform(-2, 3, (64, 3)).astype(np.float32)  # one whole wave out of range, the rest mixed in
     got = gpu_ctx.grid_encode(pos)
     ref = oracle.grid_encode(m, pos)
     # compare values (so that -0 == +0) and require exact equality: same gathers, same fp16 roundings
