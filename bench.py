@@ -36,7 +36,7 @@ def pkg(sub):
 
 def cpu_baseline(scene_dict, scene_mod):
     """The oracle (kind "port": the reference has no CPU path, scripts/run.py:25 hard-imports the CUDA module) on a
-    bounded sample of the same workload: the same camera and model at 960x540 (1/4 of the pixels)."""
+    bounded sample of the same workload: the same camera and model at 1280x720 (4/9 of the pixels)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -51,7 +51,7 @@ def cpu_baseline(scene_dict, scene_mod):
     grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
     sc["density_grid_bitfield"], _ = o.density_grid_to_bitfield(grid, sc["max_cascade"])
     m = o.make_model(sc)
-    w, h = WIDTH // 2, HEIGHT // 2
+    w, h = WIDTH * 2 // 3, HEIGHT * 2 // 3
     cam = o.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("NGP_BENCH_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
@@ -60,7 +60,7 @@ def cpu_baseline(scene_dict, scene_mod):
     dt = time.perf_counter() - t0
     o.release(m)
     return {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same model+camera at {w}x{h} (1/4 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+            "sample": f"same model+camera at {w}x{h} (4/9 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
 
 
 def pmc_traffic():

@@ -4,7 +4,8 @@ The reference replicates the model on every GPU and assigns whole views round-ro
 5523-5616, peer copies). Here ONE camera is split into 8x8-pixel tiles, tile t goes to rank t % world_size
 (interleaved, so sky and object tiles are spread evenly), every rank renders its tiles with the fused kernel into
 a full-resolution buffer, packs them, and one all_gather per frame moves 20 B/pixel (rgba + depth) to every rank.
-There is no other data-path collective: rays are independent and the model is read-only.
+There is no other data-path collective: rays are independent and the model is read-only. `broadcast_snapshot` is the
+one-off distribution of a model that only one rank can read.
 """
 import torch
 
@@ -66,6 +67,29 @@ def gather_frame(local_img, width, height, rank, world_size, group=None):
     out = packed.new_empty((world_size * n_slots,) + tuple(packed.shape[1:]))  # concatenated along dim 0
     dist.all_gather_into_tensor(out, packed, group=group)
     return unpack_tiles(out.view((world_size, n_slots) + tuple(packed.shape[1:])), width, height, world_size)
+
+
+def broadcast_snapshot(ctx, path, rank, src=0, device=None, group=None):
+    """One-off model distribution after load: rank `src` reads the snapshot file, its bytes go to every rank
+    with one broadcast (RCCL over xGMI when `device` is a GPU), and every rank's context loads them -- params, occupancy
+    grid and dataset metadata end up replicated, which is all the render path needs (the model is read-only).
+    `path` is only read on `src`. Returns the number of bytes moved."""
+    import torch.distributed as dist
+
+    device = device if device is not None else torch.device("cpu")
+    n = torch.zeros(2, dtype=torch.int64, device=device)
+    payload = None
+    if rank == src:
+        with open(path, "rb") as f:
+            raw = f.read()
+        payload = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        n[0], n[1] = payload.numel(), 1 if str(path).lower().endswith(".ingp") else 0
+    dist.broadcast(n, src=src, group=group)
+    if rank != src:
+        payload = torch.empty(int(n[0].item()), dtype=torch.uint8, device=device)
+    dist.broadcast(payload, src=src, group=group)
+    ctx.load_snapshot_bytes(payload.cpu().numpy().tobytes(), compressed=bool(n[1].item()))
+    return int(n[0].item())
 
 
 # ----------------------------------------------------------------------------------------------------------------------

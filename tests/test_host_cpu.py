@@ -269,6 +269,43 @@ def _gloo_worker(rank, world, port, w, h, q):
     dist.destroy_process_group()
 
 
+def _bcast_worker(rank, world, port, snap_path, q):
+    import torch.distributed as dist
+
+    par, native = pkg("parallel"), pkg("native")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = native.Context(-1)  # host-only: parses and validates what arrives
+    nbytes = par.broadcast_snapshot(ctx, snap_path if rank == 0 else "/nonexistent/only-rank-0-has-the-file", rank)
+    d = ctx.get_model()
+    q.put((rank, nbytes, int(d.n_params), int(d.aabb_scale), int(d.log2_hashmap_size)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_snapshot_broadcast_gloo_world2(tmp_path, native):
+    """one-off broadcast of the model after load -- only rank 0 can read the file."""
+    import torch.multiprocessing as mp
+
+    sc = pkg("synthetic").make_scene(aabb_scale=2, seed=9, log2_hashmap_size=12)
+    ctx0 = native.Context(-1)
+    ctx0.set_model(sc)
+    path = str(tmp_path / "model.ingp")
+    ctx0.save_snapshot_file(path)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 2000
+    procs = [mpctx.Process(target=_bcast_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    size = os.path.getsize(path)
+    assert res == [(0, size, sc["params"].size, 2, 12), (1, size, sc["params"].size, 2, 12)]
+
+
 @pytest.mark.parametrize("w,h", [(64, 48), (101, 67)])
 def test_tile_sharding_gather_gloo_world2(w, h):
     import torch.multiprocessing as mp
