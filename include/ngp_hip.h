@@ -178,6 +178,9 @@ NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16
 NGP_API int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16);
 /* K8/K9 update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:2863-2880): the bitfield in use, 8 x 128^3 / 8 bytes */
 NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean);
+/* m_render_aabb / m_render_aabb_to_local (python_api.cu: testbed.render_aabb, .render_aabb_to_local): the crop box of the render,
+ * min/max in ngp space; to_local9 column-major mat3 or NULL for identity */
+NGP_API int ngp_set_render_aabb(ngp_ctx* ctx, const float* min3, const float* max3, const float* to_local9);
 /* m_nerf.cone_angle_constant (python_api.cu: testbed.nerf.cone_angle_constant, run.py:167): 0 = fixed step size */
 NGP_API int ngp_set_cone_angle_constant(ngp_ctx* ctx, float cone_angle_constant);
 /* Testbed::update_density_grid_nerf (src/testbed_nerf.cu:2772-2861; kernels :185-232, :253-276): refresh the occupancy

@@ -1379,6 +1379,24 @@ int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 	});
 }
 
+int ngp_set_render_aabb(ngp_ctx* ctx, const float* min3, const float* max3, const float* to_local9) {
+	return guarded(ctx, [&] {
+		if (!ctx->have_desc) throw std::runtime_error("No network available.");
+		if (!min3 || !max3) throw std::runtime_error("null argument");
+		for (int i = 0; i < 3; ++i) if (!(min3[i] <= max3[i])) throw std::runtime_error("render_aabb: min must not exceed max");
+		if (ctx->last_stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		const float* r2l = to_local9 ? to_local9 : ident;
+		memcpy(ctx->desc.render_aabb_min, min3, 12);
+		memcpy(ctx->desc.render_aabb_max, max3, 12);
+		memcpy(ctx->desc.render_aabb_to_local, r2l, 36);
+		memcpy(ctx->M.raabb_min, min3, 12);
+		memcpy(ctx->M.raabb_max, max3, 12);
+		memcpy(ctx->M.r2l, r2l, 36);
+		ctx->M.r2l_identity = memcmp(r2l, ident, 36) == 0 ? 1u : 0u;
+	});
+}
+
 int ngp_set_cone_angle_constant(ngp_ctx* ctx, float cone_angle_constant) {
 	return guarded(ctx, [&] {
 		if (!ctx->have_desc) throw std::runtime_error("No network available.");

@@ -115,7 +115,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("root_dir", &Testbed::m_root_dir)
 		.def_readonly("data_path", &Testbed::m_data_path)
 		.def_readonly("aabb", &Testbed::m_aabb)
-		.def_readonly("render_aabb", &Testbed::m_render_aabb)
+		.def_property("render_aabb", [](Testbed& t) { return t.m_render_aabb; }, &Testbed::set_render_aabb, "crop box of the render: [min xyz, max xyz] in ngp space")
 		.def_readonly("mode", &Testbed::m_testbed_mode)
 		.def_readonly("training_step", &Testbed::m_training_step)
 		.def_readonly("loss", &Testbed::m_loss)

@@ -249,6 +249,10 @@ public:
 	int32_t m_render_lens_mode = 0;                  // m_nerf.render_lens
 	std::array<float, 7> m_render_lens_params{};
 	bool m_render_ground_truth = false;
+	void set_render_aabb(const std::array<float, 6>& bb) { // testbed.render_aabb = ...
+		check(ngp_set_render_aabb(m_ctx, bb.data(), bb.data() + 3, nullptr));
+		m_render_aabb = bb;
+	}
 	float m_pushed_cone_angle = 0.f; // what the context holds; testbed.nerf.cone_angle_constant is pushed at the next render
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.f;

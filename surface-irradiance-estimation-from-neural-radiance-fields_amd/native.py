@@ -111,6 +111,7 @@ def load_library():
     L.ngp_update_density_grid.argtypes = [vp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
     L.ngp_get_density_grid.argtypes = [vp, vp, C.c_uint64]
     L.ngp_set_cone_angle_constant.argtypes = [vp, C.c_float]
+    L.ngp_set_render_aabb.argtypes = [vp, vp, vp, vp]
     L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
     L.ngp_n_training_views.argtypes = [vp]
@@ -396,6 +397,11 @@ class Context:
         mean = C.c_float(0)
         self._check(self.L.ngp_get_density_bitfield(self.h, _p(bf), C.addressof(mean)))
         return bf, mean.value
+
+    def set_render_aabb(self, lo, hi, to_local=None):
+        lo = np.asarray(lo, np.float32); hi = np.asarray(hi, np.float32)
+        r = None if to_local is None else np.ascontiguousarray(np.asarray(to_local, np.float32).T.reshape(-1))  # column-major
+        self._check(self.L.ngp_set_render_aabb(self.h, _p(lo), _p(hi), _p(r) if r is not None else None))
 
     def set_cone_angle_constant(self, value):
         self._check(self.L.ngp_set_cone_angle_constant(self.h, value))

@@ -456,3 +456,33 @@ def test_lens_models(lens, gpu_ctx, oracle, native, scene_mod, scene_unit):
     assert np.abs(img - plain).max() > 0.05  # the lens changes the picture
     with pytest.raises(RuntimeError, match="lens mode not supported"):
         gpu_ctx.render(native.make_camera(mat, w, h, focal, lens_mode=native.LENS_FTHETA))
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+def test_render_aabb_crop(rotated, native, oracle, scene_mod, scene_unit):
+    """testbed.render_aabb / render_aabb_to_local: the crop box of the render (rays start at its entry, stop at its exit)."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    w, h = 128, 72
+    cam, ocam = _cam_pair(native, oracle, scene_mod, w, h, az=60.0)
+    full = ctx.render(cam)
+    lo, hi = (0.2, 0.05, 0.3), (0.62, 0.8, 0.95)
+    a = 0.5
+    rot = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], np.float32) if rotated else None
+    ctx.set_render_aabb(lo, hi, rot)
+    img = ctx.render(cam)
+    st = ctx.render_stats()
+    sc = dict(scene_unit)
+    sc["render_aabb"] = (lo, hi)
+    if rotated:
+        sc["render_aabb_to_local"] = rot
+    m = oracle.make_model(sc)
+    fb, _, ost = oracle.render_nerf(m, ocam)
+    oracle.release(m)
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    assert ost["n_rays_hit"] > 300 and abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 3
+    assert_image_close(img, ref, 48.0, tol=2e-2)
+    assert np.abs(img - full).max() > 0.05 and st["n_samples"] > 0
+    with pytest.raises(RuntimeError, match="min must not exceed max"):
+        ctx.set_render_aabb((0.5, 0.5, 0.5), (0.4, 0.6, 0.6))
+    ctx.close()
