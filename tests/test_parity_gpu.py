@@ -486,3 +486,22 @@ def test_render_aabb_crop(rotated, native, oracle, scene_mod, scene_unit):
     with pytest.raises(RuntimeError, match="min must not exceed max"):
         ctx.set_render_aabb((0.5, 0.5, 0.5), (0.4, 0.6, 0.6))
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (8, 8), (9, 17), (1031, 2)])
+def test_tiny_and_thin_resolutions(w, h, gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """Frames smaller than a tile, single rows, widths that leave ragged tiles: every pixel is written exactly like the oracle's."""
+    gpu_ctx.set_model(scene_unit)
+    gpu_ctx.clear_meshes()
+    mat = scene_mod.orbit_camera(45.0)
+    focal = scene_mod.focal_from_fov_x(max(w, 16), 0.6911)
+    img, depth = gpu_ctx.render(native.make_camera(mat, w, h, focal), native.make_opts(background=(0.1, 0.2, 0.3, 1.0)), want_depth=True)
+    st = gpu_ctx.render_stats()
+    m = oracle.make_model(scene_unit)
+    fb, db, ost = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal))
+    oracle.release(m)
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0), (0.1, 0.2, 0.3, 1.0)).reshape(h, w, 4)
+    assert img.shape == (h, w, 4) and np.isfinite(img).all()
+    assert abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 1
+    assert np.abs(img - ref).max() < 2e-2
+    assert np.array_equal(depth >= 16000, db.reshape(h, w) >= 16000)
