@@ -69,6 +69,27 @@ def build_pyngp(force=False, verbose=False):
     return out
 
 
+def main_path():
+    return os.path.join(HERE, "ngp_hip_main")
+
+
+def build_main(force=False, verbose=False):
+    """Headless command line (csrc/ngp_main.cpp: the flags of the reference's src/main.cu), linked against libngp_hip.so."""
+    out = main_path()
+    srcs = [os.path.join(CSRC, "ngp_main.cpp"), os.path.join(CSRC, "testbed_shim.h"), os.path.join(CSRC, "minijson.h"), os.path.join(HERE, "..", "include", "ngp_hip.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    build()
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", srcs[0], "-o", out, "-L", HERE, "-lngp_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("building ngp_hip_main failed")
+    return out
+
+
 def import_pyngp():
     """Import the in-tree pyngp extension (build it first if needed)."""
     import importlib.util

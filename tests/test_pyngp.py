@@ -118,3 +118,56 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     testbed.render_mode = pyngp.RenderMode.Normals
     with pytest.raises(RuntimeError, match="render modes supported"):
         testbed.render(8, 8, 1, True)
+
+
+@pytest.mark.gpu
+def test_headless_command_line(tmp_path, gpu_ctx, native, scene_mod, scene_unit):
+    """ngp_hip_main: the flags of the reference's src/main.cu plus --screenshot_transforms / --screenshot_dir (run.py:276-299);
+    the PNGs it writes are the Python API's frames, un-premultiplied, sRGB-encoded, quantised to 8 bits."""
+    import subprocess
+    from PIL import Image
+
+    exe = pkg("build").build_main()
+    gpu_ctx.set_model(scene_unit)
+    frames = []
+    for az in (30.0, 200.0):
+        c2w = np.eye(4, dtype=np.float64)
+        ngp = scene_mod.orbit_camera(az)
+        m = ngp[[2, 0, 1], :].copy()
+        m[:, 3] = (m[:, 3] - 0.5) / 0.33
+        m[:, 1] *= -1
+        m[:, 2] *= -1
+        c2w[:3, :4] = m
+        frames.append({"file_path": f"./images/r_{int(az)}", "transform_matrix": c2w.tolist()})
+    tj = tmp_path / "transforms.json"
+    tj.write_text(json.dumps({"camera_angle_x": 0.6911, "w": 96, "h": 54, "frames": frames}))
+    # a trained snapshot carries its dataset (scale 0.33, offset 0.5: what set_nerf_camera_matrix converts poses with)
+    writer = native.Context(0)
+    writer.set_model(scene_unit)
+    writer.load_training_data(str(tj))
+    snap = str(tmp_path / "lego.msgpack")
+    writer.save_snapshot_file(snap, compress=False)
+    writer.close()
+    out_dir = tmp_path / "shots"
+    out_dir.mkdir()
+    r = subprocess.run([exe, "--no-gui", "--snapshot", snap, "--width", "96", "--height", "54", "--screenshot_transforms", str(tj), "--screenshot_dir", str(out_dir)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for az in (30.0, 200.0):
+        png = np.asarray(Image.open(out_dir / f"r_{int(az)}.png")).astype(np.float32) / 255.0
+        assert png.shape == (54, 96, 4)
+        cam = native.make_camera(scene_mod.orbit_camera(az), 96, 54, scene_mod.focal_from_fov_x(96, 0.6911))
+        img = gpu_ctx.render(cam, native.make_opts(background=(0, 0, 0, 0)))
+        a = np.clip(img[..., 3:4], 0, 1)
+        rgb = np.where(a > 0, img[..., :3] / np.maximum(a, 1e-12), 0.0)
+        rgb = np.clip(rgb, 0, 1)
+        srgb = np.where(rgb < 0.0031308, 12.92 * rgb, 1.055 * np.power(np.maximum(rgb, 1e-12), 0.41666) - 0.055)
+        assert np.abs(png[..., 3:4] - a).max() <= 1.5 / 255  # 8-bit quantisation + the pose round trip through the NeRF convention
+        solid = a[..., 0] > 0.05
+        assert solid.mean() > 0.1 and np.abs(png[..., :3][solid] - srgb[solid]).max() <= 1.5 / 255
+    # errors are reported, not swallowed: a missing snapshot and an unknown flag
+    r = subprocess.run([exe, "--snapshot", str(tmp_path / "nope.msgpack"), "--screenshot", str(tmp_path / "x.png")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "error:" in r.stderr
+    r = subprocess.run([exe, "--frobnicate"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "unknown flag" in r.stderr
+    assert subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60).stdout.startswith("ngp_hip")
