@@ -163,7 +163,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    hist = ctx.render_history(min(args.steps, 256))
+    # outside the timed region: the frame the ranks assembled must be the frame one GPU renders alone
+    gather_diff = None
+    if world > 1:
+        last = args.steps - 1
+        img_g, depth_g = gatherers[last % len(streams)].img.view(h, w, 4), gatherers[last % len(streams)].depth.view(h, w)
+        solo_rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        solo_depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        if args.steps > 0:
+            ctx.render_device(cams[last % len(cams)], native.make_opts(), solo_rgba.data_ptr(), solo_depth.data_ptr(), streams[0].cuda_stream)
+            torch.cuda.synchronize(dev)
+            gather_diff = max(float((img_g - solo_rgba).abs().max().item()), float((depth_g - solo_depth).abs().max().item()))
+    hist_n = min(args.steps, 256) + (1 if gather_diff is not None else 0)
+    hist = ctx.render_history(min(hist_n, 256))[:min(args.steps, 256)]
     local = np.array([[s["n_rays"], s["n_rays_hit"], s["n_samples"], s["kernel_ms"], s["frame_ms"]] for s in hist], np.float64)
     if world > 1:
         tl = torch.tensor(local, dtype=torch.float64, device=dev)
@@ -206,6 +218,7 @@ def main():
                 "hit_fraction": round(hits_per_frame / n_rays, 4),
                 "samples_per_step": int(samples_per_frame),
                 "tile_sharding": f"8x8 tiles round-robin over {world} rank(s)" + (", all_gather of rgba+depth per frame (RCCL)" if world > 1 else ""),
+                "frames_in_flight": len(streams),
             },
             "roofline": {
                 "bound": "hbm",
@@ -220,6 +233,8 @@ def main():
                 "mfma_tflops": round(k_samples * 20480.0 / (k_ms * 1e-3) / 1e12, 3),
             },
         }
+        if gather_diff is not None:
+            out["gathered_frame_max_abs_diff_vs_single_gpu"] = gather_diff  # rank 0's check of the assembled frame, outside the timed region
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scene_mod)
         print(json.dumps(out), flush=True)
