@@ -14,6 +14,7 @@ cp gpurun_out/prof_$tag/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 echo "kernel trace done"
 bash tools/pmc_pass.sh ${tag}_fetch FETCH_SIZE > gpurun_out/${tag}_pmc.txt
 bash tools/pmc_pass.sh ${tag}_write WRITE_SIZE >> gpurun_out/${tag}_pmc.txt
+bash tools/pmc_pass.sh ${tag}_compute SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE >> gpurun_out/${tag}_pmc.txt
 cat gpurun_out/${tag}_pmc.txt
 python3 - "$tag" <<'PY'
 import json, re, sys
@@ -34,4 +35,16 @@ out = {
 }
 json.dump(out, open(f"gpurun_out/{tag}_pmc_hbm.json", "w"), indent=1)
 print(out)
+# compute-side utilisation of the same launch: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles,
+# v_mfma_f32_16x16x32_f16 for 16 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+if "SQ_INSTS_VALU" in vals:
+    cyc = vals["GRBM_GUI_ACTIVE"][0] / 8.0
+    simds = 1024.0
+    comp = {k: vals[k][0] for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")}
+    comp["kernel_cycles_per_xcd"] = cyc
+    comp["valu_issue_utilisation"] = comp["SQ_INSTS_VALU"] * 4.0 / simds / cyc
+    comp["mfma_pipe_utilisation"] = comp["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cyc
+    comp["note"] = "per launch of render_nerf_fused_unit at 1080p (bench.py --steps 3 --warmup 1, kernels serialised by the counter collection)"
+    json.dump(comp, open(f"gpurun_out/{tag}_pmc_compute.json", "w"), indent=1)
+    print(comp)
 PY
