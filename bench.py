@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("NGP_BENCH_INFLIGHT", "2")), help="frames in flight (streams / buffer sets)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("NGP_BENCH_INFLIGHT", "0")),
+                    help="frames in flight (streams / buffer sets); 0 = 2 on one or two GPUs, 6 beyond (a rank's share of a frame is short: tools/shard_probe.py)")
     args = ap.parse_args()
 
     import torch
@@ -123,10 +124,11 @@ def main():
     w, h = args.width, args.height
     focal = scene_mod.focal_from_fov_x(w, FOV_X)
     cams = [native.make_camera(scene_mod.orbit_camera(az), w, h, focal) for az in AZIMUTHS]
-    # Two frames in flight: frame i is rendered (and, for N > 1, gathered) on stream i % 2 into buffer set i % 2, so
+    # Frames in flight: frame i is rendered (and, for N > 1, gathered) on stream i % k into buffer set i % k, so
     # the drain of one frame's persistent kernel and its all_gather overlap the next frame's render. Every launch,
     # copy and collective of a step is enqueued on that step's stream; fence() joins both.
-    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.inflight))]
+    n_inflight = args.inflight if args.inflight > 0 else (2 if world <= 2 else 6)
+    streams = [torch.cuda.Stream(dev) for _ in range(n_inflight)]
     if world > 1:
         # tile-packed output: the fused kernel writes this rank's tiles in the layout the all_gather moves
         opts = native.make_opts(shard_index=rank, shard_count=world, packed_output=True)
