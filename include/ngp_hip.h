@@ -86,6 +86,9 @@ typedef struct ngp_camera {
 	 * parameters (OpenCV: k1 k2 p1 p2; OpenCVFisheye: k1 k2 k3 k4). All zero = perspective. */
 	int32_t lens_mode;
 	float lens_params[7];
+	/* depth of field (uv_to_ray, common_device.cuh:471-477): m_aperture_size and the focus distance plane_z = m_slice_plane_z + m_scale
+	 * (src/testbed_nerf.cu:2342); aperture_size 0 or focus_z < 0 = pinhole */
+	float aperture_size, focus_z;
 } ngp_camera;
 
 typedef struct ngp_render_opts {

@@ -61,10 +61,14 @@ typedef struct orc_camera {
 	float near_distance;
 	int32_t lens_mode;    /* ELensMode (common.h:223-230): 0 Perspective, 1 OpenCV, 3 LatLong, 4 OpenCVFisheye, 5 Equirectangular */
 	float lens_params[7]; /* OpenCV: k1 k2 p1 p2; fisheye: k1 k2 k3 k4 */
+	float aperture_size;  /* depth of field (uv_to_ray, common_device.cuh:471-477); 0 = pinhole */
+	float focus_z;        /* plane_z = m_slice_plane_z + m_scale */
 } orc_camera;
 
 /* camera-space direction of image coordinate (u, v) under the camera's lens (uv_to_ray, common_device.cuh:441-462) */
 void orc_lens_direction(const orc_camera* cam, float u, float v, float* dir3);
+/* the depth-of-field step of uv_to_ray on a camera-space origin / direction pair already rotated into world space */
+void orc_apply_aperture(const orc_camera* cam, float u, float v, float* origin3, float* dir3);
 
 typedef struct orc_render_opts {
 	float min_transmittance;      /* m_nerf.render_min_transmittance */

@@ -65,6 +65,8 @@ class Camera(C.Structure):
         ("near_distance", C.c_float),
         ("lens_mode", C.c_int32),
         ("lens_params", C.c_float * 7),
+        ("aperture_size", C.c_float),
+        ("focus_z", C.c_float),
     ]
 
 
@@ -260,7 +262,7 @@ class Oracle:
         return out
 
     @staticmethod
-    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=()):
+    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0):
         """matrix_4x3: numpy (3,4) [R|t] camera-to-world in NGP convention."""
         cam = Camera()
         mat = np.asarray(matrix_4x3, np.float32)
@@ -277,6 +279,7 @@ class Oracle:
         cam.lens_mode = lens_mode
         for i, q in enumerate(lens_params):
             cam.lens_params[i] = q
+        cam.aperture_size, cam.focus_z = aperture_size, focus_z
         return cam
 
     @staticmethod

@@ -355,7 +355,14 @@ void orc_render_mesh(const orc_mesh_scene* s, const orc_camera* cam, const orc_m
 		orc_lens_direction(cam, u, v, d3);
 		v3 dir = v3_make(d3[0], d3[1], d3[2]);
 		dir = m3_mulv(cam->matrix, dir);
-		v3 origin = v3_add(cam_pos, v3_scale(dir, cam->near_distance));
+		v3 origin = cam_pos;
+		{
+			float o3[3] = {origin.x, origin.y, origin.z}, dd[3] = {dir.x, dir.y, dir.z};
+			orc_apply_aperture(cam, u, v, o3, dd);
+			origin = v3_make(o3[0], o3[1], o3[2]);
+			dir = v3_make(dd[0], dd[1], dd[2]);
+		}
+		origin = v3_add(origin, v3_scale(dir, cam->near_distance));
 		depth_buffer[i] = ORC_MAX_DEPTH;
 		if (dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) continue;
 		dir = v3_normalize(dir);

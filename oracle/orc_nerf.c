@@ -575,6 +575,31 @@ static v3 lens_direction(const orc_camera* cam, float u, float v) {
 	return dir;
 }
 
+/* depth of field, common_device.cuh:471-477: square2disk_shirley (random_val.cuh:112-128) of ld_random_val_2d(spp, px hash) */
+void orc_apply_aperture(const orc_camera* cam, float u, float v, float* origin3, float* dir3) {
+	if (cam->aperture_size == 0.0f || cam->focus_z < 0.0f) return;
+	int px = (int)(u * (float)cam->width), py = (int)(v * (float)cam->height);
+	float sq[2];
+	ld_random_val_2d(cam->spp_index, (uint32_t)px * 19349663u + (uint32_t)py * 96925573u, sq);
+	float a = sq[0] * 2.0f - 1.0f, b = sq[1] * 2.0f - 1.0f;
+	const float PI = 3.14159265358979323846f;
+	float r, phi;
+	if (a * a > b * b) {
+		r = a;
+		phi = (PI / 4.0f) * (b / a);
+	} else {
+		r = b;
+		phi = (PI / 2.0f) - (PI / 4.0f) * (a / b);
+	}
+	float bx = cam->aperture_size * (r * cosf(phi)), by = cam->aperture_size * (r * sinf(phi));
+	v3 origin = v3_make(origin3[0], origin3[1], origin3[2]), dir = v3_make(dir3[0], dir3[1], dir3[2]);
+	v3 lookat = v3_add(origin, v3_scale(dir, cam->focus_z));
+	origin = v3_add(origin, v3_add(v3_scale(v3_make(cam->matrix[0], cam->matrix[1], cam->matrix[2]), bx), v3_scale(v3_make(cam->matrix[3], cam->matrix[4], cam->matrix[5]), by)));
+	dir = v3_make((lookat.x - origin.x) / cam->focus_z, (lookat.y - origin.y) / cam->focus_z, (lookat.z - origin.z) / cam->focus_z);
+	origin3[0] = origin.x; origin3[1] = origin.y; origin3[2] = origin.z;
+	dir3[0] = dir.x; dir3[1] = dir.y; dir3[2] = dir.z;
+}
+
 void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload) {
 	const prepared_t* p = (const prepared_t*)m->prepared;
 	uint32_t idx = x + (uint32_t)cam->width * y;
@@ -585,6 +610,12 @@ void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, ui
 	v3 dir = lens_direction(cam, u, v);
 	dir = m3_mulv(cam->matrix, dir);
 	v3 origin = v3_make(cam->matrix[9], cam->matrix[10], cam->matrix[11]);
+	{
+		float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z};
+		orc_apply_aperture(cam, u, v, o3, d3);
+		origin = v3_make(o3[0], o3[1], o3[2]);
+		dir = v3_make(d3[0], d3[1], d3[2]);
+	}
 	origin = v3_add(origin, v3_scale(dir, cam->near_distance));
 
 	memset(payload, 0, sizeof(*payload));

@@ -187,7 +187,15 @@ __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams
 	f3 dir;
 	lens_direction(C, u, v, dir);
 	dir = m3_mulv(C.m, dir);
-	f3 origin = add3(cam_pos, scale3(dir, C.near_distance));
+	f3 origin = cam_pos;
+	if (C.aperture_size != 0.0f) {
+		float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z}, cm[6];
+		for (int i = 0; i < 6; ++i) cm[i] = C.m[i];
+		apply_aperture(cm, C.aperture_size, C.focus_z, C.spp, (uint32_t)(int)(u * (float)C.width) * 19349663u + (uint32_t)(int)(v * (float)C.height) * 96925573u, o3, d3);
+		origin = mk3(o3[0], o3[1], o3[2]);
+		dir = mk3(d3[0], d3[1], d3[2]);
+	}
+	origin = add3(origin, scale3(dir, C.near_distance));
 	depth_buffer[idx] = MAX_DEPTH;
 	if (dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
 	dir = normalize3(dir);

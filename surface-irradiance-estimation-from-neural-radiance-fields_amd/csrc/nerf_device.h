@@ -381,6 +381,36 @@ NGP_DEV bool lens_direction(const CameraParams& C, float u, float v, f3& dir) {
 	}
 	return true;
 }
+// depth of field of uv_to_ray (common_device.cuh:471-477): the origin moves on the lens disk (square2disk_shirley of a
+// 2-d Sobol point, random_val.cuh:112-128, 311-330), the direction keeps the focus point. Out of line, like the lenses.
+__device__ __attribute__((noinline)) void apply_aperture(const float* cam_m, float aperture_size, float focus_z, uint32_t spp, uint32_t px_seed, float* origin3, float* dir3) {
+	// ld_random_val_2d(spp, seed): Owen-scrambled Sobol, dimensions 0 (bit reversal) and 1 (v_k = v_{k-1} ^ (v_{k-1} >> 1))
+	uint32_t index = nested_uniform_scramble_base2(spp, px_seed);
+	uint32_t s0 = __builtin_bitreverse32(index), s1 = 0, v = 0x80000000u;
+	for (uint32_t bit = 0; bit < 32u; ++bit) {
+		if ((index >> bit) & 1u) s1 ^= v;
+		v ^= v >> 1;
+	}
+	const float sx = (float)nested_uniform_scramble_base2(s0, hash_combine(px_seed, 0u)) * 2.3283064365386963e-10f * 2.0f - 1.0f;
+	const float sy = (float)nested_uniform_scramble_base2(s1, hash_combine(px_seed, 1u)) * 2.3283064365386963e-10f * 2.0f - 1.0f;
+	const float PI = 3.14159265358979323846f;
+	float r, phi;
+	if (sx * sx > sy * sy) {
+		r = sx;
+		phi = (PI / 4.0f) * (sy / sx);
+	} else {
+		r = sy;
+		phi = (PI / 2.0f) - (PI / 4.0f) * (sx / sy);
+	}
+	const float bx = aperture_size * (r * cosf(phi)), by = aperture_size * (r * sinf(phi));
+	f3 origin = mk3(origin3[0], origin3[1], origin3[2]), dir = mk3(dir3[0], dir3[1], dir3[2]);
+	const f3 lookat = add3(origin, scale3(dir, focus_z));
+	origin = add3(origin, add3(scale3(mk3(cam_m[0], cam_m[1], cam_m[2]), bx), scale3(mk3(cam_m[3], cam_m[4], cam_m[5]), by))); // mat2x3(camera) * blur
+	dir = mk3((lookat.x - origin.x) / focus_z, (lookat.y - origin.y) / focus_z, (lookat.z - origin.z) / focus_z);
+	origin3[0] = origin.x; origin3[1] = origin.y; origin3[2] = origin.z;
+	dir3[0] = dir.x; dir3[1] = dir.y; dir3[2] = dir.z;
+}
+
 NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
 	r.idx = x + (uint32_t)C.width * y;
 	r.out = r.idx;
@@ -390,6 +420,14 @@ NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, u
 	lens_direction(C, u, v, dir);
 	dir = m3_mulv(C.m, dir);
 	f3 origin = mk3(C.m[9], C.m[10], C.m[11]);
+	if (C.aperture_size != 0.0f) {
+		float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z}, cm[6];
+		for (int i = 0; i < 6; ++i) cm[i] = C.m[i];
+		// px = ivec2(uv * resolution)
+		apply_aperture(cm, C.aperture_size, C.focus_z, C.spp, (uint32_t)(int)(u * (float)C.width) * 19349663u + (uint32_t)(int)(v * (float)C.height) * 96925573u, o3, d3);
+		origin = mk3(o3[0], o3[1], o3[2]);
+		dir = mk3(d3[0], d3[1], d3[2]);
+	}
 	origin = add3(origin, scale3(dir, C.near_distance));
 	r.o = origin;
 	r.d = mk3(0.f, 0.f, 0.f);

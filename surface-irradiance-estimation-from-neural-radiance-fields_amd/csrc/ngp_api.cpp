@@ -888,6 +888,9 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 	C.near_distance = cam.near_distance;
 	if (cam.lens_mode == NGP_LENS_FTHETA || cam.lens_mode < 0 || cam.lens_mode > NGP_LENS_EQUIRECTANGULAR) throw std::runtime_error("lens mode not supported (Perspective, OpenCV, OpenCVFisheye, LatLong, Equirectangular are)");
 	C.lens_mode = cam.lens_mode;
+	C.aperture_size = cam.focus_z < 0.f ? 0.f : cam.aperture_size; // plane_z < 0 switches the aperture off (src/testbed_nerf.cu:1462-1464)
+	C.focus_z = cam.focus_z;
+	if (C.aperture_size != 0.f && !(C.focus_z > 0.f)) throw std::runtime_error("depth of field needs a positive focus distance");
 	memcpy(C.lens_params, cam.lens_params, sizeof(C.lens_params));
 	ld_random_pixel_offset(cam.snap_to_pixel_centers ? 0u : spp_index, C.pixel_offset);
 	return C;

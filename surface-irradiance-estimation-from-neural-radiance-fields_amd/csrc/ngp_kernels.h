@@ -78,6 +78,7 @@ struct CameraParams {
 	float near_distance;
 	int32_t lens_mode; // ELensMode: 0 Perspective, 1 OpenCV, 3 LatLong, 4 OpenCVFisheye, 5 Equirectangular
 	float lens_params[7];
+	float aperture_size, focus_z; // depth of field: 0 = pinhole
 };
 
 struct FrameParams {

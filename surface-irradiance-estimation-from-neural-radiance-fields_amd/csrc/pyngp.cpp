@@ -108,6 +108,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("exposure", &Testbed::m_exposure)
 		.def_readwrite("render_mode", &Testbed::m_render_mode)
 		.def_readwrite("color_space", &Testbed::m_color_space)
+		.def_readwrite("aperture_size", &Testbed::m_aperture_size)
+		.def_readwrite("slice_plane_z", &Testbed::m_slice_plane_z)
 		.def_readwrite("render_ground_truth", &Testbed::m_render_ground_truth)
 		.def_readwrite("render_near_distance", &Testbed::m_render_near_distance)
 		.def_readwrite("sun_dir", &Testbed::m_sun_dir)

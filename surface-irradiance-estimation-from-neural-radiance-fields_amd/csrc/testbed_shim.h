@@ -182,6 +182,8 @@ public:
 		cam.spp_index = 0;
 		cam.snap_to_pixel_centers = m_snap_to_pixel_centers ? 1 : 0;
 		cam.near_distance = m_render_near_distance;
+		cam.aperture_size = m_aperture_size; // src/testbed_nerf.cu:2342, 2380
+		cam.focus_z = m_slice_plane_z + m_scale;
 		if (nerf.render_with_lens_distortion) { // m_nerf.render_lens, src/testbed_nerf.cu render_nerf
 			cam.lens_mode = m_render_lens_mode;
 			memcpy(cam.lens_params, m_render_lens_params.data(), sizeof(cam.lens_params));
@@ -246,6 +248,7 @@ public:
 	// The fork defaults to ShadeGridEnvMap, for which the reference has no kernel; every BASELINE run pins Shade.
 	ERenderMode m_render_mode = ERenderMode::Shade;
 	EColorSpace m_color_space = EColorSpace::Linear; // testbed.color_space (run.py:160)
+	float m_aperture_size = 0.f, m_slice_plane_z = 0.f; // testbed.aperture_size, testbed.slice_plane_z (focus = slice_plane_z + scale)
 	int32_t m_render_lens_mode = 0;                  // m_nerf.render_lens
 	std::array<float, 7> m_render_lens_params{};
 	bool m_render_ground_truth = false;

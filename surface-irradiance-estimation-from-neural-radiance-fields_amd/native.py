@@ -45,7 +45,7 @@ class Camera(C.Structure):
     _fields_ = [
         ("matrix", C.c_float * 12), ("width", C.c_int32), ("height", C.c_int32), ("focal_length", C.c_float * 2),
         ("screen_center", C.c_float * 2), ("spp_index", C.c_uint32), ("snap_to_pixel_centers", C.c_int32), ("near_distance", C.c_float),
-        ("lens_mode", C.c_int32), ("lens_params", C.c_float * 7),
+        ("lens_mode", C.c_int32), ("lens_params", C.c_float * 7), ("aperture_size", C.c_float), ("focus_z", C.c_float),
     ]
 
 
@@ -151,7 +151,7 @@ def _p(a):
 LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR = range(6)
 
 
-def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=()):
+def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0):
     cam = Camera()
     mat = np.asarray(matrix_3x4, np.float32)
     assert mat.shape == (3, 4)
@@ -167,6 +167,7 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
     cam.lens_mode = lens_mode
     for i, q in enumerate(lens_params):
         cam.lens_params[i] = q
+    cam.aperture_size, cam.focus_z = aperture_size, focus_z
     return cam
 
 

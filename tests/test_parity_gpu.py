@@ -505,3 +505,27 @@ def test_tiny_and_thin_resolutions(w, h, gpu_ctx, oracle, native, scene_mod, sce
     assert abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 1
     assert np.abs(img - ref).max() < 2e-2
     assert np.array_equal(depth >= 16000, db.reshape(h, w) >= 16000)
+
+
+def test_depth_of_field(gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """uv_to_ray's thin-lens step (common_device.cuh:471-477): the ray origin moves on the aperture disk (2-d Sobol point per
+    pixel and sample), the direction keeps the focus point; several samples accumulate to the blur."""
+    w, h, spp = 96, 54, 4
+    gpu_ctx.set_model(scene_unit)
+    gpu_ctx.clear_meshes()
+    mat = scene_mod.orbit_camera(310.0)
+    focal = scene_mod.focal_from_fov_x(w, 0.6911)
+    kw = dict(aperture_size=0.03, focus_z=1.1)
+    img = gpu_ctx.render(native.make_camera(mat, w, h, focal, snap=False, **kw), native.make_opts(spp=spp))
+    sharp = gpu_ctx.render(native.make_camera(mat, w, h, focal, snap=False), native.make_opts(spp=spp))
+    m = oracle.make_model(scene_unit)
+    acc = np.zeros((w * h, 4), np.float32)
+    for s in range(spp):
+        fb, _, _ = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal, spp_index=s, snap=False, **kw))
+        acc = oracle.accumulate(fb.reshape(-1, 4), acc, s)
+    oracle.release(m)
+    ref = oracle.tonemap(acc).reshape(h, w, 4)
+    assert_image_close(img, ref, 45.0, tol=2e-2)
+    assert np.abs(img - sharp).max() > 0.05
+    one = gpu_ctx.render(native.make_camera(mat, w, h, focal, aperture_size=0.03, focus_z=-1.0))  # plane_z < 0 switches the aperture off
+    assert np.array_equal(one, gpu_ctx.render(native.make_camera(mat, w, h, focal)))
