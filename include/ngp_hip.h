@@ -144,6 +144,20 @@ NGP_API int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path);
 NGP_API int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress);
 /* the model as currently loaded (pointers in the returned desc are NULL; sizes are valid) */
 NGP_API int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out);
+/* session state a snapshot carries beside the model and the camera (save_snapshot / load_snapshot, src/testbed.cu:5245-5263,
+ * 5395-5418): m_background_color, m_exposure, m_sun_dir, m_up_dir, camera scale / aperture_size / autofocus_depth (= m_slice_plane_z).
+ * get: what the loaded snapshot held (valid = 0 when nothing was loaded); set: what the next ngp_save_snapshot_file writes,
+ * together with the camera (matrix12 may be NULL to leave the camera as it is). */
+typedef struct ngp_session_state {
+	int32_t valid;
+	float background_color[4];
+	float exposure;
+	float sun_dir[3], up_dir[3];
+	float camera_scale, aperture_size, autofocus_depth;
+} ngp_session_state;
+NGP_API int ngp_get_session_state(const ngp_ctx* ctx, ngp_session_state* out);
+NGP_API int ngp_set_session_state(ngp_ctx* ctx, const ngp_session_state* state, const float* matrix12, const float* relative_focal_length2, int32_t fov_axis,
+                                  const float* screen_center2, float zoom);
 /* camera stored in the snapshot: m_camera, relative focal length, fov axis, screen center, zoom */
 NGP_API int ngp_get_snapshot_camera(const ngp_ctx* ctx, float* matrix12, float* relative_focal_length2, int32_t* fov_axis, float* screen_center2, float* zoom);
 

@@ -630,6 +630,26 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 
 	ctx->dataset = ds;
 	ctx->has_snapshot_camera = false;
+	{ // src/testbed.cu:5395-5418
+		ngp_session_state& st = ctx->session;
+		st = ngp_session_state{};
+		st.valid = 1;
+		st.background_color[3] = 1.f;
+		st.sun_dir[0] = st.sun_dir[1] = st.sun_dir[2] = 0.57735026f;
+		st.up_dir[1] = 1.f;
+		st.camera_scale = 1.5f;
+		memcpy(st.up_dir, ds.up, sizeof(st.up_dir));
+		if (snap.contains("background_color")) read_vec(snap.at("background_color"), st.background_color, 4);
+		st.exposure = (float)snap.value("exposure", 0.0);
+		if (snap.contains("sun_dir")) read_vec(snap.at("sun_dir"), st.sun_dir, 3);
+		if (snap.contains("up_dir")) read_vec(snap.at("up_dir"), st.up_dir, 3);
+		if (snap.contains("camera")) {
+			const mj::Value& cam = snap.at("camera");
+			st.camera_scale = (float)cam.value("scale", 1.5);
+			st.aperture_size = (float)cam.value("aperture_size", 0.0);
+			st.autofocus_depth = (float)cam.value("autofocus_depth", 0.0);
+		}
+	}
 	if (snap.contains("camera")) {
 		const mj::Value& cam = snap.at("camera");
 		if (cam.contains("matrix")) {
@@ -1174,9 +1194,19 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 		raabb["max"] = write_vec(d.render_aabb_max, 3);
 		snap["render_aabb"] = raabb;
 		snap["render_aabb_to_local"] = write_mat(d.render_aabb_to_local, 3, 3);
-		snap["up_dir"] = write_vec(ctx->dataset.up, 3);
+		snap["up_dir"] = write_vec(ctx->session.valid ? ctx->session.up_dir : ctx->dataset.up, 3);
+		if (ctx->session.valid) { // src/testbed.cu:5249-5251
+			snap["sun_dir"] = write_vec(ctx->session.sun_dir, 3);
+			snap["exposure"] = mj::Value::make_float(ctx->session.exposure);
+			snap["background_color"] = write_vec(ctx->session.background_color, 4);
+		}
 		if (ctx->has_snapshot_camera) {
 			mj::Value cam = mj::Value::make_object();
+			if (ctx->session.valid) {
+				cam["scale"] = mj::Value::make_float(ctx->session.camera_scale);
+				cam["aperture_size"] = mj::Value::make_float(ctx->session.aperture_size);
+				cam["autofocus_depth"] = mj::Value::make_float(ctx->session.autofocus_depth);
+			}
 			cam["matrix"] = write_mat(ctx->snap_camera, 4, 3);
 			cam["fov_axis"] = mj::Value::make_int(ctx->snap_fov_axis);
 			cam["relative_focal_length"] = write_vec(ctx->snap_relative_focal_length, 2);
@@ -1204,6 +1234,27 @@ int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out) {
 	*out = ctx->desc;
 	out->n_params = ctx->params.size();
 	out->n_density_grid = ctx->density_grid.size();
+	return 0;
+}
+
+int ngp_get_session_state(const ngp_ctx* ctx, ngp_session_state* out) {
+	if (!ctx || !out) return -1;
+	*out = ctx->session;
+	return 0;
+}
+
+int ngp_set_session_state(ngp_ctx* ctx, const ngp_session_state* state, const float* matrix12, const float* rfl2, int32_t fov_axis, const float* sc2, float zoom) {
+	if (!ctx || !state) return -1;
+	ctx->session = *state;
+	ctx->session.valid = 1;
+	if (matrix12) {
+		memcpy(ctx->snap_camera, matrix12, sizeof(float) * 12);
+		if (rfl2) memcpy(ctx->snap_relative_focal_length, rfl2, sizeof(float) * 2);
+		if (sc2) memcpy(ctx->snap_screen_center, sc2, sizeof(float) * 2);
+		ctx->snap_fov_axis = fov_axis;
+		ctx->snap_zoom = zoom;
+		ctx->has_snapshot_camera = true;
+	}
 	return 0;
 }
 

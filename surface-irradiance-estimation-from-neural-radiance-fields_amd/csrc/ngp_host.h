@@ -109,6 +109,7 @@ struct ngp_ctx {
 
 	// ---- snapshot extras (src/testbed.cu:5396-5424) and dataset
 	mj::Value config; // network config (+ "snapshot" on load)
+	ngp_session_state session{}; // background, exposure, sun / up direction, camera scale / aperture / focus of the snapshot
 	bool has_snapshot_camera = false;
 	float snap_camera[12];
 	float snap_relative_focal_length[2] = {1.f, 1.f};

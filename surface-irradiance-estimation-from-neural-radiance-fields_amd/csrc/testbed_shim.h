@@ -92,6 +92,16 @@ public:
 		check(ngp_load_snapshot_file(m_ctx, path.c_str()));
 		if (m_testbed_mode != ETestbedMode::Geometry) m_testbed_mode = ETestbedMode::Nerf;
 		sync_model_state();
+		ngp_session_state st{};
+		if (ngp_get_session_state(m_ctx, &st) == 0 && st.valid) { // src/testbed.cu:5395-5418
+			memcpy(m_background_color.data(), st.background_color, 16);
+			m_exposure = st.exposure;
+			memcpy(m_sun_dir.data(), st.sun_dir, 12);
+			memcpy(m_up_dir.data(), st.up_dir, 12);
+			m_scale = st.camera_scale;
+			m_aperture_size = st.aperture_size;
+			m_slice_plane_z = st.autofocus_depth;
+		}
 		float m[12], rfl[2], sc[2], zoom;
 		int32_t axis;
 		if (ngp_get_snapshot_camera(m_ctx, m, rfl, &axis, sc, &zoom) == 0) { // src/testbed.cu:5404-5420
@@ -104,6 +114,16 @@ public:
 	}
 	void save_snapshot(const std::string& path, bool include_optimizer_state = false, bool compress = true) {
 		(void)include_optimizer_state; // inference state only
+		ngp_session_state st{}; // src/testbed.cu:5245-5263: the session travels with the model
+		st.valid = 1;
+		memcpy(st.background_color, m_background_color.data(), 16);
+		st.exposure = m_exposure;
+		memcpy(st.sun_dir, m_sun_dir.data(), 12);
+		memcpy(st.up_dir, m_up_dir.data(), 12);
+		st.camera_scale = m_scale;
+		st.aperture_size = m_aperture_size;
+		st.autofocus_depth = m_slice_plane_z;
+		check(ngp_set_session_state(m_ctx, &st, m_camera.data(), m_relative_focal_length.data(), m_fov_axis, m_screen_center.data(), m_zoom));
 		check(ngp_save_snapshot_file(m_ctx, path.c_str(), compress ? 1 : 0));
 	}
 	// src/testbed_nerf.cu:2772 (the stream argument is the context's); n = 0 / 0 selects training_prep_nerf's schedule

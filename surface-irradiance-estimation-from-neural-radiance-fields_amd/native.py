@@ -56,6 +56,13 @@ class RenderOpts(C.Structure):
     ]
 
 
+class SessionState(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int32), ("background_color", C.c_float * 4), ("exposure", C.c_float), ("sun_dir", C.c_float * 3), ("up_dir", C.c_float * 3),
+        ("camera_scale", C.c_float), ("aperture_size", C.c_float), ("autofocus_depth", C.c_float),
+    ]
+
+
 class GeometryOpts(C.Structure):
     _fields_ = [
         ("sun_dir", C.c_float * 3), ("up_dir", C.c_float * 3),
@@ -113,6 +120,8 @@ def load_library():
     L.ngp_set_cone_angle_constant.argtypes = [vp, C.c_float]
     L.ngp_set_render_aabb.argtypes = [vp, vp, vp, vp]
     L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ngp_get_session_state.argtypes = [vp, C.POINTER(SessionState)]
+    L.ngp_set_session_state.argtypes = [vp, C.POINTER(SessionState), vp, vp, C.c_int32, vp, C.c_float]
     L.ngp_load_training_data.argtypes = [vp, C.c_char_p]
     L.ngp_n_training_views.argtypes = [vp]
     L.ngp_get_training_view.argtypes = [vp, ip, vp, vp, vp, vp]
@@ -256,6 +265,16 @@ class Context:
         d = ModelDesc()
         self._check(self.L.ngp_get_model(self.h, C.byref(d)))
         return d
+
+    def session_state(self):
+        st = SessionState()
+        self._check(self.L.ngp_get_session_state(self.h, C.byref(st)))
+        return st
+
+    def set_session_state(self, st, matrix_3x4=None, relative_focal_length=(1.0, 1.0), fov_axis=1, screen_center=(0.5, 0.5), zoom=1.0):
+        m = None if matrix_3x4 is None else np.ascontiguousarray(np.asarray(matrix_3x4, np.float32).T.reshape(-1))
+        rfl = np.asarray(relative_focal_length, np.float32); sc = np.asarray(screen_center, np.float32)
+        self._check(self.L.ngp_set_session_state(self.h, C.byref(st), _p(m) if m is not None else None, _p(rfl), fov_axis, _p(sc), zoom))
 
     def snapshot_camera(self):
         m = np.zeros(12, np.float32); rfl = np.zeros(2, np.float32); sc = np.zeros(2, np.float32)

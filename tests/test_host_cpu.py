@@ -200,6 +200,41 @@ def test_snapshot_formats_roundtrip(tmp_path, native):
     ctx.close()
 
 
+def test_snapshot_session_state_roundtrip(tmp_path, native):
+    """save_snapshot / load_snapshot carry the session (src/testbed.cu:5245-5263, 5395-5418): background, exposure, sun / up
+    direction, camera with scale / aperture / autofocus depth -- under the reference's key names."""
+    import msgpack
+
+    sc = pkg("synthetic").make_scene(aabb_scale=1, seed=3, log2_hashmap_size=12)
+    ctx = native.Context(-1)
+    ctx.set_model(sc)
+    assert ctx.session_state().valid == 0
+    st = native.SessionState()
+    st.background_color[:] = [0.1, 0.2, 0.3, 0.5]
+    st.exposure = 1.25
+    st.sun_dir[:] = [0.0, 0.6, 0.8]
+    st.up_dir[:] = [0.0, 0.0, 1.0]
+    st.camera_scale, st.aperture_size, st.autofocus_depth = 2.5, 0.04, 0.7
+    cam = pkg("scene").orbit_camera(33.0)
+    ctx.set_session_state(st, cam, relative_focal_length=(1.3, 1.3), fov_axis=0, screen_center=(0.45, 0.55), zoom=1.5)
+    p = str(tmp_path / "session.msgpack")
+    ctx.save_snapshot_file(p, compress=False)
+    snap = msgpack.unpackb(open(p, "rb").read(), raw=False)["snapshot"]
+    assert np.allclose(snap["background_color"], [0.1, 0.2, 0.3, 0.5]) and abs(snap["exposure"] - 1.25) < 1e-7
+    assert np.allclose(snap["sun_dir"], [0.0, 0.6, 0.8]) and np.allclose(snap["up_dir"], [0.0, 0.0, 1.0])
+    c = snap["camera"]
+    assert abs(c["scale"] - 2.5) < 1e-7 and abs(c["aperture_size"] - 0.04) < 1e-7 and abs(c["autofocus_depth"] - 0.7) < 1e-7
+    assert c["fov_axis"] == 0 and abs(c["zoom"] - 1.5) < 1e-7 and np.allclose(c["screen_center"], [0.45, 0.55])
+    ctx2 = native.Context(-1)
+    ctx2.load_snapshot_file(p)
+    s2 = ctx2.session_state()
+    assert s2.valid == 1 and np.allclose(list(s2.background_color), [0.1, 0.2, 0.3, 0.5]) and abs(s2.exposure - 1.25) < 1e-7
+    assert np.allclose(list(s2.sun_dir), [0.0, 0.6, 0.8]) and np.allclose(list(s2.up_dir), [0.0, 0.0, 1.0])
+    assert abs(s2.camera_scale - 2.5) < 1e-7 and abs(s2.aperture_size - 0.04) < 1e-7 and abs(s2.autofocus_depth - 0.7) < 1e-7
+    c2 = ctx2.snapshot_camera()
+    assert np.allclose(c2["matrix"], cam, atol=1e-7) and c2["fov_axis"] == 0 and np.allclose(c2["relative_focal_length"], [1.3, 1.3]) and abs(c2["zoom"] - 1.5) < 1e-7
+
+
 def test_model_validation(native):
     sc = pkg("synthetic").make_scene(aabb_scale=1, seed=5, log2_hashmap_size=12)
     ctx = native.Context(-1)

@@ -115,6 +115,21 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     with pytest.raises(RuntimeError, match="training images"):
         testbed.render(8, 8, 1, True)
     testbed.render_ground_truth = False
+    # the session travels with the snapshot (src/testbed.cu:5245-5263, 5395-5418)
+    testbed.exposure = 0.75
+    testbed.background_color = [0.2, 0.1, 0.4, 1.0]
+    testbed.sun_dir = [0.0, 0.6, 0.8]
+    testbed.aperture_size = 0.0
+    saved = str(tmp_path / "with_session.ingp")
+    testbed.save_snapshot(saved, False)
+    t3 = pyngp.Testbed()
+    t3.load_snapshot(saved)
+    assert abs(t3.exposure - 0.75) < 1e-6 and np.allclose(t3.background_color, [0.2, 0.1, 0.4, 1.0]) and np.allclose(t3.sun_dir, [0.0, 0.6, 0.8])
+    assert np.allclose(t3.camera_matrix, testbed.camera_matrix) and t3.fov_axis == testbed.fov_axis and abs(t3.fov - testbed.fov) < 1e-4
+    # (settings a snapshot does not store -- pixel-centre snapping, the transmittance threshold -- are set by hand, as in the reference)
+    t3.snap_to_pixel_centers = testbed.snap_to_pixel_centers
+    t3.nerf.render_min_transmittance = testbed.nerf.render_min_transmittance
+    assert np.array_equal(t3.render(64, 36, 1, True), testbed.render(64, 36, 1, True))
     testbed.render_mode = pyngp.RenderMode.Normals
     with pytest.raises(RuntimeError, match="render modes supported"):
         testbed.render(8, 8, 1, True)
