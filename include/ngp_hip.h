@@ -49,7 +49,7 @@ typedef struct ngp_model_desc {
 	/* tcnn HashGrid encoding */
 	uint32_t n_levels;
 	uint32_t n_features_per_level;
-	uint32_t log2_hashmap_size;
+	uint32_t log2_hashmap_size; /* 31 = tcnn DenseGrid: no level is ever hashed or capped */
 	uint32_t base_resolution;
 	float per_level_scale; /* explicit: the fork derives it with aabb_scale = 1, src/testbed.cu:3959-3966 */
 	/* tcnn FullyFusedMLP density / rgb heads (nerf_network.h:81-101) */

@@ -151,6 +151,7 @@ void build_levels(const ngp_model_desc& d, LevelInfo* lv, uint32_t* total_entrie
 		lv[l].hashed = n < stride ? 1u : 0u;
 		lv[l].mask = (n & (n - 1)) == 0 ? n - 1 : 0u;
 		lv[l].pad0 = 0;
+		if ((uint64_t)offset + n > 0x1FFFFFFFull) throw std::runtime_error("grid encoding too large for 32-bit gather offsets (more than 2^29 entries)");
 		offset += n;
 	}
 	*total_entries = offset;
@@ -270,7 +271,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json "
 		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64x2 hidden)");
 	}
-	if (d.log2_hashmap_size > 28 || d.base_resolution == 0 || !(d.per_level_scale > 0.f)) throw std::runtime_error("invalid hash grid configuration");
+	if ((d.log2_hashmap_size > 28 && d.log2_hashmap_size != 31) || d.base_resolution == 0 || !(d.per_level_scale > 0.f)) throw std::runtime_error("invalid hash grid configuration");
 	if (d.aabb_scale == 0 || (d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error("NeRF dataset's `aabb_scale` must be a power of two"); // testbed_nerf.cu:2707
 	if (d.aabb_scale > (1u << (NERF_CASCADES - 1))) throw std::runtime_error("NeRF dataset must have `aabb_scale <= 128`"); // :2711-2718
 
@@ -550,11 +551,23 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 	const mj::Value& rgb = root.at("rgb_network");
 	std::string otype = enc.value("otype", "OneBlob");
 	for (auto& ch : otype) ch = (char)tolower(ch);
-	if (otype.find("grid") == std::string::npos) throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid only)");
+	// tcnn GridEncoding: HashGrid, or DenseGrid (every level x + y*res + z*res^2, never hashed, not capped by a hash-map size) --
+	// the latter is the former with a hash map that no level ever fills, which is how it is carried here (log2 = 31).
+	// TiledGrid wraps coordinates per axis and drops axes whose stride exceeds the tile: not implemented.
+	bool dense_grid = false;
+	if (otype == "densegrid") dense_grid = true;
+	else if (otype == "grid") {
+		std::string gt = enc.value("type", "Hash");
+		for (auto& ch : gt) ch = (char)tolower(ch);
+		if (gt == "dense") dense_grid = true;
+		else if (gt != "hash") throw std::runtime_error("unsupported grid type '" + gt + "' (Hash and Dense are implemented)");
+	} else if (otype != "hashgrid") {
+		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid and DenseGrid are implemented)");
+	}
 	d.n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2.0);
 	d.n_levels = enc.contains("n_features") && enc.at("n_features").num() > 0 ? (uint32_t)enc.at("n_features").num() / d.n_features_per_level
 	                                                                           : (uint32_t)enc.value("n_levels", 16.0);
-	d.log2_hashmap_size = (uint32_t)enc.value("log2_hashmap_size", 15.0);
+	d.log2_hashmap_size = dense_grid ? 31u : (uint32_t)enc.value("log2_hashmap_size", 15.0);
 	d.base_resolution = (uint32_t)enc.value("base_resolution", 0.0);
 	if (!d.base_resolution) d.base_resolution = 1u << (d.log2_hashmap_size / 3); // testbed.cu:3945-3949
 
@@ -1129,10 +1142,10 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
 		if (!root.contains("encoding")) {
 			mj::Value e = mj::Value::make_object();
-			e["otype"] = mj::Value::make_string("HashGrid");
+			e["otype"] = mj::Value::make_string(d.log2_hashmap_size == 31 ? "DenseGrid" : "HashGrid");
 			e["n_levels"] = mj::Value::make_uint(d.n_levels);
 			e["n_features_per_level"] = mj::Value::make_uint(d.n_features_per_level);
-			e["log2_hashmap_size"] = mj::Value::make_uint(d.log2_hashmap_size);
+			if (d.log2_hashmap_size != 31) e["log2_hashmap_size"] = mj::Value::make_uint(d.log2_hashmap_size);
 			e["base_resolution"] = mj::Value::make_uint(d.base_resolution);
 			root["encoding"] = e;
 			auto mlp = [&](uint32_t hidden) {

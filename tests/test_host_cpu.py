@@ -200,6 +200,43 @@ def test_snapshot_formats_roundtrip(tmp_path, native):
     ctx.close()
 
 
+def _dense_scene():
+    S = pkg("scene")
+    cfg = S.base_network_config()
+    cfg["encoding"] = dict(cfg["encoding"], otype="DenseGrid", base_resolution=4, per_level_scale=1.5)
+    return pkg("synthetic").make_scene(aabb_scale=1, seed=77, log2_hashmap_size=31, cfg=cfg)
+
+
+def test_snapshot_dense_and_unsupported_encodings(tmp_path, native):
+    """tcnn's GridEncoding family (create_grid_encoding, dependencies/tiny-cuda-nn encodings/grid.h): HashGrid and DenseGrid
+    (no level is ever hashed) are implemented; TiledGrid and non-grid position encodings are refused at load."""
+    import msgpack
+
+    sc = _dense_scene()
+    offs, res, _ = pkg("scene").grid_layout(sc["encoding"])
+    assert all(o2 - o1 >= r ** 3 for o1, o2, r in zip(offs, offs[1:], res))  # every level holds its full lattice
+    ctx = native.Context(-1)
+    ctx.set_model(sc)
+    p = str(tmp_path / "dense.msgpack")
+    ctx.save_snapshot_file(p)
+    root = msgpack.unpackb(open(p, "rb").read(), raw=False)
+    assert root["encoding"]["otype"] == "DenseGrid" and "log2_hashmap_size" not in root["encoding"]
+    ctx2 = native.Context(-1)
+    ctx2.load_snapshot_file(p)
+    d = ctx2.get_model()
+    assert d.log2_hashmap_size == 31 and d.n_params == sc["params"].size and d.base_resolution == 4
+    # the generic spelling tcnn also accepts: otype Grid + type Dense
+    root["encoding"]["otype"], root["encoding"]["type"] = "Grid", "Dense"
+    ctx2.load_snapshot_bytes(msgpack.packb(root, use_bin_type=True))
+    assert ctx2.get_model().log2_hashmap_size == 31
+    for enc in ({"otype": "TiledGrid"}, {"otype": "Grid", "type": "Tiled"}, {"otype": "Frequency"}):
+        bad = dict(root, encoding=dict(root["encoding"], **enc))
+        with pytest.raises(RuntimeError, match="unsupported (encoding|grid type)"):
+            ctx2.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    ctx2.close()
+    ctx.close()
+
+
 def test_snapshot_session_state_roundtrip(tmp_path, native):
     """save_snapshot / load_snapshot carry the session (src/testbed.cu:5245-5263, 5395-5418): background, exposure, sun / up
     direction, camera with scale / aperture / autofocus depth -- under the reference's key names."""

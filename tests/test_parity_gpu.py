@@ -59,6 +59,26 @@ def test_grid_encode_bit_exact(which, gpu_ctx, oracle, scene_unit, scene_big):
     oracle.release(m)
 
 
+def test_dense_grid_encoding(gpu_ctx, oracle, native, scene_mod):
+    """tcnn DenseGrid (log2_hashmap_size 31 on the ABI): no level is hashed, every level is a padded lattice."""
+    from conftest import _with_bitfield, pkg
+
+    cfg = scene_mod.base_network_config()
+    cfg["encoding"] = dict(cfg["encoding"], otype="DenseGrid", base_resolution=4, per_level_scale=1.5)
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=77, log2_hashmap_size=31, cfg=cfg))
+    gpu_ctx.set_model(sc)
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(8)
+    pos = rng.uniform(0, 1, (8192, 3)).astype(np.float32)
+    pos[:4] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0.999999, 1e-7, 1.0]]
+    pos[64:128] = rng.uniform(-1, 2, (64, 3)).astype(np.float32)
+    assert np.array_equal(gpu_ctx.grid_encode(pos).astype(np.float32), oracle.grid_encode(m, pos).astype(np.float32))
+    oracle.release(m)
+    img, depth, st, ref, db, ost = _render_both(gpu_ctx, oracle, native, scene_mod, sc, 128, 72, 35.0)
+    assert st["n_rays_hit"] > 500 and abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 3
+    assert_image_close(img, ref, 50.0)
+
+
 def test_grid_encode_ragged_sizes(gpu_ctx, oracle, scene_unit):
     gpu_ctx.set_model(scene_unit)
     m = oracle.make_model(scene_unit)
