@@ -249,6 +249,70 @@ NGP_API int ngp_get_envmap(ngp_ctx* ctx, uint32_t* n_theta, uint32_t* n_phi, flo
 /* E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi/(n_theta n_phi): host normals n x 3 -> host rgb n x 3 */
 NGP_API int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_out);
 
+
+/* --- training: Testbed::reset_network (src/testbed.cu:3820-4210), Testbed::train (:4364-4470),
+ * Testbed::train_nerf / train_nerf_step (src/testbed_nerf.cu:2949-3431), training_prep_nerf (:3432-3446). The default
+ * path of configs/nerf/base.json: no envmap, no camera / exposure / latent optimisation, no error-map sampling,
+ * no depth supervision. */
+enum ngp_loss_type { NGP_LOSS_L2 = 0, NGP_LOSS_L1, NGP_LOSS_MAPE, NGP_LOSS_SMAPE, NGP_LOSS_HUBER, NGP_LOSS_LOGL1, NGP_LOSS_RELATIVE_L2 }; /* ELossType, common.h:84-92 */
+enum ngp_image_type { NGP_IMAGE_NONE = 0, NGP_IMAGE_BYTE = 1, NGP_IMAGE_HALF = 2, NGP_IMAGE_FLOAT = 3 };                                    /* EImageDataType */
+typedef struct ngp_training_opts {
+	uint32_t struct_size;
+	int32_t loss_type;              /* m_nerf.training.loss_type; configs/nerf/base.json: Huber */
+	int32_t random_bg_color;        /* nerf.h defaults: true */
+	int32_t linear_colors;          /* false */
+	int32_t snap_to_pixel_centers;  /* true */
+	float near_distance;            /* 0.1 */
+	float density_grid_decay;       /* 0.95 */
+	int32_t train_network, train_encoding; /* m_train_network / m_train_encoding -> optimize_matrix_params / optimize_non_matrix_params */
+	/* configs/nerf/base.json "optimizer": Ema{decay} > ExponentialDecay{decay_start, decay_interval, decay_base} > Adam */
+	float learning_rate, beta1, beta2, epsilon, l2_reg;
+	float ema_decay;                /* 0: no Ema, inference uses the training parameters */
+	uint32_t decay_start, decay_interval;
+	float decay_base;
+	float background_color[3];      /* m_background_color.rgb() when !random_bg_color */
+	int32_t color_space;            /* m_color_space: 0 Linear, 1 SRGB */
+} ngp_training_opts;
+typedef struct ngp_training_state {
+	uint32_t struct_size;
+	uint32_t training_step;                          /* m_training_step */
+	uint32_t rays_per_batch;                         /* counters_rgb.rays_per_batch */
+	uint32_t measured_batch_size;                    /* samples after compaction in the last step */
+	uint32_t measured_batch_size_before_compaction;  /* samples marched in the last step */
+	uint32_t n_rays_total;
+	float loss;                                      /* m_loss_scalar.val(): refreshed every 16th step like Testbed::train */
+	float learning_rate;                             /* Adam's rate after ExponentialDecay */
+	uint64_t n_params, n_matrix_params;
+} ngp_training_state;
+/* Testbed::reset_network for configs/nerf/base.json: fresh random parameters (xavier-uniform matrices, grid in
+ * +-1e-4, pcg32 seeded with `seed`; the reference's m_seed is 1337), an empty occupancy grid, training counters at 0.
+ * The boxes and aabb_scale come from the loaded dataset (ngp_load_training_data) or, without one, aabb_scale 1. */
+NGP_API int ngp_reset_network(ngp_ctx* ctx, uint32_t log2_hashmap_size, uint64_t seed);
+NGP_API void ngp_default_training_opts(ngp_training_opts* opts);
+NGP_API int ngp_set_training_opts(ngp_ctx* ctx, const ngp_training_opts* opts);
+NGP_API int ngp_get_training_opts(const ngp_ctx* ctx, ngp_training_opts* opts);
+/* NerfDataset::set_training_image (src/nerf_loader.cu:745-): pixels of training view `view`, RGBA, NGP_IMAGE_BYTE
+ * (sRGB, straight alpha) or NGP_IMAGE_FLOAT (linear, premultiplied -- python_api.cu nerf.training.set_image);
+ * width/height replace the view's resolution */
+NGP_API int ngp_set_training_image(ngp_ctx* ctx, int view, int32_t width, int32_t height, const void* rgba, int32_t image_type);
+/* n_steps x Testbed::train(batch_size): occupancy-grid refresh on training_prep_nerf's schedule, one train_nerf_step,
+ * the optimizer, the counters; loss_out (nullable) receives the running loss. batch_size: a multiple of 128, 2^18 in the
+ * reference's GUI and scripts/run.py */
+NGP_API int ngp_train(ngp_ctx* ctx, uint32_t n_steps, uint32_t batch_size, float* loss_out);
+NGP_API int ngp_get_training_state(const ngp_ctx* ctx, ngp_training_state* out);
+/* The pieces of one step, for parity tests against the oracle. ngp_train_prepare_batch: sample generation + network +
+ * loss for the current step (no parameter changes); the buffers (host pointers, nullable) receive ray_indices[n_rays],
+ * numsteps[n_rays][2] (after compaction), coords_compacted[target][7], dloss fp16 [target][4], loss[n_rays];
+ * counters3 = {samples marched, rays kept, samples after compaction}. ngp_train_gradients: the fused backward on that
+ * batch, gradient of every parameter in snapshot order (loss-scaled by 128 like the reference). ngp_train_apply: the
+ * optimizer step on the gradient currently held + the step bookkeeping. */
+NGP_API int ngp_train_prepare_batch(ngp_ctx* ctx, uint32_t batch_size, uint32_t* counters3, uint32_t* ray_indices, uint32_t* numsteps, float* coords_compacted,
+                                    uint16_t* dloss_fp16, float* loss);
+NGP_API int ngp_train_gradients(ngp_ctx* ctx, uint32_t batch_size, float* grad_out /* n_params */);
+NGP_API int ngp_train_apply(ngp_ctx* ctx);
+/* current training parameters (fp32 master copy) and their Ema (fp16 -> fp32), n_params each, nullable */
+NGP_API int ngp_get_training_params(ngp_ctx* ctx, float* params_out, float* ema_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,30 @@ void orc_pcg32_advance(orc_pcg32* r, uint64_t delta);
 void orc_update_density_grid(const orc_nerf_model* m, float* grid, uint32_t max_cascade, orc_pcg32* rng, uint32_t* ema_step, float decay, uint32_t n_uniform,
                              uint32_t n_nonuniform);
 
+/* ---- training step, orc_nerf.c */
+typedef struct orc_train_image { /* TrainingImageMetadata + TrainingXForm, the fields the default path reads */
+	const void* pixels; /* RGBA: uint8 sRGB straight alpha (type 1) or float linear premultiplied (type 3) */
+	int32_t type;
+	int32_t res[2];
+	float focal[2];
+	float principal[2];
+	int32_t lens_mode;
+	float lens_params[7];
+	float xform[12];
+} orc_train_image;
+typedef struct orc_train_opts {
+	uint32_t n_rays, n_images;
+	orc_pcg32 rng;
+	int32_t snap_to_pixel_centers, random_bg_color, linear_colors, color_space, loss_type;
+	float background[3];
+	float near_distance, loss_scale, density_grid_mean;
+} orc_train_opts;
+uint32_t orc_train_generate_samples(const orc_nerf_model* m, const orc_train_image* images, const orc_train_opts* o, uint32_t max_samples, uint32_t* numsteps,
+                                    uint32_t* base_out, float* rays6, float* coords);
+void orc_train_loss(const orc_nerf_model* m, const orc_train_image* images, const orc_train_opts* o, const uint32_t* numsteps, const uint32_t* base_in,
+                    const float* rays6, const float* coords, const uint16_t* network_output, uint32_t* compacted_numsteps, float* loss_out, uint16_t* dloss);
+
+
 /* sampling sequences, random_val.cuh:207-370 */
 float orc_ld_random_val(uint32_t index, uint32_t seed, uint32_t dim);
 void orc_ld_random_pixel_offset(uint32_t spp, float* out2);

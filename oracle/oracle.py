@@ -115,6 +115,21 @@ PAYLOAD_DTYPE = np.dtype(
 assert PAYLOAD_DTYPE.itemsize == 40
 
 
+class Pcg32(C.Structure):
+    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64)]
+
+
+class TrainImage(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("type", C.c_int32), ("res", C.c_int32 * 2), ("focal", C.c_float * 2), ("principal", C.c_float * 2),
+                ("lens_mode", C.c_int32), ("lens_params", C.c_float * 7), ("xform", C.c_float * 12)]
+
+
+class TrainOpts(C.Structure):
+    _fields_ = [("n_rays", C.c_uint32), ("n_images", C.c_uint32), ("rng", Pcg32), ("snap_to_pixel_centers", C.c_int32), ("random_bg_color", C.c_int32),
+                ("linear_colors", C.c_int32), ("color_space", C.c_int32), ("loss_type", C.c_int32), ("background", C.c_float * 3),
+                ("near_distance", C.c_float), ("loss_scale", C.c_float), ("density_grid_mean", C.c_float)]
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -438,3 +453,58 @@ class Oracle:
         db = np.zeros(n, np.float32)
         self.lib.orc_render_mesh(h, C.byref(cam), C.byref(opts), _ptr(fb), _ptr(db))
         return fb.reshape(cam.height, cam.width, 4), db.reshape(cam.height, cam.width)
+
+    # ------------------------------------------------------------------ training step
+    def train_rng(self, seed=1337, n_advances=0):
+        """m_rng of training step `n_advances`: default_rng_t{seed}, one draw for the density-grid generator, one advance() per step."""
+        r = Pcg32()
+        self.lib.orc_pcg32_seed.argtypes = [C.POINTER(Pcg32), C.c_uint64, C.c_uint64]
+        self.lib.orc_pcg32_next_uint.argtypes = [C.POINTER(Pcg32)]
+        self.lib.orc_pcg32_advance.argtypes = [C.POINTER(Pcg32), C.c_uint64]
+        self.lib.orc_pcg32_seed(C.byref(r), seed, 1)
+        self.lib.orc_pcg32_next_uint(C.byref(r))
+        for _ in range(n_advances):
+            self.lib.orc_pcg32_advance(C.byref(r), 1 << 32)
+        return r
+
+    def make_train_images(self, views):
+        """views: list of dicts {pixels (H, W, 4) uint8 | float32, xform (3, 4), focal (2), principal (2)}."""
+        arr = (TrainImage * len(views))()
+        keep = []
+        for im, v in zip(arr, views):
+            px = np.ascontiguousarray(v["pixels"])
+            keep.append(px)
+            im.pixels = px.ctypes.data
+            im.type = 1 if px.dtype == np.uint8 else 3
+            im.res[0], im.res[1] = px.shape[1], px.shape[0]
+            im.focal[0], im.focal[1] = v["focal"]
+            im.principal[0], im.principal[1] = v.get("principal", (0.5, 0.5))
+            im.lens_mode = 0
+            x = np.asarray(v["xform"], np.float32)
+            for c in range(4):
+                for r in range(3):
+                    im.xform[c * 3 + r] = x[r, c]
+        arr._keep = keep
+        return arr
+
+    def train_generate_samples(self, m, images, opts, max_samples):
+        n = opts.n_rays
+        numsteps, base = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        rays = np.zeros((n, 6), np.float32)
+        coords = np.zeros((max_samples, 7), np.float32)
+        self.lib.orc_train_generate_samples.restype = C.c_uint32
+        self.lib.orc_train_generate_samples.argtypes = [C.POINTER(NerfModel), C.c_void_p, C.POINTER(TrainOpts), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        total = self.lib.orc_train_generate_samples(C.byref(m), C.cast(images, C.c_void_p), C.byref(opts), max_samples, _ptr(numsteps), _ptr(base), _ptr(rays), _ptr(coords))
+        return {"numsteps": numsteps, "base": base, "rays": rays, "coords": coords, "total": total}
+
+    def train_loss(self, m, images, opts, gen, network_output):
+        n = opts.n_rays
+        net = np.ascontiguousarray(network_output).view(np.uint16)
+        compacted = np.zeros(n, np.uint32)
+        loss = np.zeros(n, np.float32)
+        dloss = np.zeros((gen["coords"].shape[0], 4), np.uint16)
+        self.lib.orc_train_loss.restype = None
+        self.lib.orc_train_loss.argtypes = [C.POINTER(NerfModel), C.c_void_p, C.POINTER(TrainOpts)] + [C.c_void_p] * 8
+        self.lib.orc_train_loss(C.byref(m), C.cast(images, C.c_void_p), C.byref(opts), _ptr(gen["numsteps"]), _ptr(gen["base"]), _ptr(gen["rays"]), _ptr(gen["coords"]),
+                                _ptr(net), _ptr(compacted), _ptr(loss), _ptr(dloss))
+        return {"compacted_numsteps": compacted, "loss": loss, "dloss": dloss.view(np.float16)}

@@ -974,3 +974,256 @@ void orc_update_density_grid(const orc_nerf_model* m, float* grid, uint32_t max_
 	++*ema_step;
 	free(tmp);
 }
+
+/* ------------------------------------------------------------------ training step
+ * generate_training_samples_nerf (src/testbed_nerf.cu:737-890) and compute_loss_kernel_train_nerf (:893-1213),
+ * restated for the default path: no envmap, no error-map CDFs, no explicit rays, no random max level, static
+ * cameras, no exposure / depth supervision / sharpness. Rays are processed in index order, so the sample offsets
+ * (`base`) are deterministic here where the reference's atomics are not; tests compare ray by ray. */
+static uint32_t mip_from_dt(float dt, v3 pos, uint32_t max_cascade) { /* nerf_device.cuh:449-458 */
+	uint32_t mip = mip_from_pos(pos, max_cascade);
+	dt *= 2.0f * (float)NERF_GRIDSIZE;
+	if (dt < 1.0f) return mip;
+	int exponent;
+	(void)frexpf(dt, &exponent);
+	int v = (int)mip < exponent ? exponent : (int)mip;
+	if (v > (int)max_cascade) v = (int)max_cascade;
+	return (uint32_t)v;
+}
+static void train_read_pixel(const orc_train_image* im, float u, float v, float* rgba) { /* read_rgba, common_device.cuh:797-829 */
+	int px = (int)(u * (float)im->res[0]), py = (int)(v * (float)im->res[1]);
+	px = px < 0 ? 0 : (px > im->res[0] - 1 ? im->res[0] - 1 : px);
+	py = py < 0 ? 0 : (py > im->res[1] - 1 ? im->res[1] - 1 : py);
+	size_t idx = (size_t)px + (size_t)py * (size_t)im->res[0];
+	if (im->type == 1) {
+		uint32_t raw = ((const uint32_t*)im->pixels)[idx];
+		if (raw == 0x00FF00FFu) { rgba[0] = rgba[1] = rgba[2] = rgba[3] = -1.0f; return; }
+		float a = (float)(raw >> 24) * (1.0f / 255.0f);
+		rgba[0] = orc_srgb_to_linear((float)(raw & 255u) * (1.0f / 255.0f)) * a;
+		rgba[1] = orc_srgb_to_linear((float)((raw >> 8) & 255u) * (1.0f / 255.0f)) * a;
+		rgba[2] = orc_srgb_to_linear((float)((raw >> 16) & 255u) * (1.0f / 255.0f)) * a;
+		rgba[3] = a;
+	} else if (im->type == 3) {
+		for (int k = 0; k < 4; ++k) rgba[k] = ((const float*)im->pixels)[idx * 4 + k];
+	} else {
+		rgba[0] = 5.0f; rgba[1] = 0.0f; rgba[2] = 0.0f; rgba[3] = 1.0f;
+	}
+}
+static void train_uv(orc_pcg32* rng, const orc_train_image* im, int snap, float* u, float* v) { /* nerf_device.cuh:592-615 */
+	*u = pcg32_next_float(rng);
+	*v = pcg32_next_float(rng);
+	if (snap) {
+		int px = (int)(*u * (float)im->res[0]), py = (int)(*v * (float)im->res[1]);
+		px = px < 0 ? 0 : (px > im->res[0] - 1 ? im->res[0] - 1 : px);
+		py = py < 0 ? 0 : (py > im->res[1] - 1 ? im->res[1] - 1 : py);
+		*u = ((float)px + 0.5f) / (float)im->res[0];
+		*v = ((float)py + 0.5f) / (float)im->res[1];
+	}
+}
+static uint32_t train_image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_images) { return ((base_idx * n_images) / n_rays) % n_images; } /* :617-638 */
+
+uint32_t orc_train_generate_samples(const orc_nerf_model* m, const orc_train_image* images, const orc_train_opts* o, uint32_t max_samples, uint32_t* numsteps,
+                                    uint32_t* base_out, float* rays6, float* coords) {
+	const aabb_t aabb = {v3_make(m->aabb_min[0], m->aabb_min[1], m->aabb_min[2]), v3_make(m->aabb_max[0], m->aabb_max[1], m->aabb_max[2])};
+	const v3 diag = v3_sub(aabb.max, aabb.min);
+	uint32_t counter = 0;
+	for (uint32_t i = 0; i < o->n_rays; ++i) {
+		numsteps[i] = 0;
+		base_out[i] = 0;
+		const orc_train_image* im = &images[train_image_idx(i, o->n_rays, o->n_images)];
+		orc_pcg32 rng = o->rng;
+		orc_pcg32_advance(&rng, (uint64_t)(uint32_t)(i * 16u)); /* N_MAX_RANDOM_SAMPLES_PER_RAY */
+		float u, v, px[4];
+		train_uv(&rng, im, o->snap_to_pixel_centers, &u, &v);
+		train_read_pixel(im, u, v, px);
+		if (px[0] < 0.0f) continue;
+		(void)pcg32_next_float(&rng); /* motionblur_time */
+		orc_camera cam;
+		memset(&cam, 0, sizeof(cam));
+		cam.width = im->res[0]; cam.height = im->res[1];
+		cam.focal_length[0] = im->focal[0]; cam.focal_length[1] = im->focal[1];
+		cam.screen_center[0] = im->principal[0]; cam.screen_center[1] = im->principal[1];
+		cam.lens_mode = im->lens_mode;
+		memcpy(cam.lens_params, im->lens_params, sizeof(cam.lens_params));
+		const v3 d_un = m3_mulv(im->xform, lens_direction(&cam, u, v));
+		const v3 org = v3_make(im->xform[9], im->xform[10], im->xform[11]);
+		const v3 d = v3_normalize(d_un);
+		float tmin, tmax;
+		aabb_ray_intersect(&aabb, org, d, &tmin, &tmax);
+		tmin = fmaxf(tmin, 0.0f);
+		const float cone_angle = m->cone_angle_constant;
+		const float startt = advance_n_steps(tmin, cone_angle, pcg32_next_float(&rng));
+		const v3 idir = v3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+		uint32_t j = 0;
+		float t = startt;
+		v3 pos;
+		while (aabb_contains(&aabb, pos = v3_add(org, v3_scale(d, t))) && j < NERF_STEPS) {
+			float dt = calc_dt(t, cone_angle);
+			uint32_t mip = mip_from_dt(dt, pos, m->max_cascade);
+			if (density_grid_occupied_at(pos, m->density_grid_bitfield, mip)) { ++j; t += dt; }
+			else t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+		}
+		if (j == 0) continue;
+		const uint32_t n = j, base = counter;
+		counter += n;
+		if (base + n > max_samples) continue;
+		numsteps[i] = n;
+		base_out[i] = base;
+		rays6[i * 6 + 0] = org.x; rays6[i * 6 + 1] = org.y; rays6[i * 6 + 2] = org.z;
+		rays6[i * 6 + 3] = d_un.x; rays6[i * 6 + 4] = d_un.y; rays6[i * 6 + 5] = d_un.z;
+		float* c = coords + (size_t)base * 7;
+		t = startt;
+		j = 0;
+		while (aabb_contains(&aabb, pos = v3_add(org, v3_scale(d, t))) && j < n) {
+			float dt = calc_dt(t, cone_angle);
+			uint32_t mip = mip_from_dt(dt, pos, m->max_cascade);
+			if (density_grid_occupied_at(pos, m->density_grid_bitfield, mip)) {
+				v3 w = v3_div(v3_sub(pos, aabb.min), diag); /* warp_position */
+				c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = warp_dt(dt);
+				c[4] = (d.x + 1.0f) * 0.5f; c[5] = (d.y + 1.0f) * 0.5f; c[6] = (d.z + 1.0f) * 0.5f;
+				c += 7;
+				++j;
+				t += dt;
+			} else {
+				t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+			}
+		}
+	}
+	return counter;
+}
+
+static void train_loss_and_gradient(float target, float prediction, int type, float* loss, float* grad) { /* nerf_device.cuh:61-142, 640-658 */
+	const float diff = prediction - target, sign = copysignf(1.0f, diff);
+	switch (type) {
+		case 1: *loss = fabsf(diff); *grad = sign; break;
+		case 2: { float den = fabsf(prediction) + 1e-2f; *loss = fabsf(diff) / den; *grad = sign / den; break; }
+		case 3: { float den = 0.5f * (fabsf(prediction) + fabsf(target)) + 1e-2f; *loss = fabsf(diff) / den; *grad = sign / den; break; }
+		case 4: {
+			const float alpha = 0.1f, ad = fabsf(diff);
+			*loss = (ad > alpha ? (ad - 0.5f * alpha) : (0.5f / alpha * diff * diff)) / 5.0f;
+			*grad = (ad > alpha ? (diff > 0.0f ? 1.0f : -1.0f) : (diff / alpha)) / 5.0f;
+			break;
+		}
+		case 5: { float div = fabsf(diff) + 1.0f; *loss = logf(div); *grad = sign / div; break; }
+		case 6: { float den = prediction * prediction + 1e-2f; *loss = diff * diff / den; *grad = 2.0f * diff / den; break; }
+		default: *loss = diff * diff; *grad = 2.0f * diff; break;
+	}
+}
+static float network_to_rgb_derivative(float val, uint32_t act) { /* :214-223 */
+	switch (act) {
+		case ORC_ACT_RELU: return val > 0.0f ? 1.0f : 0.0f;
+		case ORC_ACT_LOGISTIC: { float s = logistic_(val); return s * (1.0f - s); }
+		case ORC_ACT_EXPONENTIAL: return expf(clampf_(val, -10.0f, 10.0f));
+		default: return 1.0f;
+	}
+}
+static float network_to_density_derivative(float val, uint32_t act) { /* :245-254 */
+	switch (act) {
+		case ORC_ACT_RELU: return val > 0.0f ? 1.0f : 0.0f;
+		case ORC_ACT_LOGISTIC: { float s = logistic_(val); return s * (1.0f - s); }
+		case ORC_ACT_EXPONENTIAL: return expf(clampf_(val, -15.0f, 15.0f));
+		default: return 1.0f;
+	}
+}
+
+/* network_output: fp16 x 4 per marched sample (rgb, density logit). Outputs per ray: compacted_numsteps (the prefix
+ * of the ray's samples that receives a gradient), loss; per marched sample: dloss fp16 x 4 at the same index as its
+ * coordinate (rows behind a ray's prefix stay zero). Every ray fits (no target-batch clamp). */
+void orc_train_loss(const orc_nerf_model* m, const orc_train_image* images, const orc_train_opts* o, const uint32_t* numsteps, const uint32_t* base_in,
+                    const float* rays6, const float* coords, const uint16_t* network_output, uint32_t* compacted_numsteps, float* loss_out, uint16_t* dloss) {
+	const v3 amin = v3_make(m->aabb_min[0], m->aabb_min[1], m->aabb_min[2]);
+	const v3 diag = v3_sub(v3_make(m->aabb_max[0], m->aabb_max[1], m->aabb_max[2]), amin);
+	for (uint32_t i = 0; i < o->n_rays; ++i) {
+		compacted_numsteps[i] = 0;
+		loss_out[i] = 0.0f;
+		const uint32_t n = numsteps[i], base = base_in[i];
+		if (n == 0) continue;
+		const float* cin = coords + (size_t)base * 7;
+		const uint16_t* net = network_output + (size_t)base * 4;
+		float T = 1.0f;
+		const float EPSILON = 1e-4f;
+		v3 rgb_ray = v3_make(0.f, 0.f, 0.f);
+		uint32_t cn = 0;
+		for (; cn < n; ++cn) {
+			if (T < EPSILON) break;
+			const uint16_t* q = net + (size_t)cn * 4;
+			v3 rgb = v3_make(network_to_rgb(orc_half_to_float(q[0]), m->rgb_activation), network_to_rgb(orc_half_to_float(q[1]), m->rgb_activation),
+			                 network_to_rgb(orc_half_to_float(q[2]), m->rgb_activation));
+			float dt = unwarp_dt(cin[(size_t)cn * 7 + 3]);
+			float density = network_to_density(orc_half_to_float(q[3]), m->density_activation);
+			float alpha = 1.0f - expf(-density * dt);
+			float weight = alpha * T;
+			rgb_ray = v3_add(rgb_ray, v3_scale(rgb, weight));
+			T *= (1.0f - alpha);
+		}
+		orc_pcg32 rng = o->rng;
+		orc_pcg32_advance(&rng, (uint64_t)(uint32_t)(i * 16u));
+		const orc_train_image* im = &images[train_image_idx(i, o->n_rays, o->n_images)];
+		float u, v;
+		train_uv(&rng, im, o->snap_to_pixel_centers, &u, &v);
+		orc_pcg32_advance(&rng, 1); /* motionblur_time */
+		v3 bg = v3_make(o->background[0], o->background[1], o->background[2]);
+		if (o->random_bg_color) {
+			bg.x = pcg32_next_float(&rng);
+			bg.y = pcg32_next_float(&rng);
+			bg.z = pcg32_next_float(&rng);
+		}
+		bg = v3_make(orc_srgb_to_linear(bg.x), orc_srgb_to_linear(bg.y), orc_srgb_to_linear(bg.z));
+		float tex[4];
+		train_read_pixel(im, u, v, tex);
+		v3 target;
+		if (o->linear_colors || o->color_space == 0) {
+			target = v3_make(tex[0] + (1.0f - tex[3]) * bg.x, tex[1] + (1.0f - tex[3]) * bg.y, tex[2] + (1.0f - tex[3]) * bg.z);
+			if (!o->linear_colors) {
+				target = v3_make(orc_linear_to_srgb(target.x), orc_linear_to_srgb(target.y), orc_linear_to_srgb(target.z));
+				bg = v3_make(orc_linear_to_srgb(bg.x), orc_linear_to_srgb(bg.y), orc_linear_to_srgb(bg.z));
+			}
+		} else {
+			bg = v3_make(orc_linear_to_srgb(bg.x), orc_linear_to_srgb(bg.y), orc_linear_to_srgb(bg.z));
+			if (tex[3] > 0.0f) {
+				target = v3_make(orc_linear_to_srgb(tex[0] / tex[3]) * tex[3] + (1.0f - tex[3]) * bg.x, orc_linear_to_srgb(tex[1] / tex[3]) * tex[3] + (1.0f - tex[3]) * bg.y,
+				                 orc_linear_to_srgb(tex[2] / tex[3]) * tex[3] + (1.0f - tex[3]) * bg.z);
+			} else {
+				target = bg;
+			}
+		}
+		if (cn == n) rgb_ray = v3_add(rgb_ray, v3_scale(bg, T));
+		compacted_numsteps[i] = cn;
+		if (cn == 0) continue;
+		float lx, ly, lz, gx, gy, gz;
+		train_loss_and_gradient(target.x, rgb_ray.x, o->loss_type, &lx, &gx);
+		train_loss_and_gradient(target.y, rgb_ray.y, o->loss_type, &ly, &gy);
+		train_loss_and_gradient(target.z, rgb_ray.z, o->loss_type, &lz, &gz);
+		const v3 lgrad = v3_make(gx, gy, gz);
+		loss_out[i] = ((lx + ly + lz) / 3.0f) / (float)o->n_rays;
+		const float loss_scale = o->loss_scale / (float)o->n_rays;
+		const float output_l2_reg = m->rgb_activation == ORC_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = o->density_grid_mean < 0.01f ? 1e-4f : 0.0f;
+		const v3 ray_o = v3_make(rays6[i * 6 + 0], rays6[i * 6 + 1], rays6[i * 6 + 2]);
+		v3 rgb_ray2 = v3_make(0.f, 0.f, 0.f);
+		T = 1.0f;
+		for (uint32_t j = 0; j < cn; ++j) {
+			const float* c = cin + (size_t)j * 7;
+			const v3 pos = v3_add(v3_mul(v3_make(c[0], c[1], c[2]), diag), amin);
+			const float depth = v3_length(v3_sub(pos, ray_o));
+			const float dt = unwarp_dt(c[3]);
+			const uint16_t* q = net + (size_t)j * 4;
+			const float o0 = orc_half_to_float(q[0]), o1 = orc_half_to_float(q[1]), o2 = orc_half_to_float(q[2]), o3 = orc_half_to_float(q[3]);
+			const v3 rgb = v3_make(network_to_rgb(o0, m->rgb_activation), network_to_rgb(o1, m->rgb_activation), network_to_rgb(o2, m->rgb_activation));
+			const float density = network_to_density(o3, m->density_activation);
+			const float alpha = 1.0f - expf(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray2 = v3_add(rgb_ray2, v3_scale(rgb, weight));
+			T *= (1.0f - alpha);
+			const v3 suffix = v3_sub(rgb_ray, rgb_ray2);
+			const v3 dl = v3_scale(lgrad, weight);
+			uint16_t* out = dloss + (size_t)(base + j) * 4;
+			out[0] = orc_float_to_half(loss_scale * (dl.x * network_to_rgb_derivative(o0, m->rgb_activation) + fmaxf(0.0f, output_l2_reg * o0)));
+			out[1] = orc_float_to_half(loss_scale * (dl.y * network_to_rgb_derivative(o1, m->rgb_activation) + fmaxf(0.0f, output_l2_reg * o1)));
+			out[2] = orc_float_to_half(loss_scale * (dl.z * network_to_rgb_derivative(o2, m->rgb_activation) + fmaxf(0.0f, output_l2_reg * o2)));
+			const float dd = network_to_density_derivative(o3, m->density_activation);
+			const float by_mlp = dd * (dt * v3_dot(lgrad, v3_sub(v3_scale(rgb, T), suffix)));
+			out[3] = orc_float_to_half(loss_scale * by_mlp + (o3 < 0.0f ? -output_l1_reg_density : 0.0f) + (o3 > -10.0f && depth < o->near_distance ? 1e-4f : 0.0f));
+		}
+	}
+}

@@ -244,6 +244,7 @@ void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t
 }
 
 void free_model(ngp_ctx* ctx) {
+	ngp::free_training(ctx);
 	if (ctx->d_params) (void)hipFree(ctx->d_params);
 	if (ctx->d_xgrid) (void)hipFree(ctx->d_xgrid);
 	ctx->d_xgrid = nullptr;
@@ -641,6 +642,9 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 
 	set_model_impl(ctx, d);
 
+	for (auto& v : ctx->dataset.views) // training images of the dataset being replaced
+		if (v.d_pixels) (void)hipFree(v.d_pixels);
+	if (ctx->train) ctx->train->images_dirty = true;
 	ctx->dataset = ds;
 	ctx->has_snapshot_camera = false;
 	{ // src/testbed.cu:5395-5418
@@ -880,6 +884,9 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			ds.views.push_back(std::move(v));
 		}
 	}
+	for (auto& v : ctx->dataset.views) // training images of the dataset being replaced
+		if (v.d_pixels) (void)hipFree(v.d_pixels);
+	if (ctx->train) ctx->train->images_dirty = true;
 	ctx->dataset = std::move(ds);
 	ctx->data_path = path;
 }
@@ -933,6 +940,7 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba_out, float* d_depth_out, hipStream_t stream) {
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
+	ngp::sync_inference_model(ctx);
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
 	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_DEPTH) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, AO, Positions, Depth");
 	if (opts.render_mode > NGP_RENDER_SHADE_ENVMAP && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth) apply to NeRF mode");
@@ -1043,6 +1051,52 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 
 namespace ngp {
 void ensure_sync_buffers(ngp_ctx* ctx) { ensure_frame_buffers(ctx, 0); }
+void install_model(ngp_ctx* ctx, const ngp_model_desc& d) { set_model_impl(ctx, d); }
+uint16_t half_from_float(float f) { return float_to_half(f); }
+void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations) {
+	const uint32_t n_cascades = ctx->max_cascade + 1;
+	const uint32_t n_elements = NERF_GRID_N_CELLS * n_cascades;
+	hipStream_t stream = ctx->stream;
+	if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream)); // frames in flight read the bitfield
+	if (!ctx->d_density_tmp) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_tmp, (size_t)n_elements * sizeof(float)));
+	Pcg32 rng;
+	rng.state = ctx->grid_rng_state;
+	rng.inc = ctx->grid_rng_inc;
+	for (uint32_t it = 0; it < n_iterations; ++it) {
+		uint32_t nu = n_uniform, nn = n_nonuniform;
+		if (nu == 0 && nn == 0) { // training_prep_nerf's schedule (src/testbed_nerf.cu:3441-3445)
+			if (ctx->grid_updates < 256) nu = NERF_GRID_N_CELLS * n_cascades;
+			else nu = nn = NERF_GRID_N_CELLS / 4 * n_cascades;
+		}
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_density_tmp, 0, (size_t)n_elements * sizeof(float), stream));
+		launch_density_grid_update(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, stream);
+		rng.advance();
+		launch_density_grid_update(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f /* NERF_MIN_OPTICAL_THICKNESS */, ctx->d_density_f32, ctx->d_density_tmp, stream);
+		rng.advance();
+		launch_density_grid_ema(n_elements, decay, ctx->d_density_f32, ctx->d_density_tmp, stream);
+		++ctx->grid_ema_step;
+		++ctx->grid_updates;
+	}
+	ctx->grid_rng_state = rng.state;
+	ctx->grid_rng_inc = rng.inc;
+	// update_density_grid_mean_and_bitfield (:2863-2880) + the block summaries the march reads
+	launch_density_grid_to_bitfield(nullptr, 0, ctx->max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield, &ctx->bitfield_mean, stream);
+	launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, stream);
+	ctx->density_grid_host_dirty = true;
+}
+// keep the snapshot copy (fp16, as the reference serialises it) in step
+void refresh_density_grid_host(ngp_ctx* ctx) {
+	if (!ctx->density_grid_host_dirty || ctx->device < 0 || !ctx->model_loaded) return;
+	const uint32_t n_elements = NERF_GRID_N_CELLS * (ctx->max_cascade + 1);
+	std::vector<float> grid(n_elements);
+	NGP_HIP_CHECK(hipMemcpyAsync(grid.data(), ctx->d_density_f32, (size_t)n_elements * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	NGP_HIP_CHECK(hipGetLastError());
+	ctx->density_grid.resize(n_elements);
+	for (uint32_t i = 0; i < n_elements; ++i) ctx->density_grid[i] = float_to_half(grid[i]);
+	ctx->desc.n_density_grid = n_elements;
+	ctx->density_grid_host_dirty = false;
+}
 void load_snapshot_path(ngp_ctx* ctx, const std::string& p) {
 	std::string data = read_file(p);
 	bool compressed = ends_with_ci(p, ".ingp"); // testbed.cu:262-266
@@ -1079,10 +1133,13 @@ ngp_ctx* ngp_create(int device) {
 
 void ngp_destroy(ngp_ctx* ctx) {
 	if (!ctx) return;
-	if (ctx->device < 0) { delete ctx; return; }
+	if (ctx->device < 0) { delete ctx->train; delete ctx; return; }
 	(void)hipSetDevice(ctx->device);
 	if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
 	free_model(ctx);
+	delete ctx->train;
+	for (auto& v : ctx->dataset.views)
+		if (v.d_pixels) (void)hipFree(v.d_pixels);
 	for (auto& m : ctx->meshes) {
 		if (m.d_tris) (void)hipFree(m.d_tris);
 		if (m.d_nodes) (void)hipFree(m.d_nodes);
@@ -1138,6 +1195,8 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 	return guarded(ctx, [&] {
 		if (!ctx->have_desc) throw std::runtime_error("no model to save");
 		if (!path) throw std::runtime_error("null path");
+		ngp::sync_host_params(ctx);
+		ngp::refresh_density_grid_host(ctx);
 		const ngp_model_desc& d = ctx->desc;
 		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
 		if (!root.contains("encoding")) {
@@ -1398,6 +1457,7 @@ int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		if (n == 0) return;
 		if (!pos01 || !out_fp16) throw std::runtime_error("null argument");
 		float* d_pos = nullptr;
@@ -1418,6 +1478,7 @@ int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const fl
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		if (n == 0) return;
 		if (!pos01 || !dir01 || !out_fp16) throw std::runtime_error("null argument");
 		float *d_pos = nullptr, *d_dir = nullptr;
@@ -1441,6 +1502,7 @@ int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean) {
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		if (out) NGP_HIP_CHECK(hipMemcpy(out, ctx->d_bitfield, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, hipMemcpyDeviceToHost));
 		if (out_mean) *out_mean = ctx->bitfield_mean;
 	});
@@ -1478,42 +1540,9 @@ int ngp_update_density_grid(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint3
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
-		const uint32_t n_cascades = ctx->max_cascade + 1;
-		const uint32_t n_elements = NERF_GRID_N_CELLS * n_cascades;
-		hipStream_t stream = ctx->stream;
-		if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream)); // frames in flight read the bitfield
-		if (!ctx->d_density_tmp) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_tmp, (size_t)n_elements * sizeof(float)));
-		Pcg32 rng;
-		rng.state = ctx->grid_rng_state;
-		rng.inc = ctx->grid_rng_inc;
-		for (uint32_t it = 0; it < n_iterations; ++it) {
-			uint32_t nu = n_uniform, nn = n_nonuniform;
-			if (nu == 0 && nn == 0) { // training_prep_nerf's schedule (src/testbed_nerf.cu:3441-3445)
-				if (ctx->grid_updates < 256) nu = NERF_GRID_N_CELLS * n_cascades;
-				else nu = nn = NERF_GRID_N_CELLS / 4 * n_cascades;
-			}
-			NGP_HIP_CHECK(hipMemsetAsync(ctx->d_density_tmp, 0, (size_t)n_elements * sizeof(float), stream));
-			launch_density_grid_update(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, stream);
-			rng.advance();
-			launch_density_grid_update(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f /* NERF_MIN_OPTICAL_THICKNESS */, ctx->d_density_f32, ctx->d_density_tmp, stream);
-			rng.advance();
-			launch_density_grid_ema(n_elements, decay, ctx->d_density_f32, ctx->d_density_tmp, stream);
-			++ctx->grid_ema_step;
-			++ctx->grid_updates;
-		}
-		ctx->grid_rng_state = rng.state;
-		ctx->grid_rng_inc = rng.inc;
-		// update_density_grid_mean_and_bitfield (:2863-2880) + the block summaries the march reads
-		launch_density_grid_to_bitfield(nullptr, 0, ctx->max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield, &ctx->bitfield_mean, stream);
-		launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, stream);
-		// keep the snapshot copy (fp16, as the reference serialises it) in step
-		std::vector<float> grid(n_elements);
-		NGP_HIP_CHECK(hipMemcpyAsync(grid.data(), ctx->d_density_f32, (size_t)n_elements * sizeof(float), hipMemcpyDeviceToHost, stream));
-		NGP_HIP_CHECK(hipStreamSynchronize(stream));
-		NGP_HIP_CHECK(hipGetLastError());
-		ctx->density_grid.resize(n_elements);
-		for (uint32_t i = 0; i < n_elements; ++i) ctx->density_grid[i] = float_to_half(grid[i]);
-		ctx->desc.n_density_grid = n_elements;
+		ngp::sync_inference_model(ctx);
+		ngp::update_density_grid_device(ctx, decay, n_uniform, n_nonuniform, n_iterations);
+		ngp::refresh_density_grid_host(ctx);
 	});
 }
 
@@ -1521,6 +1550,7 @@ int ngp_get_density_grid(ngp_ctx* ctx, float* out, uint64_t n) {
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		const uint64_t n_elements = (uint64_t)NERF_GRID_N_CELLS * (ctx->max_cascade + 1);
 		if (!out || n != n_elements) throw std::runtime_error("density grid holds " + std::to_string(n_elements) + " values");
 		NGP_HIP_CHECK(hipMemcpy(out, ctx->d_density_f32, n_elements * sizeof(float), hipMemcpyDeviceToHost));
@@ -1531,6 +1561,7 @@ int ngp_init_rays(ngp_ctx* ctx, const ngp_camera* cam, void* payloads_out) {
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		if (!cam || !payloads_out) throw std::runtime_error("null argument");
 		const size_t n = (size_t)cam->width * cam->height;
 		NerfPayload* d_p = nullptr;

@@ -5,6 +5,7 @@
 #include "minijson.h"
 #include "ngp_kernels.h"
 #include "pcg32.h"
+#include "train_kernels.h"
 
 #include <hip/hip_runtime.h>
 
@@ -45,6 +46,19 @@ void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t strea
 void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream);
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream);
 
+// kernel launchers, train_kernels.hip
+void launch_train_generate_samples(const ModelParams& M, const TrainStepParams& P, const TrainImage* images, const TrainBatch& B, hipStream_t stream);
+void launch_train_inference(const ModelParams& M, const uint4* frags, const uint32_t* counters, uint32_t max_samples, const float* coords, uint16_t* out, int n_cus,
+                            hipStream_t stream);
+void launch_train_loss(const ModelParams& M, const TrainStepParams& P, const TrainImage* images, const TrainBatch& B, hipStream_t stream);
+void launch_train_build_fragments(const uint16_t* params, uint4* frags, uint2* kfrags, hipStream_t stream);
+void launch_train_backward(const ModelParams& M, const uint4* frags, const uint2* kfrags, const uint32_t* counters, uint32_t target_batch, const float* coords,
+                           const uint16_t* dloss, float* grad, uint32_t n_matrix_params, int n_cus, hipStream_t stream);
+void launch_train_optimizer(const AdamParams& A, float* weights_fp32, uint16_t* weights, float* grad, float* m1, float* m2, uint32_t* steps, float* ema_tmp,
+                            uint16_t* weights_ema, hipStream_t stream);
+void launch_train_xor_layout(const ModelParams& M, const uint2* src, char* dst, hipStream_t stream);
+void launch_train_loss_sum(const float* loss, uint32_t n, float* out, hipStream_t stream);
+
 struct HostMesh { // MeshData (mesh.h:18-24) after load_mesh
 	std::vector<Triangle> tris;        // reordered by the BVH build
 	std::vector<TriangleBvhNode> nodes;
@@ -63,6 +77,8 @@ struct TrainingView {
 	int32_t lens_mode = 0; // ELensMode
 	float lens_params[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	std::string path;
+	void* d_pixels = nullptr; // training image on the device (ngp_set_training_image), RGBA
+	int32_t image_type = 0;   // ngp_image_type
 };
 struct Dataset {
 	std::vector<TrainingView> views;
@@ -78,6 +94,43 @@ struct Dataset {
 	int32_t n_extra_learnable_dims = 0;
 };
 
+
+// Everything Testbed::train touches beyond the inference model (m_trainer, m_optimizer, NerfCounters, m_rng ...)
+struct TrainState {
+	ngp_training_opts opts{};
+	uint32_t n_params = 0, n_matrix = 0;
+	float* d_weights_fp32 = nullptr;   // Trainer::m_params_full_precision
+	uint16_t* d_weights = nullptr;     // m_params (fp16, what the training kernels read; tcnn order: density MLP, rgb MLP, grid)
+	uint16_t* d_weights_ema = nullptr; // Ema's m_weights_ema = the inference parameters
+	float* d_ema_tmp = nullptr;
+	float* d_grad = nullptr;           // fp32, cleared by the optimizer kernel
+	float* d_m1 = nullptr;
+	float* d_m2 = nullptr;
+	uint32_t* d_steps = nullptr;
+	uint4* d_tfrags = nullptr;         // MFMA fragments of the training parameters (forward + transposed)
+	uint2* d_kfrags = nullptr;
+	uint4* d_tfrags_inference = nullptr;
+	uint2* d_kfrags_inference = nullptr;
+	TrainImage* d_images = nullptr;
+	uint32_t n_images = 0;
+	bool images_dirty = true;
+	TrainBatch B{};
+	uint32_t cap_rays = 0, cap_samples = 0, cap_target = 0;
+	float* d_loss_sum = nullptr;
+	// NerfCounters + Testbed members
+	uint32_t training_step = 0;
+	uint32_t rays_per_batch = 1u << 12;
+	uint32_t n_rays_total = 0;
+	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0;
+	float loss_scalar = 0.f;
+	Pcg32 rng{};
+	uint32_t optimizer_step = 0; // Adam::m_current_step
+	float lr_factor = 1.0f;      // ExponentialDecay
+	bool inference_dirty = false; // the render model lags the training parameters
+	bool host_params_dirty = false;
+	bool batch_ready = false;
+	TrainStepParams last_step{};
+};
 } // namespace ngp
 
 struct ngp_ctx {
@@ -145,6 +198,10 @@ struct ngp_ctx {
 	hipStream_t last_stream = nullptr;
 	unsigned long long* d_prof = nullptr;
 	int32_t tune[6] = {64, 4, 32, 1, 0, 3};
+
+	// ---- training (ngp_train.cpp)
+	ngp::TrainState* train = nullptr;
+	bool density_grid_host_dirty = false; // ctx->density_grid lags d_density_f32
 };
 
 namespace ngp {
@@ -192,5 +249,14 @@ inline bool ends_with_ci(const std::string& s, const std::string& suffix) {
 
 
 void load_snapshot_path(ngp_ctx* ctx, const std::string& path);
+void install_model(ngp_ctx* ctx, const ngp_model_desc& d); // set_model_impl of ngp_api.cpp
+void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations);
+void refresh_density_grid_host(ngp_ctx* ctx);
+uint16_t half_from_float(float f);
+// ngp_train.cpp
+void free_training(ngp_ctx* ctx);
+void sync_inference_model(ngp_ctx* ctx); // render what has been trained (no-op when nothing changed)
+void sync_host_params(ngp_ctx* ctx);     // ctx->params <- training parameters, for snapshots
+
 void ensure_sync_buffers(ngp_ctx* ctx);
 } // namespace ngp

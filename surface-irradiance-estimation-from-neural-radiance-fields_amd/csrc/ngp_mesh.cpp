@@ -361,6 +361,7 @@ int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		ngp::sync_inference_model(ctx);
 		if (!d || d->n_theta == 0 || d->n_phi == 0 || d->mode < 0 || d->mode > 2) throw std::runtime_error("invalid probe descriptor");
 		const uint32_t no = d->mode == NGP_PROBE_MULTI_CENTER ? d->n_origin : 1u;
 		if (no == 0) throw std::runtime_error("invalid probe descriptor: n_origin");

@@ -97,6 +97,28 @@ PAYLOAD_DTYPE = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"),
 _lib = None
 
 
+class TrainingOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("loss_type", C.c_int32), ("random_bg_color", C.c_int32), ("linear_colors", C.c_int32), ("snap_to_pixel_centers", C.c_int32),
+        ("near_distance", C.c_float), ("density_grid_decay", C.c_float), ("train_network", C.c_int32), ("train_encoding", C.c_int32),
+        ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float), ("l2_reg", C.c_float),
+        ("ema_decay", C.c_float), ("decay_start", C.c_uint32), ("decay_interval", C.c_uint32), ("decay_base", C.c_float),
+        ("background_color", C.c_float * 3), ("color_space", C.c_int32),
+    ]
+
+
+class TrainingState(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("training_step", C.c_uint32), ("rays_per_batch", C.c_uint32), ("measured_batch_size", C.c_uint32),
+        ("measured_batch_size_before_compaction", C.c_uint32), ("n_rays_total", C.c_uint32), ("loss", C.c_float), ("learning_rate", C.c_float),
+        ("n_params", C.c_uint64), ("n_matrix_params", C.c_uint64),
+    ]
+
+
+LOSS_TYPES = {"L2": 0, "L1": 1, "MAPE": 2, "SMAPE": 3, "Huber": 4, "LogL1": 5, "RelativeL2": 6}
+IMAGE_BYTE, IMAGE_FLOAT = 1, 3
+
+
 def load_library():
     global _lib
     if _lib is not None:
@@ -149,6 +171,17 @@ def load_library():
     L.ngp_compute_envmap.argtypes = [vp, C.POINTER(ProbeDesc), vp]
     L.ngp_get_envmap.argtypes = [vp, vp, vp, vp, vp]
     L.ngp_irradiance.argtypes = [vp, C.c_uint32, vp, vp]
+    L.ngp_reset_network.argtypes = [vp, C.c_uint32, C.c_uint64]
+    L.ngp_default_training_opts.argtypes = [C.POINTER(TrainingOpts)]; L.ngp_default_training_opts.restype = None
+    L.ngp_set_training_opts.argtypes = [vp, C.POINTER(TrainingOpts)]
+    L.ngp_get_training_opts.argtypes = [vp, C.POINTER(TrainingOpts)]
+    L.ngp_set_training_image.argtypes = [vp, ip, C.c_int32, C.c_int32, vp, C.c_int32]
+    L.ngp_train.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.ngp_get_training_state.argtypes = [vp, C.POINTER(TrainingState)]
+    L.ngp_train_prepare_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.ngp_train_gradients.argtypes = [vp, C.c_uint32, vp]
+    L.ngp_train_apply.argtypes = [vp]
+    L.ngp_get_training_params.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -439,3 +472,70 @@ class Context:
         pl = np.zeros(cam.width * cam.height, PAYLOAD_DTYPE)
         self._check(self.L.ngp_init_rays(self.h, C.byref(cam), _p(pl)))
         return pl
+
+    # ------------------------------------------------------------- training
+    def reset_network(self, log2_hashmap_size=19, seed=1337):
+        self._check(self.L.ngp_reset_network(self.h, log2_hashmap_size, seed))
+
+    def training_opts(self):
+        o = TrainingOpts()
+        self._check(self.L.ngp_get_training_opts(self.h, C.byref(o)))
+        return o
+
+    def set_training_opts(self, **kw):
+        o = self.training_opts()
+        for k, v in kw.items():
+            if k == "background_color":
+                o.background_color = (C.c_float * 3)(*v)
+            elif k == "loss_type" and isinstance(v, str):
+                o.loss_type = LOSS_TYPES[v]
+            else:
+                if not hasattr(o, k):
+                    raise AttributeError(k)
+                setattr(o, k, v)
+        self._check(self.L.ngp_set_training_opts(self.h, C.byref(o)))
+
+    def set_training_image(self, view, img):
+        """img: (H, W, 4) uint8 (sRGB, straight alpha) or float32 (linear, premultiplied)."""
+        if img.dtype == np.uint8:
+            a, t = np.ascontiguousarray(img), IMAGE_BYTE
+        else:
+            a, t = np.ascontiguousarray(img, np.float32), IMAGE_FLOAT
+        assert a.ndim == 3 and a.shape[2] == 4
+        self._check(self.L.ngp_set_training_image(self.h, view, a.shape[1], a.shape[0], _p(a), t))
+
+    def train(self, n_steps=1, batch_size=1 << 18):
+        loss = C.c_float(0)
+        self._check(self.L.ngp_train(self.h, n_steps, batch_size, C.byref(loss)))
+        return loss.value
+
+    def training_state(self):
+        st = TrainingState()
+        self._check(self.L.ngp_get_training_state(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in TrainingState._fields_ if k != "struct_size"}
+
+    def train_prepare_batch(self, batch_size):
+        n_rays = self.training_state()["rays_per_batch"]
+        counters = np.zeros(3, np.uint32)
+        ray_indices = np.zeros(n_rays, np.uint32)
+        numsteps = np.zeros((n_rays, 2), np.uint32)
+        coords = np.zeros((batch_size, 7), np.float32)
+        dloss = np.zeros((batch_size, 4), np.float16)
+        loss = np.zeros(n_rays, np.float32)
+        self._check(self.L.ngp_train_prepare_batch(self.h, batch_size, _p(counters), _p(ray_indices), _p(numsteps), _p(coords), _p(dloss), _p(loss)))
+        return {"counters": counters, "ray_indices": ray_indices, "numsteps": numsteps, "coords": coords, "dloss": dloss, "loss": loss, "n_rays": n_rays}
+
+    def train_gradients(self, batch_size):
+        n = self.training_state()["n_params"] or self.get_model().n_params
+        g = np.zeros(int(n), np.float32)
+        self._check(self.L.ngp_train_gradients(self.h, batch_size, _p(g)))
+        return g
+
+    def train_apply(self):
+        self._check(self.L.ngp_train_apply(self.h))
+
+    def training_params(self):
+        n = int(self.get_model().n_params)
+        w, e = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self._check(self.L.ngp_get_training_params(self.h, _p(w), _p(e)))
+        return w, e

@@ -113,3 +113,25 @@ def focal_from_fov_x(width, fov_x_rad):
     rel = np.float32(0.5) / np.float32(math.tan(0.5 * fov_x_rad))
     f = float(rel * np.float32(width))
     return (f, f)
+
+
+def ngp_matrix_to_nerf(m, scale=0.33, offset=(0.5, 0.5, 0.5)):
+    """Inverse of nerf_matrix_to_ngp: (3,4) ngp-space camera -> (4,4) NeRF/Blender transform_matrix."""
+    m = np.asarray(m, np.float64)[[2, 0, 1], :].copy()
+    m[:, 3] = (m[:, 3] - np.asarray(offset, np.float64)) / scale
+    m[:, 1] *= -1.0
+    m[:, 2] *= -1.0
+    out = np.eye(4)
+    out[:3, :4] = m
+    return out
+
+
+def write_transforms(path, ngp_matrices, width, height, fov_x, aabb_scale=1):
+    """A transforms.json (the reference's dataset format, src/nerf_loader.cu) for the given ngp-space cameras; frame
+    names sort in the given order."""
+    import json
+
+    frames = [{"file_path": f"./train/r_{i:04d}", "transform_matrix": ngp_matrix_to_nerf(m).tolist()} for i, m in enumerate(ngp_matrices)]
+    with open(path, "w") as f:
+        json.dump({"camera_angle_x": fov_x, "w": width, "h": height, "aabb_scale": aabb_scale, "frames": frames}, f)
+    return path

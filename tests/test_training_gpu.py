@@ -1,0 +1,203 @@
+"""Training step against the oracle: sample generation and loss ray by ray, the fused
+backward against the float64 restatement, the optimizer, and an end-to-end fit of images rendered from a known scene."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import pkg, psnr
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+W = H = 96
+FOV = 0.6911
+POSES = [(0, 30), (45, 20), (90, 40), (135, 10), (180, 30), (225, 50), (270, 25), (315, 35)]
+TARGET = 1 << 17
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory, native, scene_mod, scene_unit):
+    """Ground-truth views of the synthetic scene from the renderer itself: linear, premultiplied RGBA."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    focal = scene_mod.focal_from_fov_x(W, FOV)
+    mats = [scene_mod.orbit_camera(az, el) for az, el in POSES]
+    imgs = [ctx.render(native.make_camera(m, W, H, focal), native.make_opts(background=(0.0, 0.0, 0.0, 0.0))) for m in mats]
+    ctx.close()
+    path = scene_mod.write_transforms(str(tmp_path_factory.mktemp("ds") / "transforms.json"), mats, W, H, FOV)
+    return {"path": path, "images": imgs, "mats": mats, "focal": focal}
+
+
+def _ctx_with_data(native, dataset, byte_images=False):
+    ctx = native.Context(0)
+    ctx.load_training_data(dataset["path"])
+    for i, im in enumerate(dataset["images"]):
+        if byte_images:
+            a = np.clip(im[..., 3:4], 1e-6, 1.0)
+            rgb = np.clip(im[..., :3] / a, 0, 1)
+            srgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * rgb ** (1 / 2.4) - 0.055)
+            ctx.set_training_image(i, (np.concatenate([srgb, im[..., 3:4]], -1) * 255 + 0.5).astype(np.uint8))
+        else:
+            ctx.set_training_image(i, im)
+    return ctx
+
+
+def _oracle_views(ctx, dataset):
+    views = []
+    for i, im in enumerate(dataset["images"]):
+        v = ctx.training_view(i)
+        views.append({"pixels": im, "xform": v["matrix"], "focal": tuple(v["focal_length"]), "principal": tuple(v["principal_point"])})
+    return views
+
+
+def test_sample_generation_and_loss_match_the_oracle(native, oracle, dataset, scene_unit):
+    import oracle as O
+
+    ctx = _ctx_with_data(native, dataset)
+    ctx.set_model(scene_unit)
+    b = ctx.train_prepare_batch(TARGET)
+    n_rays = b["n_rays"]
+    assert n_rays == 4096
+    m = oracle.make_model(scene_unit)
+    images = oracle.make_train_images(_oracle_views(ctx, dataset))
+    o = O.TrainOpts()
+    o.n_rays, o.n_images, o.rng = n_rays, len(POSES), oracle.train_rng(1337, 0)
+    o.snap_to_pixel_centers, o.random_bg_color, o.linear_colors, o.color_space, o.loss_type = 1, 1, 0, 1, 4
+    o.near_distance, o.loss_scale, o.density_grid_mean = 0.1, 128.0, float(scene_unit["density_grid_mean"])
+    gen = oracle.train_generate_samples(m, images, o, TARGET * 16)
+    # --- generate_training_samples_nerf: the same rays survive with the same number of steps
+    n_kept = int(b["counters"][1])
+    kept = b["ray_indices"][:n_kept]
+    assert len(set(kept.tolist())) == n_kept
+    assert set(kept.tolist()) == set(np.flatnonzero(gen["numsteps"]).tolist())
+    assert abs(int(b["counters"][0]) - int(gen["total"])) <= 2e-4 * gen["total"]
+    # --- compute_loss_kernel_train_nerf on the oracle's own network output
+    net = oracle.network(m, gen["coords"][: gen["total"], :3], gen["coords"][: gen["total"], 4:7])
+    ls = oracle.train_loss(m, images, o, gen, net)
+    n_compacted = int(b["counters"][2])
+    assert n_compacted < TARGET and abs(n_compacted - int(ls["compacted_numsteps"].sum())) <= 2e-3 * n_compacted
+    same, checked, worst_coord, dl_err, dl_ref = 0, 0, 0.0, [], []
+    scale = n_compacted / TARGET
+    for r in range(n_kept):
+        i = int(kept[r])
+        cn, cb = int(b["numsteps"][r, 0]), int(b["numsteps"][r, 1])
+        ob, on = int(gen["base"][i]), int(ls["compacted_numsteps"][i])
+        if cn != on:
+            continue
+        same += 1
+        got_c, ref_c = b["coords"][cb:cb + cn], gen["coords"][ob:ob + cn]
+        worst_coord = max(worst_coord, float(np.abs(got_c - ref_c).max()) if cn else 0.0)
+        assert abs(b["loss"][r] - ls["loss"][i]) <= 2e-3 * abs(ls["loss"][i]) + 1e-9
+        # fill_rollover_and_rescale: sample at compacted index c carries 1 + copies * n / target
+        copies = (TARGET - 1 - np.arange(cb, cb + cn)) // n_compacted
+        ref_d = ls["dloss"][ob:ob + cn].astype(np.float32)
+        ref_d = ref_d + copies[:, None] * (ref_d * np.float32(scale)).astype(np.float16).astype(np.float32)
+        dl_err.append(np.abs(b["dloss"][cb:cb + cn].astype(np.float32) - ref_d).reshape(-1))
+        dl_ref.append(np.abs(ref_d).reshape(-1))
+        checked += cn
+    assert same >= 0.995 * n_kept and checked > 20000
+    assert worst_coord <= 2e-6  # positions, dt, directions: the same arithmetic up to the device's division / exp
+    dl_err, dl_ref = np.concatenate(dl_err), np.concatenate(dl_ref)
+    # the network outputs differ by fp16 ulps (test_network_outputs); gradients inherit that through sigmoid' / exp
+    assert np.sum(dl_err) <= 0.01 * np.sum(dl_ref) and np.quantile(dl_err, 0.999) <= 0.05 * dl_ref.max()
+    oracle.release(m)
+    ctx.close()
+
+
+def _split(g):
+    return g[:10240], g[10240:]
+
+
+def test_backward_matches_the_float64_oracle(native, dataset, scene_unit):
+    import train_oracle as T
+
+    ctx = _ctx_with_data(native, dataset)
+    ctx.set_model(scene_unit)
+    b = ctx.train_prepare_batch(TARGET)
+    n = int(b["counters"][2])
+    g = ctx.train_gradients(TARGET).astype(np.float64)
+    params = np.asarray(scene_unit["params"], np.uint16).view(np.float16).astype(np.float64)
+    ref = T.backward(params, scene_unit["encoding"], b["coords"][:n].astype(np.float64), b["dloss"][:n].astype(np.float64))
+    assert g.shape == ref.shape and np.isfinite(g).all()
+    for name, (got, want) in {"matrices": (_split(g)[0], _split(ref)[0]), "grid": (_split(g)[1], _split(ref)[1])}.items():
+        cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+        rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        # fp16 activations and gradients in the device path (like the reference), float64 in the oracle
+        assert cos > 0.9995 and rel < 0.03, (name, cos, rel)
+    # every layer on its own: a wrong fragment would hide in the total
+    for lo, hi in ((0, 2048), (2048, 3072), (3072, 5120), (5120, 9216), (9216, 10240)):
+        got, want = g[lo:hi], ref[lo:hi]
+        assert np.linalg.norm(got - want) <= 0.03 * np.linalg.norm(want), (lo, hi)
+    # untouched grid entries receive exactly nothing; touched ones may underflow to zero in the fp16 hand-over
+    gz, rz = _split(g)[1] != 0, _split(ref)[1] != 0
+    assert not np.any(gz & ~rz) and np.mean(gz != rz) < 0.01
+    ctx.close()
+
+
+def test_optimizer_step_matches_adam_and_ema(native, dataset, scene_unit):
+    import train_oracle as T
+
+    ctx = _ctx_with_data(native, dataset)
+    ctx.set_model(scene_unit)
+    ctx.train_prepare_batch(TARGET)
+    g = ctx.train_gradients(TARGET).astype(np.float64)
+    w0, _ = ctx.training_params()
+    ctx.train_apply()
+    w1, ema1 = ctx.training_params()
+    w = w0.astype(np.float64)
+    m1, m2, steps = np.zeros_like(w), np.zeros_like(w), np.zeros(w.size, np.int64)
+    upd = T.adam_step(w, g, m1, m2, steps, 10240)
+    assert np.allclose(w1, w, rtol=1e-5, atol=1e-7)
+    assert np.array_equal(w1[~upd], w0[~upd])  # grid entries no sample touched
+    moved = np.abs(w1 - w0)[upd]
+    assert np.allclose(moved[np.abs(g[upd]) > 1e-6], 0.01, rtol=1e-3)  # first Adam step: lr * m / sqrt(v) = lr
+    ema = T.ema_step(w0.astype(np.float64).copy(), w1.astype(np.float16).astype(np.float64), 1)
+    assert np.allclose(ema1, ema, rtol=1e-5, atol=1e-7)
+    st = ctx.training_state()
+    assert st["training_step"] == 1 and st["measured_batch_size"] > 0 and st["rays_per_batch"] > 4096 and st["loss"] > 0
+    ctx.close()
+
+
+def test_training_fits_the_rendered_views(native, scene_mod, dataset, tmp_path):
+    ctx = _ctx_with_data(native, dataset, byte_images=True)
+    ctx.reset_network(log2_hashmap_size=15, seed=1337)
+    losses = [ctx.train(1, 1 << 16)]
+    losses += [ctx.train(50, 1 << 16) for _ in range(8)]
+    st = ctx.training_state()
+    assert st["training_step"] == 401 and np.isfinite(losses).all()
+    assert losses[-1] < 0.1 * losses[0], losses
+    cam = native.make_camera(dataset["mats"][2], W, H, dataset["focal"])
+    got = ctx.render(cam, native.make_opts(background=(0.0, 0.0, 0.0, 0.0)))
+    ref = dataset["images"][2]
+    assert psnr(got[..., :3], ref[..., :3]) > 22.0
+    # a held-out pose between two training views
+    ctx_gt_psnr = psnr(got[..., 3], ref[..., 3])
+    assert ctx_gt_psnr > 15.0
+    # the trained model survives a snapshot round trip (training parameters, like the reference's Trainer::serialize)
+    p = str(tmp_path / "trained.ingp")
+    ctx.save_snapshot_file(p)
+    ctx2 = native.Context(0)
+    ctx2.load_snapshot_file(p)
+    again = ctx2.render(cam, native.make_opts(background=(0.0, 0.0, 0.0, 0.0)))
+    assert psnr(again[..., :3], ref[..., :3]) > 20.0
+    ctx2.close()
+    ctx.close()
+
+
+def test_training_errors(native, dataset):
+    ctx = native.Context(0)
+    with pytest.raises(RuntimeError, match="No network available"):
+        ctx.train(1, 1 << 14)
+    ctx.reset_network(log2_hashmap_size=14)
+    with pytest.raises(RuntimeError, match="No training data available"):
+        ctx.train(1, 1 << 14)
+    ctx.load_training_data(dataset["path"])
+    ctx.set_training_image(0, dataset["images"][0])
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        ctx.train(1, 1000)
+    with pytest.raises(RuntimeError, match="invalid frame index"):
+        ctx.set_training_image(99, dataset["images"][0])
+    ctx.close()
