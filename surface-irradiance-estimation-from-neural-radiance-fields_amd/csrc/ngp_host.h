@@ -53,7 +53,8 @@ void launch_train_inference(const ModelParams& M, const uint4* frags, const uint
 void launch_train_loss(const ModelParams& M, const TrainStepParams& P, const TrainImage* images, const TrainBatch& B, hipStream_t stream);
 void launch_train_build_fragments(const uint16_t* params, uint4* frags, uint2* kfrags, hipStream_t stream);
 void launch_train_backward(const ModelParams& M, const uint4* frags, const uint2* kfrags, const uint32_t* counters, uint32_t target_batch, const float* coords,
-                           const uint16_t* dloss, float* grad, uint32_t n_matrix_params, int n_cus, hipStream_t stream);
+                           const uint16_t* dloss, float* grad, uint32_t n_matrix_params, float* block_partials, int n_blocks, hipStream_t stream);
+size_t train_backward_partials_floats(int n_blocks);
 void launch_train_optimizer(const AdamParams& A, float* weights_fp32, uint16_t* weights, float* grad, float* m1, float* m2, uint32_t* steps, float* ema_tmp,
                             uint16_t* weights_ema, hipStream_t stream);
 void launch_train_xor_layout(const ModelParams& M, const uint2* src, char* dst, hipStream_t stream);
@@ -117,6 +118,7 @@ struct TrainState {
 	TrainBatch B{};
 	uint32_t cap_rays = 0, cap_samples = 0, cap_target = 0;
 	float* d_loss_sum = nullptr;
+	float* d_partials = nullptr; // per-block weight-gradient sums of train_backward_kernel
 	// NerfCounters + Testbed members
 	uint32_t training_step = 0;
 	uint32_t rays_per_batch = 1u << 12;

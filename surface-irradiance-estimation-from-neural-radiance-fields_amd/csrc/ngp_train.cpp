@@ -88,6 +88,7 @@ TrainState& ensure_training(ngp_ctx* ctx) {
 	dev_alloc(T.d_tfrags_inference, (size_t)N_TFRAGS * 64);
 	dev_alloc(T.d_kfrags_inference, (size_t)N_KFRAGS * 64);
 	dev_alloc(T.d_loss_sum, 1);
+	dev_alloc(T.d_partials, train_backward_partials_floats(ctx->n_cus));
 	NGP_HIP_CHECK(hipMemcpy(T.d_weights, ctx->params.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
 	NGP_HIP_CHECK(hipMemcpy(T.d_weights_ema, ctx->params.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
 	{
@@ -235,7 +236,7 @@ void prepare_batch(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
 
 void backward(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
 	if (!T.batch_ready) throw std::runtime_error("no training batch prepared");
-	launch_train_backward(training_model(ctx), T.d_tfrags, T.d_kfrags, T.B.counters, target_batch, T.B.coords_compacted, T.B.dloss, T.d_grad, T.n_matrix, ctx->n_cus, ctx->stream);
+	launch_train_backward(training_model(ctx), T.d_tfrags, T.d_kfrags, T.B.counters, target_batch, T.B.coords_compacted, T.B.dloss, T.d_grad, T.n_matrix, T.d_partials, ctx->n_cus, ctx->stream);
 }
 
 // m_trainer->optimizer_step + ++m_training_step + NerfCounters::update_after_training (:3002-3020, 2923-2947)
@@ -300,7 +301,7 @@ void free_training(ngp_ctx* ctx) {
 	if (!ctx->train) return;
 	TrainState& T = *ctx->train;
 	dev_free(T.d_weights_fp32); dev_free(T.d_weights); dev_free(T.d_weights_ema); dev_free(T.d_ema_tmp); dev_free(T.d_grad); dev_free(T.d_m1); dev_free(T.d_m2);
-	dev_free(T.d_steps); dev_free(T.d_tfrags); dev_free(T.d_kfrags); dev_free(T.d_tfrags_inference); dev_free(T.d_kfrags_inference); dev_free(T.d_images); dev_free(T.d_loss_sum);
+	dev_free(T.d_steps); dev_free(T.d_tfrags); dev_free(T.d_kfrags); dev_free(T.d_tfrags_inference); dev_free(T.d_kfrags_inference); dev_free(T.d_images); dev_free(T.d_loss_sum); dev_free(T.d_partials);
 	dev_free(T.B.counters); dev_free(T.B.ray_indices); dev_free(T.B.rays); dev_free(T.B.numsteps); dev_free(T.B.coords); dev_free(T.B.mlp_out);
 	dev_free(T.B.coords_compacted); dev_free(T.B.dloss); dev_free(T.B.loss);
 	const ngp_training_opts keep = T.opts; // settings outlive a model (they belong to the Testbed, not to the network)

@@ -435,6 +435,7 @@ constexpr int N_MLP_PARAMS = 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64; //
 constexpr int OFF_D0 = 0, OFF_D1 = 2048, OFF_R0 = 3072, OFF_R1 = 5120, OFF_R2 = 9216;
 
 NGP_DEV floatx4 mfma_k16(half4 a, half4 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+#define WGRAD_IF if (exp_mode != 5)
 NGP_DEV half4 ld_kfrag(const uint2* s_k, int f, int lane) {
 	union { uint2 u; half4 h; } cv;
 	cv.u = s_k[f * 64 + lane];
@@ -471,7 +472,7 @@ NGP_DEV half8 pack_masked(floatx4 lo, floatx4 hi, half8 act) { // ReLU backward 
 __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelParams M, const uint4* __restrict__ frags, const uint2* __restrict__ kfrags,
                                                                   const uint32_t* __restrict__ counters, uint32_t target_batch, const float* __restrict__ coords,
                                                                   const uint16_t* __restrict__ dloss, float* __restrict__ grad /* [n_params] fp32, tcnn parameter order */,
-                                                                  uint32_t n_matrix_params) {
+                                                                  uint32_t n_matrix_params, float* __restrict__ block_partials /* [gridDim.x][N_MLP_PARAMS] */, int exp_mode) {
 	extern __shared__ char s_dyn[];
 	uint4* s_w = (uint4*)s_dyn;                                   // N_TFRAGS * 64 * 16 B
 	uint2* s_k = (uint2*)(s_dyn + N_TFRAGS * 64 * 16);            // N_KFRAGS * 64 * 8 B
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		st_pair(ximg, XROW, X_H2, lane, h20);
 		st_pair(ximg, XROW, X_H2 + 32, lane, h21);
 
+		if (exp_mode == 7) continue;
 		// ---- backward. dL/d(rgb network output): rows 0..2 of the padded 16 (extract_rgb, nerf_network.h:206)
 		const uint16_t* dl = dloss + (size_t)s * 4;
 		half4 dout = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		}
 		// W_R2: dW = dOut . h2^T
 		st_tile4(yimg, YROW, 0, lane, dout);
-		{
+		WGRAD_IF {
 			const half4 a = tr_read(yimg, YROW, 0, lane);
 #pragma unroll
 			for (int tj = 0; tj < 4; ++tj) accR2[tj] = mfma_k16(a, tr_read(ximg, XROW, X_H2 + 16 * tj, lane), accR2[tj]);
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		st_pair(yimg, YROW, 0, lane, p0);
 		st_pair(yimg, YROW, 32, lane, p1);
 		// W_R1: dW = dH2 . h1^T
-		{
+		WGRAD_IF {
 			half4 b[4];
 #pragma unroll
 			for (int tj = 0; tj < 4; ++tj) b[tj] = tr_read(ximg, XROW, X_H1 + 16 * tj, lane);
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		st_pair(yimg, YROW, 0, lane, p0);
 		st_pair(yimg, YROW, 32, lane, p1);
 		// W_R0: dW = dH1 . rin^T
-		{
+		WGRAD_IF {
 			const half4 b0 = tr_read(ximg, XROW, X_RIN, lane), b1 = tr_read(ximg, XROW, X_RIN + 16, lane);
 #pragma unroll
 			for (int ti = 0; ti < 4; ++ti) {
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		if (h == 0) ddens[0] = (half_t)((float)ddens[0] + dsigma); // fp16 + fp16 like add_density_gradient
 		st_tile4(yimg, YROW, 0, lane, ddens);
 		// W_D1: dW = dDens . hd^T
-		{
+		WGRAD_IF {
 			const half4 a = tr_read(yimg, YROW, 0, lane);
 #pragma unroll
 			for (int tj = 0; tj < 4; ++tj) accD1[tj] = mfma_k16(a, tr_read(ximg, XROW, X_HD + 16 * tj, lane), accD1[tj]);
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		st_pair(yimg, YROW, 0, lane, p0);
 		st_pair(yimg, YROW, 32, lane, p1);
 		// W_D0: dW = dHd . enc^T
-		{
+		WGRAD_IF {
 			const half4 b0 = tr_read(ximg, XROW, X_ENC, lane), b1 = tr_read(ximg, XROW, X_ENC + 16, lane);
 #pragma unroll
 			for (int ti = 0; ti < 4; ++ti) {
@@ -641,26 +643,83 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		e0 = mfma16(ld_frag(s_w, TFRAG_D0T + 1, lane), p1, e0);
 		floatx4 e1 = mfma16(ld_frag(s_w, TFRAG_D0T + 2, lane), p0, zero);
 		e1 = mfma16(ld_frag(s_w, TFRAG_D0T + 3, lane), p1, e1);
-		// grid scatter (tcnn kernel_grid_backward): corner c of level l receives weight_c * dL/d feature
-		if (s < n_raw) {
+		// grid scatter (tcnn kernel_grid_backward): corner k of level l receives weight_k * dL/d feature. The 16 lanes of a
+		// DPP row are 16 consecutive samples of (mostly) one ray: on the coarse levels they sit in one cell, where per-lane
+		// atomics would all land on the same 8 entries and serialise. Rows whose lanes share the cell add their 32 products
+		// with row rotations first and issue 2 atomics per lane instead of 32.
+		const bool live = s < n_raw;
+		if (exp_mode == 6) { if (e0[0] + e1[0] == 12345.678f) grad[0] = 1.0f; continue; }
 #pragma unroll
-			for (int l = 0; l < 2; ++l) {
-				const floatx4 g = l ? e1 : e0;
-				// the fp16 gradient the reference's MLP backward hands to the encoding
-				const float gf[4] = {(float)(half_t)g[0], (float)(half_t)g[1], (float)(half_t)g[2], (float)(half_t)g[3]};
-				if (gf[0] == 0.0f && gf[1] == 0.0f && gf[2] == 0.0f && gf[3] == 0.0f) continue;
-				const LevelInfo& L = s_lv[h + 4 * l];
-				const CellPos p = level_cell(L, px, py, pz);
-				CornerSet cs;
-				level_corners(L, p, cs);
-				float w[8];
-				corner_weights(p, w);
+		for (int l = 0; l < 2; ++l) {
+			const floatx4 g = l ? e1 : e0;
+			// the fp16 gradient the reference's MLP backward hands to the encoding; padding samples contribute nothing
+			float gf[4];
+#pragma unroll
+			for (int f = 0; f < 4; ++f) gf[f] = live ? (float)(half_t)g[f] : 0.0f;
+			const LevelInfo& L = s_lv[h + 4 * l];
+			const CellPos p = level_cell(L, px, py, pz);
+			CornerSet cs;
+			level_corners(L, p, cs);
+			float w[8];
+			corner_weights(p, w);
+			float* gbase = grad + n_matrix_params;
+			// same cell as the lane one to the right within the row <=> the whole row shares the cell
+			const uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.gx, 0x121, 0xF, 0xF, false), ny = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.gy, 0x121, 0xF, 0xF, false),
+			               nz = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.gz, 0x121, 0xF, 0xF, false);
+			const unsigned long long same = __ballot(nx == p.gx && ny == p.gy && nz == p.gz);
+			const bool row_uniform = ((same >> (16 * h)) & 0xFFFFull) == 0xFFFFull && exp_mode != 4;
+			// Float atomics run at the memory side at a fixed rate of 64-B requests (MI355X_MICROARCH.md, Global float atomics):
+			// the four features of an entry are one 16-B segment, so four neighbouring lanes add them in ONE request.
+			if (row_uniform) {
+				// after four rotate-adds every lane of the row holds the row's sum of w_k * g_f; two instructions, lane c adds
+				// feature c & 3 of corner (c >> 2) and of corner 4 + (c >> 2)
+				float mine_a = 0.0f, mine_b = 0.0f;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					float* dst = grad + n_matrix_params + (size_t)(cs.index[k] >> 1); // byte offset / 8 B per entry * 4 features
 #pragma unroll
-					for (int f = 0; f < 4; ++f) atomicAdd(dst + f, w[k] * gf[f]);
+					for (int f = 0; f < 4; ++f) {
+						float v = w[k] * gf[f];
+						v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)); // row_ror:8
+						v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false)); // row_ror:4
+						v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false)); // row_ror:2
+						v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)); // row_ror:1
+						if ((c & 3) == f && (c >> 2) == (k & 3)) {
+							if (k & 4) mine_b = v;
+							else mine_a = v;
+						}
+					}
 				}
+				uint32_t idx_a = cs.index[0], idx_b = cs.index[4];
+#pragma unroll
+				for (int k = 1; k < 4; ++k) {
+					idx_a = (c >> 2) == k ? cs.index[k] : idx_a;
+					idx_b = (c >> 2) == k ? cs.index[4 + k] : idx_b;
+				}
+				if (mine_a != 0.0f) atomicAdd(gbase + (size_t)(idx_a >> 1) + (c & 3), mine_a);
+				if (mine_b != 0.0f) atomicAdd(gbase + (size_t)(idx_b >> 1) + (c & 3), mine_b);
+			} else {
+				// a quad (4 consecutive samples) takes turns: in turn t its four lanes add the four features of sample t's corners
+#define NGP_QUAD_TURN(t)                                                                                                                       \
+				{                                                                                                                              \
+					const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[0]), (t) * 0x55, 0xF, 0xF, false)); \
+					const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[1]), (t) * 0x55, 0xF, 0xF, false)); \
+					const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[2]), (t) * 0x55, 0xF, 0xF, false)); \
+					const float g3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[3]), (t) * 0x55, 0xF, 0xF, false)); \
+					const float gm = (c & 2) ? ((c & 1) ? g3 : g2) : ((c & 1) ? g1 : g0);                                                       \
+					if (__builtin_amdgcn_ballot_w64(gm != 0.0f) != 0ull) {                                                                      \
+						_Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                         \
+							const uint32_t ik = (uint32_t)__builtin_amdgcn_mov_dpp((int)cs.index[k], (t) * 0x55, 0xF, 0xF, false);               \
+							const float wk = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[k]), (t) * 0x55, 0xF, 0xF, false)); \
+							const float v = wk * gm;                                                                                            \
+							if (v != 0.0f) atomicAdd(gbase + (size_t)(ik >> 1) + (c & 3), v);                                                   \
+						}                                                                                                                       \
+					}                                                                                                                           \
+				}
+				NGP_QUAD_TURN(0)
+				NGP_QUAD_TURN(1)
+				NGP_QUAD_TURN(2)
+				NGP_QUAD_TURN(3)
+#undef NGP_QUAD_TURN
 			}
 		}
 	}
@@ -694,10 +753,18 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 		}
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < N_MLP_PARAMS; i += BLOCK) {
-		const float v = s_red[i];
-		if (v != 0.0f) atomicAdd(&grad[i], v);
-	}
+	// every block leaves its sums in its own row; train_reduce_partials_kernel adds the rows (256 blocks hammering the
+	// same 10240 addresses with atomics serialise at the memory side)
+	float* mine = block_partials + (size_t)blockIdx.x * N_MLP_PARAMS;
+	for (int i = threadIdx.x; i < N_MLP_PARAMS; i += BLOCK) mine[i] = s_red[i];
+}
+
+__global__ void train_reduce_partials_kernel(const float* __restrict__ block_partials, uint32_t n_blocks, float* __restrict__ grad) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= (uint32_t)N_MLP_PARAMS) return;
+	float acc = 0.0f;
+	for (uint32_t b = 0; b < n_blocks; ++b) acc += block_partials[(size_t)b * N_MLP_PARAMS + i];
+	grad[i] += acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -784,7 +851,7 @@ void launch_train_build_fragments(const uint16_t* params, uint4* frags, uint2* k
 	hipLaunchKernelGGL(train_build_fragments_kernel, dim3((N_TFRAGS * 64 * 8 + 255) / 256), dim3(256), 0, stream, params, (uint16_t*)frags, (uint16_t*)kfrags);
 }
 void launch_train_backward(const ModelParams& M, const uint4* frags, const uint2* kfrags, const uint32_t* counters, uint32_t target_batch, const float* coords,
-                           const uint16_t* dloss, float* grad, uint32_t n_matrix_params, int n_cus, hipStream_t stream) {
+                           const uint16_t* dloss, float* grad, uint32_t n_matrix_params, float* block_partials, int n_blocks, hipStream_t stream) {
 	static_assert(4 * WAVE_SCRATCH >= N_MLP_PARAMS * 4, "the block reduction reuses the waves' scratch");
 	const size_t lds = (size_t)N_TFRAGS * 64 * 16 + (size_t)N_KFRAGS * 64 * 8 + 4 * (size_t)WAVE_SCRATCH;
 	static bool configured = false;
@@ -792,8 +859,12 @@ void launch_train_backward(const ModelParams& M, const uint4* frags, const uint2
 		NGP_HIP_CHECK(hipFuncSetAttribute((const void*)train_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		configured = true;
 	}
-	hipLaunchKernelGGL(train_backward_kernel, dim3((uint32_t)n_cus), dim3(BLOCK), lds, stream, M, frags, kfrags, counters, target_batch, coords, dloss, grad, n_matrix_params);
+	static const int exp_mode = getenv("NGP_TRAIN_EXP") ? atoi(getenv("NGP_TRAIN_EXP")) : 0;
+	hipLaunchKernelGGL(train_backward_kernel, dim3((uint32_t)n_blocks), dim3(BLOCK), lds, stream, M, frags, kfrags, counters, target_batch, coords, dloss, grad, n_matrix_params,
+	                   block_partials, exp_mode);
+	hipLaunchKernelGGL(train_reduce_partials_kernel, dim3((N_MLP_PARAMS + 255) / 256), dim3(256), 0, stream, block_partials, (uint32_t)n_blocks, grad);
 }
+size_t train_backward_partials_floats(int n_blocks) { return (size_t)n_blocks * N_MLP_PARAMS; }
 void launch_train_optimizer(const AdamParams& A, float* weights_fp32, uint16_t* weights, float* grad, float* m1, float* m2, uint32_t* steps, float* ema_tmp,
                             uint16_t* weights_ema, hipStream_t stream) {
 	hipLaunchKernelGGL(train_optimizer_kernel, dim3((A.n_params + 255) / 256), dim3(256), 0, stream, A, weights_fp32, weights, grad, m1, m2, steps, ema_tmp, weights_ema);
