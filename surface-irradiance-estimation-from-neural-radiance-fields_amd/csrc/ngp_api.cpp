@@ -867,6 +867,7 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			read_lens(frame, v);
 			v.path = frame.at("file_path").str();
 			std::replace(v.path.begin(), v.path.end(), '\\', '/');
+			v.abs_path = resolve(v.path);
 			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
 			v.resolution[1] = (int)(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
 			if (v.resolution[0] <= 0 || v.resolution[1] <= 0) throw std::runtime_error("transforms.json must provide 'w' and 'h' (images are not decoded on the inference path)");

@@ -74,7 +74,7 @@ std::string read_text(const std::string& path) {
 void usage() {
 	std::cout << "ngp_hip_main [files...] [--scene PATH] [--snapshot|--load_snapshot PATH] [--width W] [--height H] [--spp N]\n"
 	             "             [--screenshot OUT.png] [--screenshot_transforms T.json --screenshot_dir DIR] [--render_mode Shade|ShadeEnvMap|AO|Positions|Depth]\n"
-	             "             [--exposure E] [--no-gui] [--no-train] [--version]\n";
+	             "             [--exposure E] [--n_steps N] [--save_snapshot OUT.ingp] [--network CONFIG.json] [--no-gui] [--no-train] [--version]\n";
 }
 
 } // namespace
@@ -82,8 +82,9 @@ void usage() {
 int main(int argc, char** argv) {
 	try {
 		std::vector<std::string> files;
-		std::string scene, snapshot, screenshot, shot_transforms, shot_dir, render_mode = "Shade";
-		int width = 1920, height = 1080, spp = 1;
+		std::string scene, snapshot, screenshot, shot_transforms, shot_dir, render_mode = "Shade", save_snapshot, network;
+		int width = 1920, height = 1080, spp = 1, n_steps = -1;
+		bool no_train = false;
 		float exposure = 0.f;
 		for (int i = 1; i < argc; ++i) {
 			std::string a = argv[i];
@@ -103,8 +104,12 @@ int main(int argc, char** argv) {
 			else if (a == "--screenshot_dir") shot_dir = val();
 			else if (a == "--render_mode") render_mode = val();
 			else if (a == "--exposure") exposure = (float)std::atof(val().c_str());
-			else if (a == "--no-gui" || a == "--no-train" || a == "--vr") { /* headless inference build */ }
-			else if (a == "--mode" || a == "-m" || a == "--network" || a == "--config" || a == "-n" || a == "-c") { (void)val(); std::cerr << "warning: " << a << " has no effect in this build\n"; }
+			else if (a == "--n_steps") n_steps = std::atoi(val().c_str()); // scripts/run.py:66
+			else if (a == "--save_snapshot") save_snapshot = val();       // scripts/run.py:37
+			else if (a == "--network" || a == "--config" || a == "-n" || a == "-c") network = val(); // src/main.cu:96-101
+			else if (a == "--no-train") no_train = true;
+			else if (a == "--no-gui" || a == "--vr") { /* headless build */ }
+			else if (a == "--mode" || a == "-m") { (void)val(); std::cerr << "warning: " << a << " has no effect in this build\n"; }
 			else if (!a.empty() && a[0] == '-') throw std::runtime_error("unknown flag " + a);
 			else files.push_back(a);
 		}
@@ -118,6 +123,22 @@ int main(int argc, char** argv) {
 			testbed.load_training_data(scene);
 		}
 		if (!snapshot.empty()) testbed.load_snapshot(snapshot);
+		// training (scripts/run.py:172-208): n_steps < 0 with a scene and no snapshot trains run.py's default of 35000 steps
+		if (!network.empty()) testbed.reload_network_from_file(network);
+		if (n_steps < 0 && !scene.empty() && snapshot.empty() && !no_train && testbed.m_training_data_available && (!save_snapshot.empty() || !screenshot.empty() || !shot_transforms.empty())) n_steps = 35000;
+		if (n_steps > 0 && !no_train) {
+			if (!testbed.m_training_data_available) throw std::runtime_error("No training data available (the dataset's images must be PNG files).");
+			testbed.m_train = true;
+			while ((int)testbed.m_training_step < n_steps && testbed.frame()) {
+				if (testbed.m_training_step % 1000 == 0 || (int)testbed.m_training_step == n_steps) std::cerr << "step " << testbed.m_training_step << " loss " << testbed.m_loss << "\n";
+				if (!testbed.m_train) break;
+			}
+			testbed.m_train = false;
+		}
+		if (!save_snapshot.empty()) {
+			testbed.save_snapshot(save_snapshot, false);
+			std::cerr << "wrote " << save_snapshot << "\n";
+		}
 		if (render_mode == "ShadeEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeEnvMap;
 		else if (render_mode == "AO") testbed.m_render_mode = ngp::ERenderMode::AO;
 		else if (render_mode == "Positions") testbed.m_render_mode = ngp::ERenderMode::Positions;
@@ -153,7 +174,7 @@ int main(int argc, char** argv) {
 			write_png(screenshot, img, width, height, exposure);
 			std::cerr << "wrote " << screenshot << "\n";
 		} else {
-			std::cerr << "nothing to render: give --screenshot or --screenshot_transforms (this build has no window and does not train)\n";
+			if (save_snapshot.empty()) std::cerr << "nothing to do: give --screenshot, --screenshot_transforms or --n_steps with --save_snapshot (this build has no window)\n";
 		}
 		return 0;
 	} catch (const std::exception& e) {

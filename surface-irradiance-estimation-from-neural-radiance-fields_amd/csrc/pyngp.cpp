@@ -35,6 +35,10 @@ PYBIND11_MODULE(pyngp, m) {
 	// the reference registers the name "Shade" twice (python_api.cu:284-294), which pybind11 rejects at import;
 	// ShadeNerf keeps its own name here
 	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).value("VisPosNeg", EColorSpace::VisPosNeg).export_values();
+	py::enum_<ELossType>(m, "LossType")
+		.value("L2", ELossType::L2).value("L1", ELossType::L1).value("Mape", ELossType::Mape).value("Smape", ELossType::Smape)
+		.value("Huber", ELossType::Huber).value("LogL1", ELossType::LogL1).value("RelativeL2", ELossType::RelativeL2)
+		.export_values();
 	py::enum_<ERenderMode>(m, "RenderMode")
 		.value("AO", ERenderMode::AO).value("Shade", ERenderMode::Shade).value("Normals", ERenderMode::Normals)
 		.value("Positions", ERenderMode::Positions).value("Depth", ERenderMode::Depth).value("Distortion", ERenderMode::Distortion)
@@ -59,6 +63,11 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("dataset", &Testbed::Nerf::Training::dataset)
 		.def_readwrite("view", &Testbed::Nerf::Training::view)
 		.def_readwrite("random_bg_color", &Testbed::Nerf::Training::random_bg_color)
+		.def_readwrite("linear_colors", &Testbed::Nerf::Training::linear_colors)
+		.def_readwrite("loss_type", &Testbed::Nerf::Training::loss_type)
+		.def_readwrite("snap_to_pixel_centers", &Testbed::Nerf::Training::snap_to_pixel_centers)
+		.def_readwrite("density_grid_decay", &Testbed::Nerf::Training::density_grid_decay)
+		.def_readonly("n_images_for_training", &Testbed::Nerf::Training::n_images_for_training)
 		.def_readwrite("near_distance", &Testbed::Nerf::Training::near_distance);
 	py::class_<Testbed::Nerf>(testbed, "Nerf")
 		.def_readwrite("render_min_transmittance", &Testbed::Nerf::render_min_transmittance)
@@ -122,7 +131,20 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("training_step", &Testbed::m_training_step)
 		.def_readonly("loss", &Testbed::m_loss)
 		.def_readwrite("brdf", &Testbed::brdf)
-		.def_property("shall_train", [](Testbed& t) { return t.m_train; },
-			[](Testbed& t, bool v) { if (v) throw std::runtime_error("training is out of scope of the MI355X inference renderer"); t.m_train = false; })
+		.def_readwrite("shall_train", &Testbed::m_train)
+		.def_readwrite("shall_train_encoding", &Testbed::m_train_encoding)
+		.def_readwrite("shall_train_network", &Testbed::m_train_network)
+		.def_readwrite("training_batch_size", &Testbed::m_training_batch_size)
+		.def_readwrite("seed", &Testbed::m_seed)
+		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>(), "Process a single frame: one training step when shall_train is set (headless, nothing is drawn).")
+		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>(), "Perform a single training step with a specified batch size.")
+		.def("reset", &Testbed::reset_network, py::arg("reset_density_grid") = true, "Reset training.")
+		.def("reload_network_from_file", &Testbed::reload_network_from_file, py::arg("path") = "", "Reload the network from a config file.")
+		.def("set_training_image", [](Testbed& t, int frame_idx, py::array_t<float, py::array::c_style | py::array::forcecast> img) {
+				py::buffer_info b = img.request();
+				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error("image should be (H,W,C) where C=4");
+				t.set_training_image(frame_idx, (int)b.shape[1], (int)b.shape[0], (const float*)b.ptr);
+			}, py::arg("frame_idx"), py::arg("img"),
+			"nerf.training.set_image of the reference (python_api.cu:691-697): a float (H,W,4) image, linear colour space, premultiplied alpha")
 		.def_readonly("nerf", &Testbed::nerf);
 }

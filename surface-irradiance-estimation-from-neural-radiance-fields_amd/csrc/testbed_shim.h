@@ -17,6 +17,7 @@
 namespace ngp {
 
 enum class ETestbedMode : int { Nerf, Sdf, Image, Volume, Geometry, None }; // common.h:35-43
+enum class ELossType : int { L2, L1, Mape, Smape, Huber, LogL1, RelativeL2 }; // common.h:84-92
 enum class EColorSpace : int { Linear, SRGB, VisPosNeg }; // common.h
 enum class ERenderMode : int { AO, Shade, Normals, Positions, Depth, Distortion, Cost, Slice, ShadeNerf, ShadeEnvMap, ShadeGridEnvMap, EncodingVis }; // common.h:58-72
 
@@ -45,8 +46,14 @@ public:
 		struct Training {
 			NerfDatasetView dataset;
 			int view = 0;
-			bool random_bg_color = true; // training-only settings run.py touches: accepted, no effect on inference
+			// nerf.h:98-117 defaults; pushed to the context before every training step
+			bool random_bg_color = true;
+			bool linear_colors = false;
+			ELossType loss_type = ELossType::Huber; // configs/nerf/base.json "loss" (reset_network, src/testbed.cu:3912)
+			bool snap_to_pixel_centers = true;
 			float near_distance = 0.1f;
+			float density_grid_decay = 0.95f;
+			int n_images_for_training = 0; // images with pixels on the device
 		} training;
 	} nerf;
 
@@ -86,7 +93,77 @@ public:
 		} else {
 			check(ngp_load_training_data(m_ctx, path.c_str()));
 			sync_dataset();
+			// images (PNG) for training; a dataset whose images are absent or of another format still serves its cameras
+			int32_t n_loaded = 0;
+			if (ngp_load_training_images(m_ctx, &n_loaded) != 0) n_loaded = 0;
+			nerf.training.n_images_for_training = n_loaded;
+			m_training_data_available = n_loaded > 0;
 		}
+	}
+	// ---- training (src/testbed.cu:3820-4210 reset_network, 4364-4470 train, 3600-3660 frame; python_api.cu:416-434)
+	void reset_network(bool reset_density_grid = true) {
+		(void)reset_density_grid; // a fresh network always starts from an empty occupancy grid here
+		check(ngp_reset_network(m_ctx, m_log2_hashmap_size, m_seed));
+		m_training_step = 0;
+		m_loss = 0.f;
+		sync_model_state();
+	}
+	void reload_network_from_file(const std::string& path = "") {
+		// configs/nerf/*.json: the render path is specialised for base.json's shapes; what varies between the shipped
+		// configs that it accepts is the table size (base 19, small 15, base_14 14, big 21)
+		if (!path.empty()) {
+			FILE* f = fopen(path.c_str(), "rb");
+			if (!f) throw std::runtime_error("Network config \"" + path + "\" does not exist.");
+			std::string text;
+			char buf[4096];
+			size_t got;
+			while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+			fclose(f);
+			size_t k = text.find("\"log2_hashmap_size\"");
+			if (k != std::string::npos) {
+				k = text.find(':', k);
+				if (k != std::string::npos) m_log2_hashmap_size = (uint32_t)strtoul(text.c_str() + k + 1, nullptr, 10);
+			}
+			for (const char* unsupported : {"\"TiledGrid\"", "\"Frequency\"", "\"CutlassMLP\"", "\"Identity\""})
+				if (text.find(unsupported) != std::string::npos) throw std::runtime_error(std::string("network config uses ") + unsupported + ", which the MI355X path does not implement (configs/nerf/base.json shapes only)");
+		}
+		reset_network();
+	}
+	void set_training_image(int frame_idx, int width, int height, const float* rgba_linear_premultiplied) { // Nerf::Training::set_image, python_api.cu:46-64
+		check(ngp_set_training_image(m_ctx, frame_idx, width, height, rgba_linear_premultiplied, NGP_IMAGE_FLOAT));
+		m_training_data_available = true;
+	}
+	void train(uint32_t batch_size) {
+		if (!m_training_data_available) { // src/testbed.cu:4365-4369
+			m_train = false;
+			return;
+		}
+		if (m_testbed_mode == ETestbedMode::None) throw std::runtime_error("Cannot train without a mode.");
+		ngp_model_desc d{};
+		if (ngp_get_model(m_ctx, &d) != 0 || d.n_params == 0) reset_network(); // "Creating neural network trainer."
+		ngp_training_opts o{};
+		check(ngp_get_training_opts(m_ctx, &o));
+		o.loss_type = (int32_t)nerf.training.loss_type;
+		o.random_bg_color = nerf.training.random_bg_color;
+		o.linear_colors = nerf.training.linear_colors;
+		o.snap_to_pixel_centers = nerf.training.snap_to_pixel_centers;
+		o.near_distance = nerf.training.near_distance;
+		o.density_grid_decay = nerf.training.density_grid_decay;
+		o.train_network = m_train_network;
+		o.train_encoding = m_train_encoding;
+		o.color_space = (int32_t)m_color_space;
+		for (int i = 0; i < 3; ++i) o.background_color[i] = m_background_color[(size_t)i];
+		check(ngp_set_training_opts(m_ctx, &o));
+		float loss = 0.f;
+		check(ngp_train(m_ctx, 1, batch_size, &loss));
+		ngp_training_state st{};
+		check(ngp_get_training_state(m_ctx, &st));
+		m_training_step = st.training_step;
+		m_loss = st.loss;
+	}
+	bool frame() { // headless: one training step when shall_train is set; there is no window to close
+		if (m_train) train(m_training_batch_size);
+		return true;
 	}
 	void load_snapshot(const std::string& path) {
 		check(ngp_load_snapshot_file(m_ctx, path.c_str()));
@@ -280,6 +357,11 @@ public:
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.f;
 	bool m_train = false;
+	bool m_train_encoding = true, m_train_network = true;
+	bool m_training_data_available = false;
+	uint32_t m_training_batch_size = 1u << 18;
+	uint32_t m_seed = 1337;
+	uint32_t m_log2_hashmap_size = 19;
 	std::string m_data_path, m_root_dir;
 	std::array<float, 6> m_aabb{0, 0, 0, 1, 1, 1}, m_render_aabb{0, 0, 0, 1, 1, 1};
 	uint32_t m_training_step = 0;

@@ -177,6 +177,7 @@ def load_library():
     L.ngp_get_training_opts.argtypes = [vp, C.POINTER(TrainingOpts)]
     L.ngp_set_training_image.argtypes = [vp, ip, C.c_int32, C.c_int32, vp, C.c_int32]
     L.ngp_train.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.ngp_load_training_images.argtypes = [vp, vp]
     L.ngp_get_training_state.argtypes = [vp, C.POINTER(TrainingState)]
     L.ngp_train_prepare_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.ngp_train_gradients.argtypes = [vp, C.c_uint32, vp]
@@ -503,6 +504,11 @@ class Context:
             a, t = np.ascontiguousarray(img, np.float32), IMAGE_FLOAT
         assert a.ndim == 3 and a.shape[2] == 4
         self._check(self.L.ngp_set_training_image(self.h, view, a.shape[1], a.shape[0], _p(a), t))
+
+    def load_training_images(self):
+        n = C.c_int32(0)
+        self._check(self.L.ngp_load_training_images(self.h, C.byref(n)))
+        return n.value
 
     def train(self, n_steps=1, batch_size=1 << 18):
         loss = C.c_float(0)

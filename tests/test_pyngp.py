@@ -52,9 +52,9 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     testbed.root_dir = str(tmp_path)
     testbed.load_file(snap)
     assert testbed.mode == pyngp.TestbedMode.Nerf
-    testbed.shall_train = False
-    with pytest.raises(RuntimeError, match="out of scope"):
-        testbed.shall_train = True
+    # no training data: a frame with shall_train set clears the flag like Testbed::train (src/testbed.cu:4365-4369)
+    testbed.shall_train = True
+    assert testbed.frame() and not testbed.shall_train and testbed.training_step == 0
     testbed.background_color = [0.0, 0.0, 0.0, 1.0]
     testbed.snap_to_pixel_centers = True
     testbed.nerf.render_min_transmittance = 1e-4
