@@ -1,6 +1,6 @@
 // NeRF training step on gfx950. One step is five launches:
 //
-//   train_generate_samples_kernel   one thread per ray: pixel draw, occupancy march, NerfCoordinates    (:737-890)
+//   train_generate_samples_kernel   one wave per ray: pixel draw, speculative occupancy march, NerfCoordinates (:737-890)
 //   network_inference (tcnn order)  the fused MLP on the training parameters                            (:3303)
 //   train_loss_kernel               one wave per ray: scans for composite / loss / dL/d(rgb, sigma), compaction (:893-1213)
 //   train_backward_kernel           forward again + backward + weight gradients + grid scatter, fused
@@ -77,43 +77,31 @@ NGP_DEV bool train_aabb_contains(const ModelParams& M, f3 p) {
 	       p.z <= M.aabb_min[2] + M.aabb_diag[2];
 }
 
-// density_grid_occupied_at for a marching thread: the 4x4x4-block summary in LDS answers for empty space, and the 64
-// occupancy bits of the block the ray is in (one aligned 8-byte word of the Morton-ordered bitfield) stay in two
-// registers -- a ray spends ~18 consecutive steps in one block -- so the serial march waits for global memory once per
-// block instead of once per step. The decisions, and with them every t, are those of the plain lookup.
-struct OccBlock {
-	uint32_t key; // (mip << 26) | block; 0xffffffff: nothing cached
-	uint2 bits;
-};
-NGP_DEV bool occupied_cached(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, uint32_t mip, OccBlock& cache) {
-	const float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
-	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
-	const int ix = (int)(pos.x * (float)NERF_GRIDSIZE), iy = (int)(pos.y * (float)NERF_GRIDSIZE), iz = (int)(pos.z * (float)NERF_GRIDSIZE);
-	if (ix < 0 || ix >= (int)NERF_GRIDSIZE || iy < 0 || iy >= (int)NERF_GRIDSIZE || iz < 0 || iz >= (int)NERF_GRIDSIZE) return false;
-	const uint32_t idx = morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
-	const uint32_t block = idx >> 6;
-	if (!((s_coarse[mip * COARSE_WORDS_PER_MIP + (block >> 5)] >> (block & 31u)) & 1u)) return false;
-	const uint32_t key = (mip << 26) | block;
-	if (cache.key != key) {
-		cache.bits = *(const uint2*)(bitfield + (size_t)(NERF_GRID_N_CELLS / 8) * mip + (size_t)block * 8u);
-		cache.key = key;
-	}
-	const uint32_t bit = idx & 63u;
-	return (((bit & 32u) ? cache.bits.y : cache.bits.x) >> (bit & 31u)) & 1u;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // generate_training_samples_nerf, src/testbed_nerf.cu:737-890 (no envmap, no error-map CDFs, no explicit rays, no
-// random max level, static cameras)
-__global__ __launch_bounds__(128) void train_generate_samples_kernel(const ModelParams M, const TrainStepParams P, const TrainImage* __restrict__ images, const TrainBatch B) {
+// random max level, static cameras).
+//
+// The reference marches a ray in one thread, twice (count, then write): up to 1024 dependent iterations of
+// "look up the cell, then either step or jump". With the ~5000 rays of a batch that is a few dozen waves running a
+// long serial chain each -- 2 ms of an otherwise 1.5 ms step. The chain of positions, however, only depends on
+// memory through the yes/no answers, so ONE WAVE owns a ray and speculates:
+//   dense mode   the 64 positions t_0 = t, t_{k+1} = t_k + calc_dt(t_k) that the loop visits if every cell is occupied
+//                are formed once (a short scalar-like recurrence, no memory), lane k tests position k, and a ballot
+//                finds the first empty or outside one: everything in front of it is accepted at once;
+//   jump mode    after an empty cell the 16 positions of "every cell empty" (advance_to_next_voxel chained) are formed
+//                and tested the same way; the first occupied one hands over to dense mode.
+// Accepted positions are exactly the reference loop's (the same functions applied in the same order to the same
+// values); they wait in LDS until the ray's offset is known, then all lanes write the coordinates.
+constexpr int GEN_RAYS_PER_BLOCK = 4;
+__global__ __launch_bounds__(256) void train_generate_samples_kernel(const ModelParams M, const TrainStepParams P, const TrainImage* __restrict__ images, const TrainBatch B) {
 	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP];
+	__shared__ float s_t[GEN_RAYS_PER_BLOCK][NERF_STEPS];
 	for (uint32_t k = threadIdx.x; k < (M.max_cascade + 1u) * COARSE_WORDS_PER_MIP; k += blockDim.x) s_coarse[k] = M.coarse[k];
 	__syncthreads();
-	OccBlock occ;
-	occ.key = 0xFFFFFFFFu;
-	occ.bits = make_uint2(0u, 0u);
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * GEN_RAYS_PER_BLOCK + wave;
 	if (i >= P.n_rays) return;
+	float* my_ts = s_t[wave];
 	const uint32_t img = training_image_of(i, P.n_rays, P.n_images);
 	const TrainImage im = images[img];
 	Pcg32 rng = P.rng;
@@ -137,51 +125,92 @@ __global__ __launch_bounds__(128) void train_generate_samples_kernel(const Model
 	float bmax[3] = {M.aabb_min[0] + M.aabb_diag[0], M.aabb_min[1] + M.aabb_diag[1], M.aabb_min[2] + M.aabb_diag[2]};
 	const float tmin = fmaxf(aabb_ray_entry(M.aabb_min, bmax, o, d), 0.0f);
 	const float cone_angle = M.cone_angle;
-	const float startt = advance_n_steps(tmin, cone_angle, rng.next_float());
 	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 
-	// first pass: the number of steps
+	float t = advance_n_steps(tmin, cone_angle, rng.next_float()); // wave-uniform from here on
 	uint32_t j = 0;
-	float t = startt;
-	f3 pos;
-	while (train_aabb_contains(M, pos = add3(o, scale3(d, t))) && j < NERF_STEPS) {
-		const float dt = calc_dt(t, cone_angle);
-		const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
-		if (occupied_cached(pos, M.bitfield, s_coarse, mip, occ)) {
-			++j;
-			t += dt;
+	bool dense = true;
+	while (true) {
+		float my_t = t, my_dt = 0.0f, next_t = t;
+		uint32_t my_mip = 0;
+		int n_cand;
+		if (dense) {
+			n_cand = 64;
+			float tt = t;
+			for (int k = 0; k < 64; ++k) {
+				const float dt = calc_dt(tt, cone_angle);
+				if (lane == k) { my_t = tt; my_dt = dt; }
+				tt += dt;
+			}
+			next_t = tt;
 		} else {
-			t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+			n_cand = 16;
+			float tt = t;
+			for (int k = 0; k < 16; ++k) {
+				const float dt = calc_dt(tt, cone_angle);
+				const f3 pos = add3(o, scale3(d, tt));
+				const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
+				if (lane == k) { my_t = tt; my_dt = dt; }
+				tt = advance_to_next_voxel(tt, cone_angle, pos, d, idir, mip);
+			}
+			next_t = tt;
+		}
+		const f3 my_pos = add3(o, scale3(d, my_t));
+		const bool cand = lane < n_cand;
+		const bool inside = cand && train_aabb_contains(M, my_pos);
+		my_mip = mip_from_dt(my_dt, my_pos, M.max_cascade);
+		const bool occupied = inside && density_grid_occupied_at_lds(my_pos, M.bitfield, s_coarse, my_mip);
+		const unsigned long long cand_mask = n_cand == 64 ? ~0ull : ((1ull << n_cand) - 1ull);
+		const unsigned long long out_mask = ~__ballot(inside) & cand_mask, occ_mask = __ballot(occupied);
+		const int first_out = out_mask ? __builtin_ctzll(out_mask) : 64;
+		if (dense) {
+			const unsigned long long empty_mask = ~occ_mask & ~out_mask & cand_mask;
+			const int first_empty = empty_mask ? __builtin_ctzll(empty_mask) : 64;
+			const int stop = first_out < first_empty ? first_out : first_empty;
+			const uint32_t room = NERF_STEPS - j;
+			const uint32_t n_acc = (uint32_t)stop < room ? (uint32_t)stop : room;
+			if ((uint32_t)lane < n_acc) my_ts[j + lane] = my_t;
+			j += n_acc;
+			if (j >= NERF_STEPS || stop == first_out && stop < 64) break; // full, or the ray left the box
+			if (stop == 64) { t = next_t; continue; }
+			// position `stop` is inside and empty: one jump from it, then look for the next occupied cell
+			const float te = __shfl(my_t, stop, 64);
+			const uint32_t mipe = (uint32_t)__shfl((int)my_mip, stop, 64);
+			t = advance_to_next_voxel(te, cone_angle, add3(o, scale3(d, te)), d, idir, mipe);
+			dense = false;
+		} else {
+			const int first_occ = occ_mask ? __builtin_ctzll(occ_mask) : 64;
+			if (first_out < first_occ) break; // left the box before meeting anything
+			if (first_occ < 64) {
+				t = __shfl(my_t, first_occ, 64);
+				dense = true;
+			} else {
+				t = next_t;
+			}
 		}
 	}
 	if (j == 0) return;
 	const uint32_t numsteps = j;
-	const uint32_t base = atomicAdd(&B.counters[0], numsteps);
+	uint32_t base = 0, ray_idx = 0;
+	if (lane == 0) base = atomicAdd(&B.counters[0], numsteps);
+	base = (uint32_t)__shfl((int)base, 0, 64);
 	if (base + numsteps > P.max_samples) return;
-	const uint32_t ray_idx = atomicAdd(&B.counters[1], 1u);
-	B.ray_indices[ray_idx] = i;
-	float* r = B.rays + (size_t)ray_idx * 6;
-	r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d_un.x; r[4] = d_un.y; r[5] = d_un.z;
-	B.numsteps[ray_idx * 2 + 0] = numsteps;
-	B.numsteps[ray_idx * 2 + 1] = base;
-
+	if (lane == 0) {
+		ray_idx = atomicAdd(&B.counters[1], 1u);
+		B.ray_indices[ray_idx] = i;
+		float* r = B.rays + (size_t)ray_idx * 6;
+		r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d_un.x; r[4] = d_un.y; r[5] = d_un.z;
+		B.numsteps[ray_idx * 2 + 0] = numsteps;
+		B.numsteps[ray_idx * 2 + 1] = base;
+	}
 	const f3 wdir = mk3((d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f);
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]), adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
-	float* c = B.coords + (size_t)base * TRAIN_COORD_FLOATS;
-	t = startt;
-	j = 0;
-	while (train_aabb_contains(M, pos = add3(o, scale3(d, t))) && j < numsteps) {
-		const float dt = calc_dt(t, cone_angle);
-		const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
-		if (occupied_cached(pos, M.bitfield, s_coarse, mip, occ)) {
-			const f3 w = div3(sub3(pos, amin), adiag);
-			c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = warp_dt(dt); c[4] = wdir.x; c[5] = wdir.y; c[6] = wdir.z;
-			c += TRAIN_COORD_FLOATS;
-			++j;
-			t += dt;
-		} else {
-			t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
-		}
+	for (uint32_t k = lane; k < numsteps; k += 64) {
+		const float tk = my_ts[k];
+		const float dt = calc_dt(tk, cone_angle);
+		const f3 w = div3(sub3(add3(o, scale3(d, tk)), amin), adiag);
+		float* c = B.coords + (size_t)(base + k) * TRAIN_COORD_FLOATS;
+		c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = warp_dt(dt); c[4] = wdir.x; c[5] = wdir.y; c[6] = wdir.z;
 	}
 }
 
@@ -933,7 +962,7 @@ __global__ void train_loss_sum_kernel(const float* __restrict__ loss, uint32_t n
 
 // ---------------------------------------------------------------------------------------------------------
 void launch_train_generate_samples(const ModelParams& M, const TrainStepParams& P, const TrainImage* images, const TrainBatch& B, hipStream_t stream) {
-	hipLaunchKernelGGL(train_generate_samples_kernel, dim3((P.n_rays + 127) / 128), dim3(128), 0, stream, M, P, images, B);
+	hipLaunchKernelGGL(train_generate_samples_kernel, dim3((P.n_rays + GEN_RAYS_PER_BLOCK - 1) / GEN_RAYS_PER_BLOCK), dim3(256), 0, stream, M, P, images, B); // one wave per ray
 }
 void launch_train_inference(const ModelParams& M, const uint4* frags, const uint32_t* counters, uint32_t max_samples, const float* coords, uint16_t* out, int n_cus,
                             hipStream_t stream) {
