@@ -468,7 +468,7 @@ int ngp_reset_network(ngp_ctx* ctx, uint32_t log2_hashmap_size, uint64_t seed) {
 		d.n_hidden_density = 1;
 		d.n_hidden_rgb = 2;
 		d.density_out_dims = 16;
-		d.rgb_activation = 2;     // Logistic
+		d.rgb_activation = ctx->dataset.is_hdr ? 3u : 2u; // Exponential for HDR data, else Logistic (load_nerf_post, src/testbed_nerf.cu:2652-2653)
 		d.density_activation = 3; // Exponential
 		const uint32_t aabb_scale = ctx->dataset.views.empty() ? 1u : (uint32_t)ctx->dataset.aabb_scale;
 		d.aabb_scale = aabb_scale;
