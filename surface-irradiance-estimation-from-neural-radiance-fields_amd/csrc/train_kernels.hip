@@ -822,28 +822,36 @@ __global__ __launch_bounds__(BLOCK, 1) void train_backward_kernel(const ModelPar
 				if (mine_a != 0.0f) atomicAdd(gbase + (size_t)(idx_a >> 1) + (c & 3), mine_a);
 				if (mine_b != 0.0f) atomicAdd(gbase + (size_t)(idx_b >> 1) + (c & 3), mine_b);
 			} else {
-				// a quad (4 consecutive samples) takes turns: in turn t its four lanes add the four features of sample t's corners
-#define NGP_QUAD_TURN(t)                                                                                                                       \
-				{                                                                                                                              \
-					const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[0]), (t) * 0x55, 0xF, 0xF, false)); \
-					const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[1]), (t) * 0x55, 0xF, 0xF, false)); \
-					const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[2]), (t) * 0x55, 0xF, 0xF, false)); \
-					const float g3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, gf[3]), (t) * 0x55, 0xF, 0xF, false)); \
-					const float gm = (c & 2) ? ((c & 1) ? g3 : g2) : ((c & 1) ? g1 : g0);                                                       \
-					if (__builtin_amdgcn_ballot_w64(gm != 0.0f) != 0ull) {                                                                      \
-						_Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                         \
-							const uint32_t ik = (uint32_t)__builtin_amdgcn_mov_dpp((int)cs.index[k], (t) * 0x55, 0xF, 0xF, false);               \
-							const float wk = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[k]), (t) * 0x55, 0xF, 0xF, false)); \
-							const float v = wk * gm;                                                                                            \
-							if (v != 0.0f) atomicAdd(gbase + (size_t)(ik >> 1) + (c & 3), v);                                                   \
-						}                                                                                                                       \
-					}                                                                                                                           \
+				// An octet (8 consecutive samples) takes turns: in turn t its lanes (e = which corner of an x-pair, f = feature)
+				// add sample t's corners two at a time. The corners of an x-pair are neighbouring entries whenever x is even
+				// (hashed levels: index ^ 1) or the level is dense, so about half of the pairs leave as ONE request.
+				// ds_swizzle (bit mode) broadcasts lane t of every octet: lane' = (lane & 0x18) | t.
+#define NGP_OCT_BCAST_F(x, t) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (x)), 0x18 | ((t) << 5)))
+#define NGP_OCT_BCAST_U(x, t) (uint32_t)__builtin_amdgcn_ds_swizzle((int)(x), 0x18 | ((t) << 5))
+#define NGP_OCT_TURN(t)                                                                                                  \
+				{                                                                                                        \
+					const float g0 = NGP_OCT_BCAST_F(gf[0], t), g1 = NGP_OCT_BCAST_F(gf[1], t), g2 = NGP_OCT_BCAST_F(gf[2], t), g3 = NGP_OCT_BCAST_F(gf[3], t); \
+					const float gm = (c & 2) ? ((c & 1) ? g3 : g2) : ((c & 1) ? g1 : g0);                                 \
+					if (__builtin_amdgcn_ballot_w64(gm != 0.0f) != 0ull) {                                                \
+						_Pragma("unroll") for (int pr = 0; pr < 4; ++pr) {                                                \
+							const uint32_t i0 = NGP_OCT_BCAST_U(cs.index[2 * pr], t), i1 = NGP_OCT_BCAST_U(cs.index[2 * pr + 1], t); \
+							const float w0 = NGP_OCT_BCAST_F(w[2 * pr], t), w1 = NGP_OCT_BCAST_F(w[2 * pr + 1], t);       \
+							const float v = ((c & 4) ? w1 : w0) * gm;                                                     \
+							if (v != 0.0f) atomicAdd(gbase + (size_t)(((c & 4) ? i1 : i0) >> 1) + (c & 3), v);            \
+						}                                                                                                 \
+					}                                                                                                     \
 				}
-				NGP_QUAD_TURN(0)
-				NGP_QUAD_TURN(1)
-				NGP_QUAD_TURN(2)
-				NGP_QUAD_TURN(3)
-#undef NGP_QUAD_TURN
+				NGP_OCT_TURN(0)
+				NGP_OCT_TURN(1)
+				NGP_OCT_TURN(2)
+				NGP_OCT_TURN(3)
+				NGP_OCT_TURN(4)
+				NGP_OCT_TURN(5)
+				NGP_OCT_TURN(6)
+				NGP_OCT_TURN(7)
+#undef NGP_OCT_TURN
+#undef NGP_OCT_BCAST_F
+#undef NGP_OCT_BCAST_U
 			}
 		}
 	}
