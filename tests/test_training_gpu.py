@@ -111,6 +111,30 @@ def test_sample_generation_and_loss_match_the_oracle(native, oracle, dataset, sc
     ctx.close()
 
 
+@pytest.mark.parametrize("opts", [
+    dict(loss_type=0, random_bg_color=0, background_color=(0.2, 0.4, 0.6), snap_to_pixel_centers=0, linear_colors=1),  # L2, fixed background, free uv, linear
+    dict(loss_type=6, color_space=0, near_distance=0.5),  # RelativeL2, linear colour space targets, a wide near-distance penalty
+    dict(loss_type=1, random_bg_color=0),  # L1 on the default black background
+])
+def test_training_options_reach_the_kernels(native, oracle, dataset, scene_unit, opts):
+    ctx = _ctx_with_data(native, dataset)
+    _check_batch_against_oracle(ctx, oracle, dataset["images"], scene_unit, opts=opts)
+    ctx.close()
+
+
+def test_train_network_and_encoding_switches(native, dataset, scene_unit):
+    """m_train_network / m_train_encoding -> optimize_matrix_params / optimize_non_matrix_params (src/testbed.cu:4436-4442)"""
+    for net, enc in ((1, 0), (0, 1)):
+        ctx = _ctx_with_data(native, dataset)
+        ctx.set_model(scene_unit)
+        ctx.set_training_opts(train_network=net, train_encoding=enc)
+        w0, _ = ctx.training_params()
+        ctx.train(2, 1 << 15)
+        w1, _ = ctx.training_params()
+        assert (np.any(w1[:10240] != w0[:10240])) == bool(net) and (np.any(w1[10240:] != w0[10240:])) == bool(enc)
+        ctx.close()
+
+
 def test_sample_generation_and_loss_with_cascades(native, oracle, dataset_big, scene_big):
     """mip_from_dt across cascades, exponential stepping in calc_dt / advance_to_next_voxel, rays that start inside the box."""
     ctx = _ctx_with_data(native, dataset_big)
@@ -152,11 +176,13 @@ def test_png_images_decode_to_the_same_batch(native, oracle, dataset, scene_unit
     ctx.close()
 
 
-def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit, coord_tol=2e-6, same_frac=0.995, count_tol=2e-4):
+def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit, coord_tol=2e-6, same_frac=0.995, count_tol=2e-4, opts=None):
     import oracle as O
 
     dataset = {"images": view_pixels}
     ctx.set_model(scene_unit)
+    if opts:
+        ctx.set_training_opts(**opts)
     b = ctx.train_prepare_batch(TARGET)
     n_rays = b["n_rays"]
     assert n_rays == 4096
@@ -166,6 +192,11 @@ def _check_batch_against_oracle(ctx, oracle, view_pixels, scene_unit, coord_tol=
     o.n_rays, o.n_images, o.rng = n_rays, len(POSES), oracle.train_rng(1337, 0)
     o.snap_to_pixel_centers, o.random_bg_color, o.linear_colors, o.color_space, o.loss_type = 1, 1, 0, 1, 4
     o.near_distance, o.loss_scale, o.density_grid_mean = 0.1, 128.0, float(scene_unit["density_grid_mean"])
+    for k, v in (opts or {}).items():
+        if k == "background_color":
+            o.background = (O.C.c_float * 3)(*v)
+        else:
+            setattr(o, k, v)
     gen = oracle.train_generate_samples(m, images, o, TARGET * 16)
     # --- generate_training_samples_nerf: the same rays survive with the same number of steps
     n_kept = int(b["counters"][1])
