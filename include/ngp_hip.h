@@ -296,9 +296,12 @@ NGP_API int ngp_get_training_opts(const ngp_ctx* ctx, ngp_training_opts* opts);
  * width/height replace the view's resolution */
 NGP_API int ngp_set_training_image(ngp_ctx* ctx, int view, int32_t width, int32_t height, const void* rgba, int32_t image_type);
 /* Decode the dataset's image files into training images (the reference does this inside load_nerf with stb_image,
- * src/nerf_loader.cu:520-640): 8/16-bit PNG files only -- views whose file is missing or of another format stay without
- * pixels and take no part in training. Fails when no view could be loaded. */
+ * src/nerf_loader.cu:520-640): PNG and baseline JPEG files -- views whose file is missing or of another format (EXR,
+ * progressive JPEG ...) stay without pixels and take no part in training. Fails when no view could be loaded. */
 NGP_API int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out);
+/* The decoder behind it, on its own (needs no device): PNG (8/16-bit, non-interlaced) and baseline JPEG -> RGBA8.
+ * rgba_out may be NULL to query the size; error_out (nullable) receives the reason on failure. */
+NGP_API int ngp_decode_image(const void* bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgba_out, size_t rgba_capacity, char* error_out, size_t error_capacity);
 /* n_steps x Testbed::train(batch_size): occupancy-grid refresh on training_prep_nerf's schedule, one train_nerf_step,
  * the optimizer, the counters; loss_out (nullable) receives the running loss. batch_size: a multiple of 128, 2^18 in the
  * reference's GUI and scripts/run.py */

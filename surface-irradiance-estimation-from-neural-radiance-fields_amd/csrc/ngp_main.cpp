@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
 		if (!network.empty()) testbed.reload_network_from_file(network);
 		if (n_steps < 0 && !scene.empty() && snapshot.empty() && !no_train && testbed.m_training_data_available && (!save_snapshot.empty() || !screenshot.empty() || !shot_transforms.empty())) n_steps = 35000;
 		if (n_steps > 0 && !no_train) {
-			if (!testbed.m_training_data_available) throw std::runtime_error("No training data available (the dataset's images must be PNG files).");
+			if (!testbed.m_training_data_available) throw std::runtime_error("No training data available (the dataset's images must be PNG or baseline JPEG files).");
 			testbed.m_train = true;
 			while ((int)testbed.m_training_step < n_steps && testbed.frame()) {
 				if (testbed.m_training_step % 1000 == 0 || (int)testbed.m_training_step == n_steps) std::cerr << "step " << testbed.m_training_step << " loss " << testbed.m_loss << "\n";

@@ -2,6 +2,7 @@
 // train_nerf_step, NerfCounters (src/testbed.cu:3820-4210, 4364-4470; src/testbed_nerf.cu:2914-3431) and the optimizer
 // chain of configs/nerf/base.json (tcnn Ema > ExponentialDecay > Adam). Kernels: train_kernels.hip.
 #include "ngp_host.h"
+#include "jpeg_decode.h"
 
 #include <zlib.h>
 
@@ -385,6 +386,13 @@ bool decode_png(const std::string& bytes, std::vector<uint8_t>& rgba, int& width
 	return true;
 }
 
+bool decode_image(const std::string& bytes, std::vector<uint8_t>& rgba, int& width, int& height, std::string& why) {
+	if (bytes.size() >= 8 && (uint8_t)bytes[0] == 0x89 && bytes[1] == 'P') return decode_png(bytes, rgba, width, height, why);
+	if (bytes.size() >= 3 && (uint8_t)bytes[0] == 0xFF && (uint8_t)bytes[1] == 0xD8) return decode_jpeg(bytes, rgba, width, height, why);
+	why = "only PNG and JPEG images are decoded";
+	return false;
+}
+
 } // namespace
 
 namespace ngp {
@@ -540,6 +548,26 @@ int ngp_set_training_image(ngp_ctx* ctx, int view, int32_t width, int32_t height
 	});
 }
 
+int ngp_decode_image(const void* bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgba_out, size_t rgba_capacity, char* error_out, size_t error_capacity) {
+	std::string why;
+	try {
+		if (!bytes || !width || !height) throw std::runtime_error("null argument");
+		std::vector<uint8_t> rgba;
+		int w = 0, h = 0;
+		if (!decode_image(std::string((const char*)bytes, n_bytes), rgba, w, h, why)) throw std::runtime_error(why);
+		*width = w;
+		*height = h;
+		if (rgba_out) {
+			if (rgba_capacity < rgba.size()) throw std::runtime_error("output buffer too small");
+			memcpy(rgba_out, rgba.data(), rgba.size());
+		}
+		return 0;
+	} catch (const std::exception& e) {
+		if (error_out && error_capacity) snprintf(error_out, error_capacity, "%s", e.what());
+		return -1;
+	}
+}
+
 int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out) {
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
@@ -550,11 +578,10 @@ int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out) {
 			if (v.d_pixels) { ++n_loaded; continue; }
 			std::string why;
 			if (v.abs_path.empty() || !file_exists(v.abs_path)) why = "no such file";
-			else if (!ends_with_ci(v.abs_path, ".png")) why = "only PNG images are decoded";
 			else {
 				std::vector<uint8_t> rgba;
 				int w = 0, h = 0;
-				if (decode_png(read_file(v.abs_path), rgba, w, h, why)) {
+				if (decode_image(read_file(v.abs_path), rgba, w, h, why)) {
 					if (ngp_set_training_image(ctx, (int)i, w, h, rgba.data(), NGP_IMAGE_BYTE) != 0) throw std::runtime_error(ctx->error);
 					++n_loaded;
 					continue;

@@ -93,7 +93,7 @@ public:
 		} else {
 			check(ngp_load_training_data(m_ctx, path.c_str()));
 			sync_dataset();
-			// images (PNG) for training; a dataset whose images are absent or of another format still serves its cameras
+			// images (PNG, baseline JPEG) for training; a dataset whose images are absent or of another format still serves its cameras
 			int32_t n_loaded = 0;
 			if (ngp_load_training_images(m_ctx, &n_loaded) != 0) n_loaded = 0;
 			nerf.training.n_images_for_training = n_loaded;

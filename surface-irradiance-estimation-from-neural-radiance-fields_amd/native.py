@@ -178,6 +178,7 @@ def load_library():
     L.ngp_set_training_image.argtypes = [vp, ip, C.c_int32, C.c_int32, vp, C.c_int32]
     L.ngp_train.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.ngp_load_training_images.argtypes = [vp, vp]
+    L.ngp_decode_image.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_size_t]
     L.ngp_get_training_state.argtypes = [vp, C.POINTER(TrainingState)]
     L.ngp_train_prepare_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.ngp_train_gradients.argtypes = [vp, C.c_uint32, vp]
@@ -192,6 +193,19 @@ def _p(a):
 
 
 LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR = range(6)
+
+
+def decode_image(data):
+    """PNG / baseline JPEG bytes -> (H, W, 4) uint8 through the library's decoder."""
+    L = load_library()
+    w, h = C.c_int32(0), C.c_int32(0)
+    err = C.create_string_buffer(256)
+    if L.ngp_decode_image(data, len(data), C.byref(w), C.byref(h), None, 0, err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    if L.ngp_decode_image(data, len(data), C.byref(w), C.byref(h), _p(out), out.size, err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    return out
 
 
 def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0):

@@ -419,3 +419,69 @@ def test_constant_division_is_exact(tmp_path):
     subprocess.check_call(["gcc", *flags, "-o", str(exe), os.path.join(ROOT, "tests", "aux", "div_const_check.c"), "-lm"])
     out = subprocess.run([str(exe), "1" if has_fma else "251"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
+
+
+def test_image_decoders_against_pillow(native):
+    """ngp_decode_image (what ngp_load_training_images feeds on): PNG exactly, baseline JPEG within the +-3 levels that
+    separate two conforming IDCT / upsampling implementations; unsupported files are refused with a reason."""
+    import io
+
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    h, w = 67, 101
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 9.0), 128 + 100 * np.cos(yy / 7.0), (xx * 2 + yy * 3) % 256, 255 * (xx > yy)], -1)
+    img = (img + rng.normal(0, 6, img.shape)).clip(0, 255).astype(np.uint8)
+
+    def png(im, **kw):
+        b = io.BytesIO()
+        im.save(b, format="PNG", **kw)
+        return b.getvalue()
+
+    assert np.array_equal(native.decode_image(png(Image.fromarray(img))), img)  # RGBA
+    rgb = native.decode_image(png(Image.fromarray(img[..., :3]), compress_level=1))
+    assert np.array_equal(rgb[..., :3], img[..., :3]) and (rgb[..., 3] == 255).all()
+    grey = native.decode_image(png(Image.fromarray(img[..., 0])))
+    assert np.array_equal(grey[..., 0], img[..., 0]) and np.array_equal(grey[..., 1], grey[..., 2])
+    la = native.decode_image(png(Image.fromarray(img[..., [0, 3]], "LA")))
+    assert np.array_equal(la[..., 0], img[..., 0]) and np.array_equal(la[..., 3], img[..., 3])
+    pal_im = Image.fromarray(img[..., :3]).quantize(32)
+    assert np.array_equal(native.decode_image(png(pal_im))[..., :3], np.asarray(pal_im.convert("RGB")))
+    g16 = (img[..., 0].astype(np.uint16) << 8) | 0x5A
+    assert np.array_equal(native.decode_image(png(Image.fromarray(g16)))[..., 0], img[..., 0])  # 16-bit: the high byte
+    for sub in (0, 1, 2):  # 4:4:4, 4:2:2, 4:2:0
+        for extra in ({}, {"restart_marker_blocks": 5}):
+            b = io.BytesIO()
+            try:
+                Image.fromarray(img[..., :3]).save(b, format="JPEG", quality=90, subsampling=sub, **extra)
+            except TypeError:
+                continue
+            ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB")).astype(int)
+            got = native.decode_image(b.getvalue())
+            d = np.abs(got[..., :3].astype(int) - ref)
+            assert got.shape == (h, w, 4) and d.max() <= 3 and d.mean() < 0.1 and (got[..., 3] == 255).all()
+    b = io.BytesIO()
+    Image.fromarray(img[..., 1]).save(b, format="JPEG", quality=85)
+    assert np.abs(native.decode_image(b.getvalue())[..., 0].astype(int) - np.asarray(Image.open(io.BytesIO(b.getvalue()))).astype(int)).max() <= 2
+    b = io.BytesIO()
+    Image.fromarray(img[..., :3]).save(b, format="JPEG", progressive=True)
+    with pytest.raises(RuntimeError, match="progressive"):
+        native.decode_image(b.getvalue())
+    with pytest.raises(RuntimeError, match="interlaced"):
+        native.decode_image(_interlaced_png())
+    with pytest.raises(RuntimeError, match="only PNG and JPEG"):
+        native.decode_image(b"GIF89a" + b"\0" * 64)
+    base = io.BytesIO()
+    Image.fromarray(img[..., :3]).save(base, format="JPEG", quality=90)
+    with pytest.raises(RuntimeError, match="truncated|corrupt|without image data"):
+        native.decode_image(base.getvalue()[:200])
+
+
+def _interlaced_png():
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
