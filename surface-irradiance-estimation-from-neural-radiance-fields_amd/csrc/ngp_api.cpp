@@ -870,7 +870,8 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			v.abs_path = resolve(v.path);
 			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
 			v.resolution[1] = (int)(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
-			if (v.resolution[0] <= 0 || v.resolution[1] <= 0) throw std::runtime_error("transforms.json must provide 'w' and 'h' (images are not decoded on the inference path)");
+			if ((v.resolution[0] <= 0 || v.resolution[1] <= 0) && !probe_image_size(v.abs_path, v.resolution[0], v.resolution[1]))
+				throw std::runtime_error("transforms.json gives no 'w' / 'h' and the resolution of '" + v.abs_path + "' cannot be read (PNG or JPEG expected)");
 			v.focal_length[0] = v.focal_length[1] = 1000.f;
 			bool got = read_focal_length(json, v.focal_length, v.resolution);
 			got |= read_focal_length(frame, v.focal_length, v.resolution);

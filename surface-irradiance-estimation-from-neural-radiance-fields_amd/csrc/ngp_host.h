@@ -258,6 +258,7 @@ void refresh_density_grid_host(ngp_ctx* ctx);
 uint16_t half_from_float(float f);
 // ngp_train.cpp
 void free_training(ngp_ctx* ctx);
+bool probe_image_size(const std::string& path, int& width, int& height);
 void sync_inference_model(ngp_ctx* ctx); // render what has been trained (no-op when nothing changed)
 void sync_host_params(ngp_ctx* ctx);     // ctx->params <- training parameters, for snapshots
 

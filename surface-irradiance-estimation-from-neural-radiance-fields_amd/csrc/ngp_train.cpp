@@ -397,6 +397,40 @@ bool decode_image(const std::string& bytes, std::vector<uint8_t>& rgba, int& wid
 
 namespace ngp {
 
+// resolution of a PNG / JPEG file from its header (the loader needs it when transforms.json gives no "w" / "h",
+// as in the NeRF-synthetic scenes; the reference takes it from the decoded image, src/nerf_loader.cu:560-600)
+bool probe_image_size(const std::string& path, int& width, int& height) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	std::string head(1 << 16, '\0');
+	f.read(&head[0], (std::streamsize)head.size());
+	head.resize((size_t)f.gcount());
+	const uint8_t* d = (const uint8_t*)head.data();
+	const size_t n = head.size();
+	if (n >= 24 && d[0] == 0x89 && d[1] == 'P' && !memcmp(d + 12, "IHDR", 4)) {
+		width = (int)be32(d + 16);
+		height = (int)be32(d + 20);
+		return width > 0 && height > 0;
+	}
+	if (n >= 4 && d[0] == 0xFF && d[1] == 0xD8) {
+		size_t pos = 2;
+		while (pos + 9 < n) {
+			if (d[pos] != 0xFF) { ++pos; continue; }
+			const int marker = d[pos + 1];
+			if (marker == 0xFF) { ++pos; continue; }
+			if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD8)) { pos += 2; continue; }
+			const size_t len = ((size_t)d[pos + 2] << 8) | d[pos + 3];
+			if (marker >= 0xC0 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
+				height = (d[pos + 5] << 8) | d[pos + 6];
+				width = (d[pos + 7] << 8) | d[pos + 8];
+				return width > 0 && height > 0;
+			}
+			pos += 2 + len;
+		}
+	}
+	return false;
+}
+
 void free_training(ngp_ctx* ctx) {
 	if (!ctx->train) return;
 	TrainState& T = *ctx->train;

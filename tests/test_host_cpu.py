@@ -485,3 +485,23 @@ def _interlaced_png():
         return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
 
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+
+
+def test_resolution_comes_from_the_image_when_the_json_has_none(tmp_path, native):
+    """NeRF-synthetic style transforms (camera_angle_x only): the loader reads w / h from the PNG / JPEG header."""
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "train")
+    Image.fromarray(np.zeros((30, 40, 4), np.uint8)).save(tmp_path / "train" / "r_0.png")
+    Image.fromarray(np.zeros((30, 40, 3), np.uint8)).save(tmp_path / "train" / "r_1.jpg", quality=80)
+    frames = [{"file_path": "./train/r_0", "transform_matrix": np.eye(4).tolist()}, {"file_path": "./train/r_1.jpg", "transform_matrix": np.eye(4).tolist()}]
+    (tmp_path / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911, "frames": frames}))
+    ctx = native.Context(-1)
+    ctx.load_training_data(str(tmp_path / "transforms_train.json"))
+    for i in range(2):
+        v = ctx.training_view(i)
+        assert v["resolution"].tolist() == [40, 30] and np.allclose(v["focal_length"], 0.5 * 40 / np.tan(0.5 * 0.6911), rtol=1e-5)
+    frames.append({"file_path": "./train/missing", "transform_matrix": np.eye(4).tolist()})
+    (tmp_path / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911, "frames": frames}))
+    with pytest.raises(RuntimeError, match="cannot be read"):
+        ctx.load_training_data(str(tmp_path / "transforms_train.json"))
+    ctx.close()
