@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -79,12 +80,46 @@ def pmc_traffic():
         return None
 
 
+def training_probe(native, scene_mod, gt_ctx):
+    """SURVEY 8 f-2, reported beside the headline (never part of `value`): the training step at the reference's batch of
+    2^18 samples on views rendered from the bench scene. Failures are reported, not raised."""
+    try:
+        res, views, warm, steps, batch = 256, 16, 300, 200, 1 << 18
+        focal = scene_mod.focal_from_fov_x(res, FOV_X)
+        opts = native.make_opts(background=(0.0, 0.0, 0.0, 0.0))
+        mats = [scene_mod.orbit_camera(360.0 * k / views, 15.0 + 40.0 * ((k * 7) % views) / views) for k in range(views)]
+        imgs = [gt_ctx.render(native.make_camera(m, res, res, focal), opts) for m in mats]
+        path = scene_mod.write_transforms(os.path.join("/tmp", "bench_train_%d.json" % os.getpid()), mats, res, res, FOV_X)
+        tctx = native.Context(0)
+        tctx.load_training_data(path)
+        os.remove(path)
+        for i, im in enumerate(imgs):
+            tctx.set_training_image(i, im)
+        tctx.reset_network(log2_hashmap_size=19, seed=1337)
+        tctx.train(warm, batch)
+        t0 = time.perf_counter()
+        loss = tctx.train(steps, batch)
+        dt = time.perf_counter() - t0
+        st = tctx.training_state()
+        test = scene_mod.orbit_camera(77.0, 33.0)
+        got = tctx.render(native.make_camera(test, res, res, focal), opts)
+        ref = gt_ctx.render(native.make_camera(test, res, res, focal), opts)
+        mse = float(((got[..., :3] - ref[..., :3]) ** 2).mean())
+        tctx.close()
+        return {"steps_per_s": round(steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "batch_samples": batch, "samples_per_s": round(steps * st["measured_batch_size"] / dt),
+                "steps_total": st["training_step"], "loss": loss, "heldout_psnr_db": round(-10.0 * math.log10(max(mse, 1e-12)), 2),
+                "config": "fresh base.json network (HashGrid T2^19), %d views %dx%d rendered from the bench scene" % (views, res, res)}
+    except Exception as e:  # the headline line must come out whatever happens here
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training-probe", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("NGP_BENCH_INFLIGHT", "0")),
@@ -239,6 +274,8 @@ def main():
             out["gathered_frame_max_abs_diff_vs_single_gpu"] = gather_diff  # rank 0's check of the assembled frame, outside the timed region
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scene_mod)
+        if world == 1 and not args.no_training_probe:
+            out["training"] = training_probe(native, scene_mod, ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
