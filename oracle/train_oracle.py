@@ -68,9 +68,6 @@ def corners(enc, pos01):
     return res_out
 
 
-SH_C = None
-
-
 def sh4(dir01):
     d = np.asarray(dir01, np.float64) * 2.0 - 1.0
     x, y, z = d[:, 0], d[:, 1], d[:, 2]

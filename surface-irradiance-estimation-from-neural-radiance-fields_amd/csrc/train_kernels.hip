@@ -1,6 +1,6 @@
 // NeRF training step on gfx950. One step is five launches:
 //
-//   train_generate_samples_kernel   one wave per ray: pixel draw, speculative occupancy march, NerfCoordinates (:737-890)
+//   train_generate_samples_kernel   16 lanes per ray: pixel draw, speculative occupancy march, NerfCoordinates (:737-890)
 //   network_inference (tcnn order)  the fused MLP on the training parameters                            (:3303)
 //   train_loss_kernel               one wave per ray: scans for composite / loss / dL/d(rgb, sigma), compaction (:893-1213)
 //   train_backward_kernel           forward again + backward + weight gradients + grid scatter, fused
@@ -83,34 +83,38 @@ NGP_DEV bool train_aabb_contains(const ModelParams& M, f3 p) {
 //
 // The reference marches a ray in one thread, twice (count, then write): up to 1024 dependent iterations of
 // "look up the cell, then either step or jump". With the ~5000 rays of a batch that is a few dozen waves running a
-// long serial chain each -- 2 ms of an otherwise 1.5 ms step. The chain of positions, however, only depends on
-// memory through the yes/no answers, so ONE WAVE owns a ray and speculates:
-//   dense mode   the 64 positions t_0 = t, t_{k+1} = t_k + calc_dt(t_k) that the loop visits if every cell is occupied
-//                are formed once (a short scalar-like recurrence, no memory), lane k tests position k, and a ballot
-//                finds the first empty or outside one: everything in front of it is accepted at once;
+// long serial chain each -- 2 ms of an otherwise 1 ms step. The chain of positions, however, only depends on memory
+// through the yes/no answers, so a ROW of 16 lanes owns a ray (four rays per wave) and speculates:
+//   dense mode   the 16 positions t_0 = t, t_{k+1} = t_k + calc_dt(t_k) that the loop visits if every cell is occupied
+//                are formed once (a short recurrence, no memory), lane k tests position k, and the row's ballot bits
+//                find the first empty or outside one: everything in front of it is accepted at once;
 //   jump mode    after an empty cell the 16 positions of "every cell empty" (advance_to_next_voxel chained) are formed
 //                and tested the same way; the first occupied one hands over to dense mode.
+// The recurrences are the serial part; the four rows of a wave run theirs side by side in the same instructions.
 // Accepted positions are exactly the reference loop's (the same functions applied in the same order to the same
-// values); they wait in LDS until the ray's offset is known, then all lanes write the coordinates.
-constexpr int GEN_RAYS_PER_BLOCK = 4;
-__global__ __launch_bounds__(256) void train_generate_samples_kernel(const ModelParams M, const TrainStepParams P, const TrainImage* __restrict__ images, const TrainBatch B) {
-	__shared__ uint32_t s_coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP];
-	__shared__ float s_t[GEN_RAYS_PER_BLOCK][NERF_STEPS];
+// values); they wait in LDS until the ray's offset is known, then the row writes the coordinates.
+constexpr int GEN_RAYS_PER_WAVE = 4, GEN_WAVES_PER_BLOCK = 2, GEN_CAND = 16;
+__global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_samples_kernel(const ModelParams M, const TrainStepParams P, const TrainImage* __restrict__ images,
+                                                                                         const TrainBatch B) {
+	extern __shared__ char s_gen[];
+	float* s_t = (float*)s_gen;                                                                    // [rays per block][NERF_STEPS]
+	uint32_t* s_coarse = (uint32_t*)(s_gen + sizeof(float) * NERF_STEPS * GEN_RAYS_PER_WAVE * GEN_WAVES_PER_BLOCK); // [max_cascade + 1][1024]
 	for (uint32_t k = threadIdx.x; k < (M.max_cascade + 1u) * COARSE_WORDS_PER_MIP; k += blockDim.x) s_coarse[k] = M.coarse[k];
 	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t i = blockIdx.x * GEN_RAYS_PER_BLOCK + wave;
-	if (i >= P.n_rays) return;
-	float* my_ts = s_t[wave];
-	const uint32_t img = training_image_of(i, P.n_rays, P.n_images);
-	const TrainImage im = images[img];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+	const uint32_t i = (blockIdx.x * GEN_WAVES_PER_BLOCK + wave) * GEN_RAYS_PER_WAVE + g;
+	float* my_ts = s_t + (size_t)(wave * GEN_RAYS_PER_WAVE + g) * NERF_STEPS;
+
+	// ---- ray setup, identical in the 16 lanes of a row
+	bool done = i >= P.n_rays;
+	const uint32_t ic = done ? 0u : i;
+	const TrainImage im = images[training_image_of(ic, P.n_rays, P.n_images)];
 	Pcg32 rng = P.rng;
-	rng.advance((uint64_t)(uint32_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
+	rng.advance((uint64_t)(uint32_t)(ic * N_MAX_RANDOM_SAMPLES_PER_RAY));
 	float u, v;
 	training_uv(rng, im, P.snap_to_pixel_centers, u, v);
-	if (read_training_pixel(im, u, v).x < 0.0f) return;
+	if (read_training_pixel(im, u, v).x < 0.0f) done = true;
 	(void)rng.next_float(); // motionblur_time
-
 	CameraParams C;
 	C.width = im.res[0]; C.height = im.res[1];
 	C.focal[0] = im.focal[0]; C.focal[1] = im.focal[1];
@@ -127,90 +131,93 @@ __global__ __launch_bounds__(256) void train_generate_samples_kernel(const Model
 	const float cone_angle = M.cone_angle;
 	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 
-	float t = advance_n_steps(tmin, cone_angle, rng.next_float()); // wave-uniform from here on
+	float t = advance_n_steps(tmin, cone_angle, rng.next_float()); // row-uniform from here on
 	uint32_t j = 0;
 	bool dense = true;
-	while (true) {
+	const int row_shift = 16 * g;
+	while (__ballot(!done) != 0ull) {
 		float my_t = t, my_dt = 0.0f, next_t = t;
-		uint32_t my_mip = 0;
-		int n_cand;
-		if (dense) {
-			n_cand = 64;
-			float tt = t;
-			for (int k = 0; k < 64; ++k) {
-				const float dt = calc_dt(tt, cone_angle);
-				if (lane == k) { my_t = tt; my_dt = dt; }
-				tt += dt;
+		if (__ballot(!done && dense) != 0ull) {
+			if (!done && dense) {
+				float tt = t;
+				for (int k = 0; k < GEN_CAND; ++k) {
+					const float dt = calc_dt(tt, cone_angle);
+					if (c == k) { my_t = tt; my_dt = dt; }
+					tt += dt;
+				}
+				next_t = tt;
 			}
-			next_t = tt;
-		} else {
-			n_cand = 16;
-			float tt = t;
-			for (int k = 0; k < 16; ++k) {
-				const float dt = calc_dt(tt, cone_angle);
-				const f3 pos = add3(o, scale3(d, tt));
-				const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
-				if (lane == k) { my_t = tt; my_dt = dt; }
-				tt = advance_to_next_voxel(tt, cone_angle, pos, d, idir, mip);
+		}
+		if (__ballot(!done && !dense) != 0ull) {
+			if (!done && !dense) {
+				float tt = t;
+				for (int k = 0; k < GEN_CAND; ++k) {
+					const float dt = calc_dt(tt, cone_angle);
+					const f3 pos = add3(o, scale3(d, tt));
+					const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
+					if (c == k) { my_t = tt; my_dt = dt; }
+					tt = advance_to_next_voxel(tt, cone_angle, pos, d, idir, mip);
+				}
+				next_t = tt;
 			}
-			next_t = tt;
 		}
 		const f3 my_pos = add3(o, scale3(d, my_t));
-		const bool cand = lane < n_cand;
-		const bool inside = cand && train_aabb_contains(M, my_pos);
-		my_mip = mip_from_dt(my_dt, my_pos, M.max_cascade);
+		const bool inside = !done && train_aabb_contains(M, my_pos);
+		const uint32_t my_mip = mip_from_dt(my_dt, my_pos, M.max_cascade);
 		const bool occupied = inside && density_grid_occupied_at_lds(my_pos, M.bitfield, s_coarse, my_mip);
-		const unsigned long long cand_mask = n_cand == 64 ? ~0ull : ((1ull << n_cand) - 1ull);
-		const unsigned long long out_mask = ~__ballot(inside) & cand_mask, occ_mask = __ballot(occupied);
-		const int first_out = out_mask ? __builtin_ctzll(out_mask) : 64;
+		// the row's 16 answers
+		const uint32_t in_mask = (uint32_t)(__ballot(inside) >> row_shift) & 0xFFFFu, occ_mask = (uint32_t)(__ballot(occupied) >> row_shift) & 0xFFFFu;
+		const uint32_t out_mask = ~in_mask & 0xFFFFu;
+		const int first_out = out_mask ? __builtin_ctz(out_mask) : GEN_CAND;
+		// row broadcasts of the candidate a decision may need (executed by every lane: shuffles want the whole wave)
+		const uint32_t empty_mask = ~occ_mask & in_mask;
+		const int first_empty = empty_mask ? __builtin_ctz(empty_mask) : GEN_CAND;
+		const int first_occ = occ_mask ? __builtin_ctz(occ_mask) : GEN_CAND;
+		const int pick = dense ? (first_empty < GEN_CAND ? first_empty : 0) : (first_occ < GEN_CAND ? first_occ : 0);
+		const float t_pick = __shfl(my_t, row_shift + pick, 64);
+		const uint32_t mip_pick = (uint32_t)__shfl((int)my_mip, row_shift + pick, 64);
+		if (done) continue;
 		if (dense) {
-			const unsigned long long empty_mask = ~occ_mask & ~out_mask & cand_mask;
-			const int first_empty = empty_mask ? __builtin_ctzll(empty_mask) : 64;
 			const int stop = first_out < first_empty ? first_out : first_empty;
 			const uint32_t room = NERF_STEPS - j;
 			const uint32_t n_acc = (uint32_t)stop < room ? (uint32_t)stop : room;
-			if ((uint32_t)lane < n_acc) my_ts[j + lane] = my_t;
+			if ((uint32_t)c < n_acc) my_ts[j + c] = my_t;
 			j += n_acc;
-			if (j >= NERF_STEPS || stop == first_out && stop < 64) break; // full, or the ray left the box
-			if (stop == 64) { t = next_t; continue; }
-			// position `stop` is inside and empty: one jump from it, then look for the next occupied cell
-			const float te = __shfl(my_t, stop, 64);
-			const uint32_t mipe = (uint32_t)__shfl((int)my_mip, stop, 64);
-			t = advance_to_next_voxel(te, cone_angle, add3(o, scale3(d, te)), d, idir, mipe);
-			dense = false;
-		} else {
-			const int first_occ = occ_mask ? __builtin_ctzll(occ_mask) : 64;
-			if (first_out < first_occ) break; // left the box before meeting anything
-			if (first_occ < 64) {
-				t = __shfl(my_t, first_occ, 64);
-				dense = true;
-			} else {
-				t = next_t;
+			if (j >= NERF_STEPS || (stop == first_out && stop < GEN_CAND)) done = true; // full, or the ray left the box
+			else if (stop == GEN_CAND) t = next_t;
+			else { // position `stop` is inside and empty: one jump from it, then look for the next occupied cell
+				t = advance_to_next_voxel(t_pick, cone_angle, add3(o, scale3(d, t_pick)), d, idir, mip_pick);
+				dense = false;
 			}
+		} else {
+			if (first_out < first_occ) done = true; // left the box before meeting anything
+			else if (first_occ < GEN_CAND) { t = t_pick; dense = true; }
+			else t = next_t;
 		}
 	}
-	if (j == 0) return;
 	const uint32_t numsteps = j;
-	uint32_t base = 0, ray_idx = 0;
-	if (lane == 0) base = atomicAdd(&B.counters[0], numsteps);
-	base = (uint32_t)__shfl((int)base, 0, 64);
-	if (base + numsteps > P.max_samples) return;
-	if (lane == 0) {
-		ray_idx = atomicAdd(&B.counters[1], 1u);
+	uint32_t base = 0;
+	const bool leader = c == 0 && numsteps > 0;
+	if (leader) base = atomicAdd(&B.counters[0], numsteps);
+	base = (uint32_t)__shfl((int)base, row_shift, 64);
+	const bool fits = numsteps > 0 && base + numsteps <= P.max_samples;
+	if (leader && fits) {
+		const uint32_t ray_idx = atomicAdd(&B.counters[1], 1u);
 		B.ray_indices[ray_idx] = i;
 		float* r = B.rays + (size_t)ray_idx * 6;
 		r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d_un.x; r[4] = d_un.y; r[5] = d_un.z;
 		B.numsteps[ray_idx * 2 + 0] = numsteps;
 		B.numsteps[ray_idx * 2 + 1] = base;
 	}
+	if (!fits) return;
 	const f3 wdir = mk3((d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f);
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]), adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
-	for (uint32_t k = lane; k < numsteps; k += 64) {
+	for (uint32_t k = (uint32_t)c; k < numsteps; k += 16) {
 		const float tk = my_ts[k];
 		const float dt = calc_dt(tk, cone_angle);
 		const f3 w = div3(sub3(add3(o, scale3(d, tk)), amin), adiag);
-		float* c = B.coords + (size_t)(base + k) * TRAIN_COORD_FLOATS;
-		c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = warp_dt(dt); c[4] = wdir.x; c[5] = wdir.y; c[6] = wdir.z;
+		float* co = B.coords + (size_t)(base + k) * TRAIN_COORD_FLOATS;
+		co[0] = w.x; co[1] = w.y; co[2] = w.z; co[3] = warp_dt(dt); co[4] = wdir.x; co[5] = wdir.y; co[6] = wdir.z;
 	}
 }
 
@@ -970,7 +977,9 @@ __global__ void train_loss_sum_kernel(const float* __restrict__ loss, uint32_t n
 
 // ---------------------------------------------------------------------------------------------------------
 void launch_train_generate_samples(const ModelParams& M, const TrainStepParams& P, const TrainImage* images, const TrainBatch& B, hipStream_t stream) {
-	hipLaunchKernelGGL(train_generate_samples_kernel, dim3((P.n_rays + GEN_RAYS_PER_BLOCK - 1) / GEN_RAYS_PER_BLOCK), dim3(256), 0, stream, M, P, images, B); // one wave per ray
+	const uint32_t rays_per_block = GEN_RAYS_PER_WAVE * GEN_WAVES_PER_BLOCK;
+	const size_t lds = sizeof(float) * NERF_STEPS * rays_per_block + (size_t)(M.max_cascade + 1u) * COARSE_WORDS_PER_MIP * sizeof(uint32_t);
+	hipLaunchKernelGGL(train_generate_samples_kernel, dim3((P.n_rays + rays_per_block - 1) / rays_per_block), dim3(64 * GEN_WAVES_PER_BLOCK), lds, stream, M, P, images, B);
 }
 void launch_train_inference(const ModelParams& M, const uint4* frags, const uint32_t* counters, uint32_t max_samples, const float* coords, uint16_t* out, int n_cus,
                             hipStream_t stream) {
