@@ -46,6 +46,7 @@ struct BitReader {
 	uint32_t acc = 0;
 	int n = 0;
 	bool hit_marker = false;
+	int padded = 0; // zero bytes fed past the end of the entropy-coded data
 	void fill() {
 		while (n <= 24) {
 			int byte = 0;
@@ -59,6 +60,7 @@ struct BitReader {
 					++p;
 				}
 			}
+			if (hit_marker || p >= end) ++padded;
 			acc |= (uint32_t)byte << (24 - n);
 			n += 8;
 		}
@@ -66,7 +68,7 @@ struct BitReader {
 	int peek(int k) { fill(); return (int)(acc >> (32 - k)); }
 	void skip(int k) { acc <<= k; n -= k; }
 	int get(int k) { if (k == 0) return 0; const int v = peek(k); skip(k); return v; }
-	void reset() { acc = 0; n = 0; hit_marker = false; }
+	void reset() { acc = 0; n = 0; hit_marker = false; padded = 0; }
 };
 
 inline int decode_symbol(BitReader& br, const Huffman& h) {
@@ -230,6 +232,7 @@ inline bool decode_jpeg(const std::string& bytes, std::vector<uint8_t>& rgba, in
 				H = be16(seg + 1);
 				W = be16(seg + 3);
 				const int nc = d[seg + 5];
+				if ((int64_t)W * H > (1ll << 28)) { why = "JPEG image too large"; return false; }
 				if (W <= 0 || H <= 0 || (nc != 1 && nc != 3)) { why = nc == 4 ? "CMYK JPEG files are not supported" : "bad JPEG frame header"; return false; }
 				comps.resize((size_t)nc);
 				for (int i = 0; i < nc; ++i) {
@@ -285,6 +288,7 @@ inline bool decode_jpeg(const std::string& bytes, std::vector<uint8_t>& rgba, in
 							for (Component& c : comps) c.pred = 0;
 							until_restart = restart_interval;
 						}
+						if (br.padded > 16) { why = "truncated JPEG data"; return false; } // the lookahead never needs more than a few bytes of padding
 						for (Component& c : comps) {
 							for (int by = 0; by < c.v; ++by) {
 								for (int bx = 0; bx < c.h; ++bx) {

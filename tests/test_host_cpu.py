@@ -505,3 +505,26 @@ def test_resolution_comes_from_the_image_when_the_json_has_none(tmp_path, native
     with pytest.raises(RuntimeError, match="cannot be read"):
         ctx.load_training_data(str(tmp_path / "transforms_train.json"))
     ctx.close()
+
+
+def test_image_decoders_survive_mutated_files(tmp_path):
+    """tests/aux/decode_fuzz.cpp under AddressSanitizer + UBSan: truncations, byte flips, 0xFF runs and insertions of
+    PNG / JPEG seeds either decode or are refused -- no crash, no hang (dataset images are untrusted input)."""
+    import subprocess
+
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 255, (40, 56, 4)).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "seed.png")
+    Image.fromarray(img[..., :3]).save(tmp_path / "seed420.jpg", quality=85, subsampling=2)
+    try:
+        Image.fromarray(img[..., :3]).save(tmp_path / "seed444.jpg", quality=95, subsampling=0, restart_marker_blocks=3)
+    except TypeError:
+        Image.fromarray(img[..., :3]).save(tmp_path / "seed444.jpg", quality=95, subsampling=0)
+    exe = str(tmp_path / "fuzz")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "decode_fuzz.cpp")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src, "-o", exe, "-lz"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for seed in ("seed.png", "seed420.jpg", "seed444.jpg"):
+        r = subprocess.run([exe, str(tmp_path / seed), "1500"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "decoded" in r.stdout, (seed, r.stdout[-300:], r.stderr[-800:])
