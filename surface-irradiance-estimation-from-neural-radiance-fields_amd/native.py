@@ -268,7 +268,7 @@ class Context:
 
     def _check(self, rc):
         if rc != 0:
-            raise RuntimeError(self.L.ngp_last_error(self.h).decode())
+            raise RuntimeError(self.L.ngp_last_error(self.h).decode(errors="replace"))
 
     # ---------------------------------------------------------------- model
     def set_model(self, scene):
