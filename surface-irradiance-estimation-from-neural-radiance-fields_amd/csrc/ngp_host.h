@@ -116,8 +116,24 @@ struct TrainState {
 	TrainImage* d_images = nullptr;
 	uint32_t n_images = 0;
 	bool images_dirty = true;
-	TrainBatch B{};
-	uint32_t cap_rays = 0, cap_samples = 0, cap_target = 0;
+	TrainBatch B{}; // the step in flight: gen[cur]'s buffers + the shared ones
+	// sample generation only reads the images, the occupancy bitfield and the step's rng: step N+1's runs on a second
+	// stream beside step N's backward pass, into the other of two buffer sets
+	struct GenSet {
+		uint32_t* counters = nullptr;
+		uint32_t* ray_indices = nullptr;
+		float* rays = nullptr;
+		uint32_t* numsteps = nullptr;
+		float* coords = nullptr;
+		uint32_t cap_rays = 0, cap_samples = 0;
+	} gen[2];
+	int cur = 0;
+	bool pregenerated = false; // gen[cur ^ 1] holds the next step's samples (ev_gen marks them complete)
+	TrainStepParams pre_P{};
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_gen = nullptr, ev_loss = nullptr;
+	uint32_t* h_counters = nullptr; // pinned: counters[4] + loss sum
+	uint32_t cap_loss = 0, cap_out = 0, cap_target = 0;
 	float* d_loss_sum = nullptr;
 	float* d_partials = nullptr; // per-block weight-gradient sums of train_backward_kernel
 	// NerfCounters + Testbed members

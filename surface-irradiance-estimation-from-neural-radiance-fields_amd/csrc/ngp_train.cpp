@@ -157,24 +157,41 @@ void upload_images(ngp_ctx* ctx, TrainState& T) {
 	T.images_dirty = false;
 }
 
-void ensure_workspace(TrainState& T, uint32_t n_rays, uint32_t max_samples, uint32_t target) {
+void ensure_gen_set(TrainState::GenSet& G, uint32_t n_rays, uint32_t max_samples) {
+	if (!G.counters) dev_alloc(G.counters, 4);
+	if (n_rays > G.cap_rays) {
+		dev_free(G.ray_indices); dev_free(G.rays); dev_free(G.numsteps);
+		G.cap_rays = n_rays;
+		dev_alloc(G.ray_indices, n_rays);
+		dev_alloc(G.rays, (size_t)n_rays * 6);
+		dev_alloc(G.numsteps, (size_t)n_rays * 2);
+	}
+	if (max_samples > G.cap_samples) {
+		dev_free(G.coords);
+		G.cap_samples = max_samples;
+		dev_alloc(G.coords, ((size_t)max_samples + 64) * TRAIN_COORD_FLOATS);
+	}
+}
+void ensure_workspace(ngp_ctx* ctx, TrainState& T, uint32_t n_rays, uint32_t max_samples, uint32_t target) {
 	TrainBatch& B = T.B;
-	if (!B.counters) dev_alloc(B.counters, 4);
-	if (n_rays > T.cap_rays) {
-		dev_free(B.ray_indices); dev_free(B.rays); dev_free(B.numsteps); dev_free(B.loss);
-		T.cap_rays = n_rays;
-		dev_alloc(B.ray_indices, n_rays);
-		dev_alloc(B.rays, (size_t)n_rays * 6);
-		dev_alloc(B.numsteps, (size_t)n_rays * 2);
+	if (!T.stream2) {
+		NGP_HIP_CHECK(hipStreamCreateWithFlags(&T.stream2, hipStreamNonBlocking));
+		NGP_HIP_CHECK(hipEventCreateWithFlags(&T.ev_gen, hipEventDisableTiming));
+		NGP_HIP_CHECK(hipEventCreateWithFlags(&T.ev_loss, hipEventDisableTiming));
+		NGP_HIP_CHECK(hipHostMalloc((void**)&T.h_counters, 8 * sizeof(uint32_t)));
+	}
+	if (n_rays > T.cap_loss) { // read by the previous step's loss kernels only: complete (the host waited for ev_loss)
+		dev_free(B.loss);
+		T.cap_loss = n_rays;
 		dev_alloc(B.loss, n_rays);
 	}
-	if (max_samples > T.cap_samples) {
-		dev_free(B.coords); dev_free(B.mlp_out);
-		T.cap_samples = max_samples;
-		dev_alloc(B.coords, ((size_t)max_samples + 64) * TRAIN_COORD_FLOATS);
+	if (max_samples > T.cap_out) {
+		dev_free(B.mlp_out);
+		T.cap_out = max_samples;
 		dev_alloc(B.mlp_out, ((size_t)max_samples + 64) * 4);
 	}
 	if (target > T.cap_target) {
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // a backward pass may still read the old buffers
 		dev_free(B.coords_compacted); dev_free(B.dloss);
 		T.cap_target = target;
 		dev_alloc(B.coords_compacted, ((size_t)target + 64) * TRAIN_COORD_FLOATS);
@@ -185,33 +202,22 @@ void ensure_workspace(TrainState& T, uint32_t n_rays, uint32_t max_samples, uint
 }
 
 // training_prep_nerf on Testbed::train's schedule (src/testbed.cu:4412-4434)
-void training_prep(ngp_ctx* ctx, TrainState& T) {
-	uint32_t n_prep_to_skip = T.training_step / 16u;
+void training_prep(ngp_ctx* ctx, TrainState& T);
+
+bool prep_due(const TrainState& T, uint32_t step) {
+	uint32_t n_prep_to_skip = step / 16u;
 	n_prep_to_skip = n_prep_to_skip < 1u ? 1u : (n_prep_to_skip > 16u ? 16u : n_prep_to_skip);
-	if (T.training_step % n_prep_to_skip != 0) return;
-	sync_inference_model(ctx); // NerfNetwork::density runs on the inference parameters
-	const uint32_t n_cascades = ctx->max_cascade + 1;
-	if (T.training_step < 256) update_density_grid_device(ctx, T.opts.density_grid_decay, NERF_GRID_N_CELLS * n_cascades, 0, 1);
-	else update_density_grid_device(ctx, T.opts.density_grid_decay, NERF_GRID_N_CELLS / 4 * n_cascades, NERF_GRID_N_CELLS / 4 * n_cascades, 1);
+	return step % n_prep_to_skip == 0;
 }
 
-// generate_training_samples_nerf + inference + compute_loss_kernel_train_nerf of train_nerf_step
-void prepare_batch(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
-	if (target_batch == 0 || target_batch % BATCH_SIZE_GRANULARITY != 0) throw std::runtime_error("the training batch size must be a positive multiple of 128");
-	upload_images(ctx, T);
+// the parameters of the step the state is about to run (train_nerf_step's head, :3183-3260)
+TrainStepParams step_params(const ngp_ctx* ctx, const TrainState& T, uint32_t target_batch) {
 	const uint32_t max_samples = target_batch * 16; // "somewhat of a worst case", :3185
-	uint32_t max_inference;
-	if (T.measured_batch_size_before_compaction == 0) {
-		T.measured_batch_size_before_compaction = max_inference = max_samples;
-	} else {
-		max_inference = next_multiple(std::min(T.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
-	}
-	ensure_workspace(T, T.rays_per_batch, max_inference, target_batch);
-	if (T.training_step == 0) T.n_rays_total = 0;
+	const uint32_t max_inference = T.measured_batch_size_before_compaction == 0 ? max_samples
+	                                                                           : next_multiple(std::min(T.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
 	TrainStepParams P{};
 	P.n_rays = T.rays_per_batch;
-	P.n_rays_total = T.n_rays_total;
-	T.n_rays_total += T.rays_per_batch;
+	P.n_rays_total = T.training_step == 0 ? 0u : T.n_rays_total;
 	P.n_images = T.n_images;
 	P.max_samples = max_inference;
 	P.target_batch = target_batch;
@@ -225,13 +231,60 @@ void prepare_batch(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
 	P.near_distance = T.opts.near_distance;
 	P.loss_scale = TRAIN_LOSS_SCALE;
 	P.density_grid_mean = ctx->bitfield_mean;
+	return P;
+}
+
+TrainBatch gen_batch(const TrainState::GenSet& G) {
+	TrainBatch B{};
+	B.counters = G.counters;
+	B.ray_indices = G.ray_indices;
+	B.rays = G.rays;
+	B.numsteps = G.numsteps;
+	B.coords = G.coords;
+	return B;
+}
+void launch_generate(ngp_ctx* ctx, TrainState& T, int set, const TrainStepParams& P, hipStream_t stream) {
+	TrainState::GenSet& G = T.gen[set];
+	ensure_gen_set(G, P.n_rays, P.max_samples);
+	NGP_HIP_CHECK(hipMemsetAsync(G.counters, 0, 4 * sizeof(uint32_t), stream));
+	launch_train_generate_samples(training_model(ctx), P, T.d_images, gen_batch(G), stream);
+}
+
+// generate_training_samples_nerf + inference + compute_loss_kernel_train_nerf of train_nerf_step
+void prepare_batch(ngp_ctx* ctx, TrainState& T, uint32_t target_batch, bool get_loss_scalar) {
+	if (target_batch == 0 || target_batch % BATCH_SIZE_GRANULARITY != 0) throw std::runtime_error("the training batch size must be a positive multiple of 128");
+	upload_images(ctx, T);
 	hipStream_t stream = ctx->stream;
+	TrainStepParams P;
+	if (T.pregenerated && T.pre_P.target_batch == target_batch) {
+		P = T.pre_P;
+		T.cur ^= 1;
+		NGP_HIP_CHECK(hipStreamWaitEvent(stream, T.ev_gen, 0));
+	} else {
+		if (T.pregenerated) NGP_HIP_CHECK(hipStreamSynchronize(T.stream2)); // samples for another batch size: dropped
+		if (T.measured_batch_size_before_compaction == 0) T.measured_batch_size_before_compaction = target_batch * 16;
+		P = step_params(ctx, T, target_batch);
+	}
+	ensure_workspace(ctx, T, P.n_rays, P.max_samples, target_batch);
+	if (!T.pregenerated || T.pre_P.target_batch != target_batch) launch_generate(ctx, T, T.cur, P, stream);
+	T.pregenerated = false;
+	if (T.training_step == 0) T.n_rays_total = 0;
+	T.n_rays_total += P.n_rays;
+	const TrainState::GenSet& G = T.gen[T.cur];
+	T.B.counters = G.counters;
+	T.B.ray_indices = G.ray_indices;
+	T.B.rays = G.rays;
+	T.B.numsteps = G.numsteps;
+	T.B.coords = G.coords;
 	const ModelParams M = training_model(ctx);
-	NGP_HIP_CHECK(hipMemsetAsync(T.B.counters, 0, 4 * sizeof(uint32_t), stream));
-	NGP_HIP_CHECK(hipMemsetAsync(T.B.loss, 0, (size_t)T.rays_per_batch * sizeof(float), stream));
-	launch_train_generate_samples(M, P, T.d_images, T.B, stream);
-	launch_train_inference(M, T.d_tfrags, T.B.counters, max_inference, T.B.coords, T.B.mlp_out, ctx->n_cus, stream);
+	NGP_HIP_CHECK(hipMemsetAsync(T.B.loss, 0, (size_t)P.n_rays * sizeof(float), stream));
+	launch_train_inference(M, T.d_tfrags, T.B.counters, P.max_samples, T.B.coords, T.B.mlp_out, ctx->n_cus, stream);
 	launch_train_loss(M, P, T.d_images, T.B, stream);
+	// what the host needs to plan the next step, as soon as the loss kernel is through
+	if (get_loss_scalar) launch_train_loss_sum(T.B.loss, P.n_rays, T.d_loss_sum, stream);
+	NGP_HIP_CHECK(hipMemcpyAsync(T.h_counters, T.B.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	if (get_loss_scalar) NGP_HIP_CHECK(hipMemcpyAsync(T.h_counters + 4, T.d_loss_sum, sizeof(float), hipMemcpyDeviceToHost, stream));
+	NGP_HIP_CHECK(hipEventRecord(T.ev_loss, stream));
 	T.last_step = P;
 	T.batch_ready = true;
 }
@@ -241,14 +294,13 @@ void backward(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
 	launch_train_backward(training_model(ctx), T.d_tfrags, T.d_kfrags, T.B.counters, target_batch, T.B.coords_compacted, T.B.dloss, T.d_grad, T.n_matrix, T.d_partials, ctx->n_cus, ctx->stream);
 }
 
-// m_trainer->optimizer_step + ++m_training_step + NerfCounters::update_after_training (:3002-3020, 2923-2947)
-float apply_step(ngp_ctx* ctx, TrainState& T, uint32_t target_batch, bool get_loss_scalar) {
+// m_trainer->optimizer_step (:3002): ExponentialDecay > Adam > Ema, then the fragments of the new weights. Asynchronous.
+void launch_optimizer(ngp_ctx* ctx, TrainState& T) {
 	hipStream_t stream = ctx->stream;
-	// ExponentialDecay::step then Adam::step: the rate of this step uses the factor accumulated so far
 	AdamParams A{};
 	A.n_params = T.n_params;
 	A.n_matrix = T.n_matrix;
-	A.learning_rate = T.opts.learning_rate * T.lr_factor;
+	A.learning_rate = T.opts.learning_rate * T.lr_factor; // the rate of this step uses the factor accumulated so far
 	A.beta1 = T.opts.beta1;
 	A.beta2 = T.opts.beta2;
 	A.epsilon = T.opts.epsilon;
@@ -264,18 +316,19 @@ float apply_step(ngp_ctx* ctx, TrainState& T, uint32_t target_batch, bool get_lo
 	launch_train_optimizer(A, T.d_weights_fp32, T.d_weights, T.d_grad, T.d_m1, T.d_m2, T.d_steps, T.d_ema_tmp, ema ? T.d_weights_ema : nullptr, stream);
 	launch_train_build_fragments(T.d_weights, T.d_tfrags, T.d_kfrags, stream);
 	if (T.opts.decay_interval > 0 && T.optimizer_step >= T.opts.decay_start && (T.optimizer_step - T.opts.decay_start) % T.opts.decay_interval == 0) T.lr_factor *= T.opts.decay_base;
-	++T.training_step;
 	T.inference_dirty = true;
 	T.host_params_dirty = true;
 	T.batch_ready = false;
+}
 
-	uint32_t counters[4];
-	if (get_loss_scalar) launch_train_loss_sum(T.B.loss, T.last_step.n_rays, T.d_loss_sum, stream);
-	NGP_HIP_CHECK(hipMemcpyAsync(counters, T.B.counters, sizeof(counters), hipMemcpyDeviceToHost, stream));
+// ++m_training_step + NerfCounters::update_after_training (:3004-3020, 2923-2947): waits for the loss kernel only --
+// the backward pass and the optimizer keep running
+float finish_step(TrainState& T, uint32_t target_batch, bool get_loss_scalar) {
+	NGP_HIP_CHECK(hipEventSynchronize(T.ev_loss));
+	const uint32_t* counters = T.h_counters;
 	float loss_sum = 0.f;
-	if (get_loss_scalar) NGP_HIP_CHECK(hipMemcpyAsync(&loss_sum, T.d_loss_sum, sizeof(float), hipMemcpyDeviceToHost, stream));
-	NGP_HIP_CHECK(hipStreamSynchronize(stream));
-	NGP_HIP_CHECK(hipGetLastError());
+	memcpy(&loss_sum, T.h_counters + 4, sizeof(float));
+	++T.training_step;
 	T.rng.advance();
 	T.measured_batch_size = 0;
 	T.measured_batch_size_before_compaction = 0;
@@ -290,9 +343,25 @@ float apply_step(ngp_ctx* ctx, TrainState& T, uint32_t target_batch, bool get_lo
 		loss_scalar = loss_sum * (float)T.measured_batch_size / (float)target_batch;
 		T.loss_scalar = loss_scalar;
 	}
-	T.rays_per_batch = (uint32_t)((float)T.rays_per_batch * (float)target_batch / (float)T.measured_batch_size);
+	T.rays_per_batch = (uint32_t)((float)T.last_step.n_rays * (float)target_batch / (float)T.measured_batch_size);
 	T.rays_per_batch = std::min(next_multiple(T.rays_per_batch, BATCH_SIZE_GRANULARITY), 1u << 18);
 	return loss_scalar;
+}
+
+void training_prep(ngp_ctx* ctx, TrainState& T) {
+	if (!prep_due(T, T.training_step)) return;
+	sync_inference_model(ctx); // NerfNetwork::density runs on the inference parameters
+	const uint32_t n_cascades = ctx->max_cascade + 1;
+	if (T.training_step < 256) update_density_grid_device(ctx, T.opts.density_grid_decay, NERF_GRID_N_CELLS * n_cascades, 0, 1);
+	else update_density_grid_device(ctx, T.opts.density_grid_decay, NERF_GRID_N_CELLS / 4 * n_cascades, NERF_GRID_N_CELLS / 4 * n_cascades, 1);
+}
+
+// step N+1's samples, on the second stream, while step N's backward pass and optimizer run
+void pregenerate(ngp_ctx* ctx, TrainState& T, uint32_t target_batch) {
+	T.pre_P = step_params(ctx, T, target_batch);
+	launch_generate(ctx, T, T.cur ^ 1, T.pre_P, T.stream2);
+	NGP_HIP_CHECK(hipEventRecord(T.ev_gen, T.stream2));
+	T.pregenerated = true;
 }
 
 bool decode_image(const std::string& bytes, std::vector<uint8_t>& rgba, int& width, int& height, std::string& why) {
@@ -345,8 +414,13 @@ void free_training(ngp_ctx* ctx) {
 	TrainState& T = *ctx->train;
 	dev_free(T.d_weights_fp32); dev_free(T.d_weights); dev_free(T.d_weights_ema); dev_free(T.d_ema_tmp); dev_free(T.d_grad); dev_free(T.d_m1); dev_free(T.d_m2);
 	dev_free(T.d_steps); dev_free(T.d_tfrags); dev_free(T.d_kfrags); dev_free(T.d_tfrags_inference); dev_free(T.d_kfrags_inference); dev_free(T.d_images); dev_free(T.d_loss_sum); dev_free(T.d_partials);
-	dev_free(T.B.counters); dev_free(T.B.ray_indices); dev_free(T.B.rays); dev_free(T.B.numsteps); dev_free(T.B.coords); dev_free(T.B.mlp_out);
-	dev_free(T.B.coords_compacted); dev_free(T.B.dloss); dev_free(T.B.loss);
+	if (T.stream2) (void)hipStreamSynchronize(T.stream2);
+	for (auto& G : T.gen) { dev_free(G.counters); dev_free(G.ray_indices); dev_free(G.rays); dev_free(G.numsteps); dev_free(G.coords); }
+	dev_free(T.B.mlp_out); dev_free(T.B.coords_compacted); dev_free(T.B.dloss); dev_free(T.B.loss);
+	if (T.stream2) (void)hipStreamDestroy(T.stream2);
+	if (T.ev_gen) (void)hipEventDestroy(T.ev_gen);
+	if (T.ev_loss) (void)hipEventDestroy(T.ev_loss);
+	if (T.h_counters) (void)hipHostFree(T.h_counters);
 	const ngp_training_opts keep = T.opts; // settings outlive a model (they belong to the Testbed, not to the network)
 	delete ctx->train;
 	ctx->train = new TrainState();
@@ -544,10 +618,16 @@ int ngp_train(ngp_ctx* ctx, uint32_t n_steps, uint32_t batch_size, float* loss_o
 			upload_images(ctx, T);
 			training_prep(ctx, T);
 			const bool get_loss_scalar = T.training_step % 16 == 0;
-			prepare_batch(ctx, T, batch_size);
+			prepare_batch(ctx, T, batch_size, get_loss_scalar);
 			backward(ctx, T, batch_size);
-			apply_step(ctx, T, batch_size, get_loss_scalar);
+			launch_optimizer(ctx, T);
+			finish_step(T, batch_size, get_loss_scalar);
+			// the next step's rays do not depend on the weights: generate them beside this step's backward pass, unless
+			// the occupancy grid is refreshed first
+			if (it + 1 < n_steps && !prep_due(T, T.training_step) && !T.images_dirty) pregenerate(ctx, T, batch_size);
 		}
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipGetLastError());
 		if (loss_out) *loss_out = T.loss_scalar;
 	});
 }
@@ -575,7 +655,7 @@ int ngp_train_prepare_batch(ngp_ctx* ctx, uint32_t batch_size, uint32_t* counter
                             float* loss) {
 	return guarded(ctx, [&] {
 		TrainState& T = ensure_training(ctx);
-		prepare_batch(ctx, T, batch_size);
+		prepare_batch(ctx, T, batch_size, true);
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		NGP_HIP_CHECK(hipGetLastError());
 		uint32_t c[4];
@@ -605,7 +685,10 @@ int ngp_train_apply(ngp_ctx* ctx) {
 	return guarded(ctx, [&] {
 		TrainState& T = ensure_training(ctx);
 		if (!T.batch_ready) throw std::runtime_error("no training batch prepared");
-		apply_step(ctx, T, T.last_step.target_batch, true);
+		launch_optimizer(ctx, T);
+		finish_step(T, T.last_step.target_batch, true);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipGetLastError());
 	});
 }
 
