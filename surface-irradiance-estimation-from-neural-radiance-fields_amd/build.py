@@ -17,10 +17,13 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+LIB_EXACT = os.path.join(HERE, "libngp_hip_exact.so")  # -DNGP_EXACT_TCNN_ENCODE: tcnn's fp16 rounding sequence in the grid encode
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     for f in os.listdir(CSRC):
         if os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
@@ -28,18 +31,21 @@ def needs_build():
     return os.path.getmtime(inc) > t
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, exact=False):
+    """exact=True builds the variant whose hash-grid encode reproduces tcnn's rounding sequence bit for bit (the parity
+    tests' reference point for gathers and layout); the default build accumulates with packed fmas, 5 % faster."""
+    lib = LIB_EXACT if exact else LIB
+    if not force and not needs_build(lib):
+        return lib
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + srcs + ["-lz"]
+    cmd = [hipcc()] + FLAGS + (["-DNGP_EXACT_TCNN_ENCODE"] if exact else []) + ["-o", lib] + srcs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed")
-    return LIB
+    return lib
 
 
 def pyngp_path():

@@ -123,6 +123,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    LIB_PATH = os.environ.get("NGP_HIP_LIBRARY") or globals()["LIB_PATH"]  # e.g. the exact-encode variant, libngp_hip_exact.so
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py or the package's build.py). "
                            "There is no CPU fallback.")
