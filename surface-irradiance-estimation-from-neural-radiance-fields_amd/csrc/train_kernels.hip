@@ -998,10 +998,12 @@ void launch_train_backward(const ModelParams& M, const uint4* frags, const uint2
                            const uint16_t* dloss, float* grad, uint32_t n_matrix_params, float* block_partials, int n_blocks, hipStream_t stream) {
 	static_assert(4 * WAVE_SCRATCH >= N_MLP_PARAMS * 4, "the block reduction reuses the waves' scratch");
 	const size_t lds = (size_t)N_TFRAGS * 64 * 16 + (size_t)N_KFRAGS * 64 * 8 + 4 * (size_t)WAVE_SCRATCH;
-	static bool configured = false;
-	if (!configured) {
+	static bool configured[64] = {}; // per device: a process may hold contexts on several GPUs
+	int device = 0;
+	NGP_HIP_CHECK(hipGetDevice(&device));
+	if (device < 0 || device >= 64 || !configured[device]) {
 		NGP_HIP_CHECK(hipFuncSetAttribute((const void*)train_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		configured = true;
+		if (device >= 0 && device < 64) configured[device] = true;
 	}
 	hipLaunchKernelGGL(train_backward_kernel, dim3((uint32_t)n_blocks), dim3(BLOCK), lds, stream, M, frags, kfrags, counters, target_batch, coords, dloss, grad, n_matrix_params,
 	                   block_partials);
