@@ -741,7 +741,17 @@ __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const Model
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	__syncthreads();
 	const int lane = threadIdx.x & 63, c = lane & 15;
-	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	// Sample i visits cell ((i + step n) A + C) mod 2^21 first -- a bijection of i's low 21 bits. The reference lets thread
+	// i take sample i, which sends neighbouring lanes to unrelated cells: every hash-grid gather of the wave misses. The
+	// set of samples is what matters (the splat is an atomic max), so thread t takes the sample whose first cell is t
+	// in Morton order: a wave works on one 4x4x4 block of cells and its gathers share lines.
+	const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+	constexpr uint32_t A = 56924617u, C = 96925573u;
+	constexpr uint32_t AINV = []() { uint32_t x = A; for (int k = 0; k < 5; ++k) x *= 2u - A * x; return x; }(); // A^-1 mod 2^32
+	static_assert(A * AINV == 1u, "modular inverse");
+	// (whole replicas of 2^21 samples only; the samples of a partial replica keep the reference's order)
+	const uint32_t n_whole = n_samples & ~(NERF_GRID_N_CELLS - 1u);
+	const uint32_t i = t < n_whole ? ((t & ~(NERF_GRID_N_CELLS - 1u)) | ((((t & (NERF_GRID_N_CELLS - 1u)) - C) * AINV - step * n_samples) & (NERF_GRID_N_CELLS - 1u))) : t;
 	const bool valid = i < n_samples;
 	// 1 random number to select the level, 3 to select the position
 	rng.advance((uint64_t)i * 4u);
