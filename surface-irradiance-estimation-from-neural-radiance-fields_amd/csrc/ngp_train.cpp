@@ -470,6 +470,7 @@ int ngp_set_training_opts(ngp_ctx* ctx, const ngp_training_opts* opts) {
 			throw std::runtime_error("invalid optimizer settings");
 		if (!ctx->train) ctx->train = new TrainState();
 		ctx->train->opts = *opts;
+		if (ctx->have_desc) ctx->desc.linear_colors = opts->linear_colors; // m_nerf.training.linear_colors is one setting for training and shade_kernel_nerf
 	});
 }
 
@@ -506,7 +507,7 @@ int ngp_reset_network(ngp_ctx* ctx, uint32_t log2_hashmap_size, uint64_t seed) {
 		}
 		for (int i = 0; i < 9; ++i) d.render_aabb_to_local[i] = ctx->dataset.render_aabb_to_local[i];
 		d.cone_angle_constant = aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f); // :2736
-		d.linear_colors = 0;
+		d.linear_colors = (ctx->train && ctx->train->opts.struct_size) ? ctx->train->opts.linear_colors : 0;
 		// parameter count: the same level table the loader builds
 		uint64_t ng = 0;
 		{
