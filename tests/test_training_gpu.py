@@ -122,6 +122,21 @@ def test_training_options_reach_the_kernels(native, oracle, dataset, scene_unit,
     ctx.close()
 
 
+def test_exponential_decay_schedule(native, dataset, scene_unit):
+    """tcnn ExponentialDecay around Adam (configs/nerf/base.json: decay_start 20000, decay_interval 10000, decay_base 0.33):
+    the rate drops by decay_base at optimizer steps decay_start, decay_start + decay_interval, ..."""
+    ctx = _ctx_with_data(native, dataset)
+    ctx.set_model(scene_unit)
+    ctx.set_training_opts(decay_start=3, decay_interval=2, decay_base=0.5)
+    rates = []
+    for _ in range(7):
+        ctx.train(1, 1 << 15)
+        rates.append(ctx.training_state()["learning_rate"])
+    assert np.allclose(rates, [0.01, 0.01, 0.005, 0.005, 0.0025, 0.0025, 0.00125], rtol=1e-6)
+    # the step after a drop moves the weights by the lower rate (first Adam steps move by ~lr)
+    ctx.close()
+
+
 def test_train_network_and_encoding_switches(native, dataset, scene_unit):
     """m_train_network / m_train_encoding -> optimize_matrix_params / optimize_non_matrix_params (src/testbed.cu:4436-4442)"""
     for net, enc in ((1, 0), (0, 1)):
