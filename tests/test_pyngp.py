@@ -20,8 +20,12 @@ def test_pyngp_surface(pyngp):
     assert pyngp.TestbedMode.Geometry != pyngp.TestbedMode.Nerf and hasattr(pyngp.RenderMode, "ShadeEnvMap")
     for m in ("load_training_data", "load_snapshot", "save_snapshot", "load_file", "render", "set_nerf_camera_matrix", "set_camera_to_training_view",
               "camera_matrix", "fov", "fov_axis", "background_color", "snap_to_pixel_centers", "exposure", "render_mode", "shall_train", "nerf",
-              "screen_center", "root_dir", "sun_dir", "up_dir"):
+              "screen_center", "root_dir", "sun_dir", "up_dir",
+              # training surface (python_api.cu:416-434, 487-532)
+              "train", "frame", "reset", "reload_network_from_file", "shall_train_encoding", "shall_train_network", "training_batch_size", "seed",
+              "training_step", "loss", "set_training_image"):
         assert hasattr(pyngp.Testbed, m), m
+    assert pyngp.LossType.Huber != pyngp.LossType.L2 and hasattr(pyngp.LossType, "RelativeL2")
     import torch
 
     if not torch.cuda.is_available():
