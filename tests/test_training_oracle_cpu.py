@@ -129,3 +129,24 @@ def test_loss_kernel_gradient_is_the_derivative_of_its_loss(loss_setup, loss_typ
                 assert abs(got - fd) <= 0.06 * abs(fd) + 2e-3 * scale + reg + 2e-4, (loss_type, ray, j, ch, got, fd)
                 checked += 1
     assert checked > 100
+
+
+def test_training_oracle_matches_golden_vectors():
+    """tests/golden/train_unit_v1.npz (made by make_golden_train.py): the training oracle recomputed from the seeded
+    inputs -- integers and sample positions exactly, floating point to the last few ulps across compilers / numpy."""
+    import importlib.util
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_train", os.path.join(here, "golden", "make_golden_train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.compute()
+    ref = np.load(os.path.join(here, "golden", "train_unit_v1.npz"))
+    for k in ("numsteps", "base", "total", "compacted_numsteps", "grad_index", "n_touched"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(got["coords"], ref["coords"]) and np.array_equal(got["net"], ref["net"])
+    assert np.allclose(got["loss"], ref["loss"], rtol=1e-5, atol=1e-12)
+    d_got, d_ref = got["dloss"].view(np.float16).astype(np.float32), ref["dloss"].view(np.float16).astype(np.float32)
+    assert np.mean(d_got != d_ref) < 1e-3 and np.allclose(d_got, d_ref, rtol=2e-3, atol=1e-7)  # an fp16 rounding may flip with libm's last bit
+    for k in ("grad_value", "grad_matrix", "adam_value", "ema_value"):
+        assert np.allclose(got[k], ref[k], rtol=1e-6, atol=1e-10), k
