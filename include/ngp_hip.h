@@ -302,6 +302,13 @@ NGP_API int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out);
 /* The decoder behind it, on its own (needs no device): PNG (8/16-bit, non-interlaced) and baseline JPEG -> RGBA8.
  * rgba_out may be NULL to query the size; error_out (nullable) receives the reason on failure. */
 NGP_API int ngp_decode_image(const void* bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgba_out, size_t rgba_capacity, char* error_out, size_t error_capacity);
+/* m_render_ground_truth (python_api.cu:490-491; CudaRenderBuffer::overlay_image at alpha 1, src/render_buffer.cu:344-414, called
+ * from Testbed::render_frame_epilogue, src/testbed.cu:4979-4994): the training image of `view`, resampled (nearest) to
+ * width x height around the screen centre, over background_rgba (sRGB values), times 2^exposure, in linear or sRGB output --
+ * what scripts/run.py --test_transforms compares the render with (run.py:236-241). color_space: m_color_space (0 Linear,
+ * 1 SRGB); fov_axis / zoom: m_fov_axis / m_zoom. Host float RGBA out. */
+NGP_API int ngp_render_ground_truth(ngp_ctx* ctx, int view, int32_t width, int32_t height, const float* background_rgba, float exposure, int32_t color_space, int32_t to_srgb,
+                                    int32_t fov_axis, float zoom, float* rgba_out);
 /* n_steps x Testbed::train(batch_size): occupancy-grid refresh on training_prep_nerf's schedule, one train_nerf_step,
  * the optimizer, the counters; loss_out (nullable) receives the running loss. batch_size: a multiple of 128, 2^18 in the
  * reference's GUI and scripts/run.py */

@@ -59,6 +59,8 @@ void launch_train_optimizer(const AdamParams& A, float* weights_fp32, uint16_t* 
                             uint16_t* weights_ema, hipStream_t stream);
 void launch_train_xor_layout(const ModelParams& M, const uint2* src, char* dst, hipStream_t stream);
 void launch_train_loss_sum(const float* loss, uint32_t n, float* out, hipStream_t stream);
+void launch_overlay_image(int width, int height, float exposure, const float* background4, const TrainImage& im, int color_space, int to_srgb, int fov_axis, float zoom, float4* out,
+                          hipStream_t stream);
 
 struct HostMesh { // MeshData (mesh.h:18-24) after load_mesh
 	std::vector<Triangle> tris;        // reordered by the BVH build

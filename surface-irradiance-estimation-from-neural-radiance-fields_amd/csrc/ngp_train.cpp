@@ -612,6 +612,30 @@ int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out) {
 	});
 }
 
+int ngp_render_ground_truth(ngp_ctx* ctx, int view, int32_t width, int32_t height, const float* background_rgba, float exposure, int32_t color_space, int32_t to_srgb,
+                            int32_t fov_axis, float zoom, float* rgba_out) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (view < 0 || (size_t)view >= ctx->dataset.views.size()) throw std::runtime_error("Invalid training view.");
+		const TrainingView& v = ctx->dataset.views[(size_t)view];
+		if (!v.d_pixels) throw std::runtime_error("training view " + std::to_string(view) + " has no image (ngp_load_training_images / ngp_set_training_image)");
+		if (width <= 0 || height <= 0 || !rgba_out || !background_rgba || !(zoom > 0.f) || (fov_axis != 0 && fov_axis != 1)) throw std::runtime_error("invalid ground-truth render arguments");
+		TrainImage im{};
+		im.pixels = v.d_pixels;
+		im.type = v.image_type;
+		im.res[0] = v.resolution[0]; im.res[1] = v.resolution[1];
+		ensure_sync_buffers(ctx);
+		float4* d_out = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)width * height * sizeof(float4)));
+		launch_overlay_image(width, height, exposure, background_rgba, im, color_space, to_srgb, fov_axis, zoom, d_out, ctx->stream);
+		hipError_t e = hipMemcpyAsync(rgba_out, d_out, (size_t)width * height * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		(void)hipFree(d_out);
+		NGP_HIP_CHECK(e);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
 int ngp_train(ngp_ctx* ctx, uint32_t n_steps, uint32_t batch_size, float* loss_out) {
 	return guarded(ctx, [&] {
 		TrainState& T = ensure_training(ctx);

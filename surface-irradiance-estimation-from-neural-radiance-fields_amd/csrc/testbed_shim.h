@@ -303,7 +303,10 @@ public:
 			check(ngp_set_cone_angle_constant(m_ctx, nerf.cone_angle_constant));
 			m_pushed_cone_angle = nerf.cone_angle_constant;
 		}
-		if (m_render_ground_truth) throw std::runtime_error("render_ground_truth shows the training images, which this build does not decode");
+		if (m_render_ground_truth) { // the training image of nerf.training.view over the frame at alpha 1 (src/testbed.cu:4979-4994)
+			check(ngp_render_ground_truth(m_ctx, nerf.training.view, width, height, m_background_color.data(), m_exposure, o.color_space, linear ? 0 : 1, m_fov_axis, m_zoom, out));
+			return;
+		}
 		ngp_geometry_opts g{};
 		memcpy(g.sun_dir, m_sun_dir.data(), 12);
 		memcpy(g.up_dir, m_up_dir.data(), 12);

@@ -960,6 +960,40 @@ __global__ void train_xor_layout_kernel(const LevelInfo L, const uint2* __restri
 	*(uint2*)(dst + L.base8 + ((x << 3) ^ (y * L.mul_y8) ^ (z * L.mul_z8))) = src[L.offset + e];
 }
 
+// CudaRenderBuffer::overlay_image at alpha 1 (src/render_buffer.cu:344-414; Testbed::render_frame_epilogue shows the
+// training image of the current view this way when m_render_ground_truth is set, src/testbed.cu:4979-4994): the image
+// resampled (nearest) around the screen centre, blended over the background, exposure, output colour space.
+__global__ void overlay_image_kernel(int width, int height, float exposure, float4 background, const TrainImage im, int color_space, int to_srgb, int fov_axis, float zoom,
+                                     float4* __restrict__ out) {
+	const int x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= width || y >= height) return;
+	const float scale = (float)im.res[fov_axis] / (float)(fov_axis ? height : width);
+	float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+	fx -= (float)width * 0.5f; fx /= zoom; fx += 0.5f * (float)width;
+	fy -= (float)height * 0.5f; fy /= zoom; fy += 0.5f * (float)height;
+	const float u = (fx - (float)width * 0.5f) * scale + (float)im.res[0] * 0.5f;
+	const float v = (fy - (float)height * 0.5f) * scale + (float)im.res[1] * 0.5f;
+	const int srcx = (int)__builtin_floorf(u), srcy = (int)__builtin_floorf(v);
+	float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (srcx >= 0 && srcy >= 0 && srcx < im.res[0] && srcy < im.res[1]) val = read_training_pixel(im, ((float)srcx + 0.5f) / (float)im.res[0], ((float)srcy + 0.5f) / (float)im.res[1]);
+	f3 color = mk3(val.x, val.y, val.z);
+	f3 bg = mk3(background.x, background.y, background.z);
+	if (color_space != 1) { // the background colour is given in sRGB
+		bg = mk3(srgb_to_linear(bg.x), srgb_to_linear(bg.y), srgb_to_linear(bg.z));
+	} else if (val.w > 0.0f) {
+		color = mk3(linear_to_srgb(color.x / val.w) * val.w, linear_to_srgb(color.y / val.w) * val.w, linear_to_srgb(color.z / val.w) * val.w);
+	} else {
+		color = mk3(0.f, 0.f, 0.f);
+	}
+	const float weight = (1.0f - val.w) * background.w;
+	color = add3(color, scale3(bg, weight));
+	const float alpha = val.w + weight;
+	if (color_space == 1) color = mk3(srgb_to_linear(color.x), srgb_to_linear(color.y), srgb_to_linear(color.z)); // tonemap(): to linear,
+	color = scale3(color, __builtin_exp2f(exposure));                                                              // exposure,
+	if (to_srgb) color = mk3(linear_to_srgb(color.x), linear_to_srgb(color.y), linear_to_srgb(color.z));           // output space
+	out[(size_t)y * width + x] = make_float4(color.x, color.y, color.z, alpha);
+}
+
 __global__ void train_loss_sum_kernel(const float* __restrict__ loss, uint32_t n, float* __restrict__ out) {
 	__shared__ float s[256];
 	float acc = 0.0f;
@@ -1020,6 +1054,11 @@ void launch_train_xor_layout(const ModelParams& M, const uint2* src, char* dst, 
 		const uint32_t n = L.hashed ? L.size : (L.res + 1u) * (L.res + 1u) * (L.res + 1u);
 		hipLaunchKernelGGL(train_xor_layout_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, L, src, dst, n);
 	}
+}
+void launch_overlay_image(int width, int height, float exposure, const float* background4, const TrainImage& im, int color_space, int to_srgb, int fov_axis, float zoom, float4* out,
+                          hipStream_t stream) {
+	hipLaunchKernelGGL(overlay_image_kernel, dim3((width + 15) / 16, (height + 7) / 8), dim3(16, 8), 0, stream, width, height, exposure,
+	                   make_float4(background4[0], background4[1], background4[2], background4[3]), im, color_space, to_srgb, fov_axis, zoom, out);
 }
 void launch_train_loss_sum(const float* loss, uint32_t n, float* out, hipStream_t stream) { hipLaunchKernelGGL(train_loss_sum_kernel, dim3(1), dim3(256), 0, stream, loss, n, out); }
 

@@ -179,6 +179,7 @@ def load_library():
     L.ngp_set_training_image.argtypes = [vp, ip, C.c_int32, C.c_int32, vp, C.c_int32]
     L.ngp_train.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.ngp_load_training_images.argtypes = [vp, vp]
+    L.ngp_render_ground_truth.argtypes = [vp, ip, C.c_int32, C.c_int32, vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]
     L.ngp_decode_image.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_size_t]
     L.ngp_get_training_state.argtypes = [vp, C.POINTER(TrainingState)]
     L.ngp_train_prepare_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
@@ -524,6 +525,12 @@ class Context:
         n = C.c_int32(0)
         self._check(self.L.ngp_load_training_images(self.h, C.byref(n)))
         return n.value
+
+    def render_ground_truth(self, view, width, height, background=(0.0, 0.0, 0.0, 1.0), exposure=0.0, color_space=1, to_srgb=False, fov_axis=1, zoom=1.0):
+        bg = np.asarray(background, np.float32)
+        out = np.zeros((height, width, 4), np.float32)
+        self._check(self.L.ngp_render_ground_truth(self.h, view, width, height, _p(bg), exposure, color_space, int(to_srgb), fov_axis, zoom, _p(out)))
+        return out
 
     def train(self, n_steps=1, batch_size=1 << 18):
         loss = C.c_float(0)

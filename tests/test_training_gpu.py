@@ -392,6 +392,17 @@ def test_pyngp_and_cli_train_a_png_dataset(native, dataset, scene_mod, tmp_path)
     assert testbed.training_step == 300 and 0 < testbed.loss < 0.2 * first
     testbed.shall_train = False
     assert testbed.frame() and testbed.training_step == 300
+    # scripts/run.py --test_transforms (run.py:210-262): ground truth of a view, then the render of the same camera
+    testbed.background_color = [0.0, 0.0, 0.0, 1.0]
+    testbed.snap_to_pixel_centers = True
+    testbed.nerf.render_min_transmittance = 1e-4
+    res = testbed.nerf.training.dataset.metadata[2].resolution
+    testbed.render_ground_truth = True
+    testbed.set_camera_to_training_view(2)
+    ref_image = testbed.render(res[0], res[1], 1, True)
+    testbed.render_ground_truth = False
+    image = testbed.render(res[0], res[1], 4, True)
+    assert ref_image.shape == image.shape == (H, W, 4) and psnr(image[..., :3], ref_image[..., :3]) > 20.0
     testbed.reset()
     assert testbed.training_step == 0
     del testbed
@@ -404,4 +415,42 @@ def test_pyngp_and_cli_train_a_png_dataset(native, dataset, scene_mod, tmp_path)
     ctx = native.Context(0)
     ctx.load_snapshot_file(str(tmp_path / "out.ingp"))
     assert ctx.get_model().log2_hashmap_size == 15
+    ctx.close()
+
+
+def test_render_ground_truth_is_the_training_image(native, dataset):
+    """CudaRenderBuffer::overlay_image (src/render_buffer.cu:344-414), the m_render_ground_truth path of scripts/run.py
+    --test_transforms: same resolution -> the image itself over the background; other resolutions -> nearest resampling
+    about the centre; byte images decode through sRGB."""
+    from conftest import psnr as _psnr
+
+    ctx = _ctx_with_data(native, dataset)
+    img = dataset["images"][3]
+    a = img[..., 3:4]
+    # Linear colour space: premultiplied colour + (1 - a) * srgb_to_linear(bg)
+    bg = np.array([0.25, 0.5, 0.75, 1.0], np.float32)
+    bg_lin = np.where(bg[:3] <= 0.04045, bg[:3] / 12.92, ((bg[:3] + 0.055) / 1.055) ** 2.4)
+    got = ctx.render_ground_truth(3, W, H, background=bg, color_space=0)
+    want = np.concatenate([img[..., :3] + (1 - a) * bg_lin, a + (1 - a)], -1)
+    assert np.abs(got - want).max() < 2e-6
+    # exposure doubles linear values; sRGB output applies the transfer curve
+    got2 = ctx.render_ground_truth(3, W, H, background=bg, color_space=0, exposure=1.0)
+    assert np.allclose(got2[..., :3], 2 * want[..., :3], rtol=1e-5, atol=1e-6)
+    # SRGB colour space (the default): blending happens on sRGB values, the result returns to linear; opaque pixels are unchanged
+    got3 = ctx.render_ground_truth(3, W, H, background=(0, 0, 0, 1), color_space=1)
+    opaque = a[..., 0] > 0.9999
+    assert opaque.sum() > 100 and np.abs(got3[opaque][:, :3] - img[opaque][:, :3]).max() < 2e-3
+    # half resolution: pixel (x, y) shows source pixel (2x + 1, 2y + 1)
+    half = ctx.render_ground_truth(3, W // 2, H // 2, background=bg, color_space=0)
+    assert np.abs(half - want[1::2, 1::2]).max() < 2e-6
+    # zoom 2 about the centre: the middle half of the image, each source pixel twice
+    zoomed = ctx.render_ground_truth(3, W, H, background=bg, color_space=0, zoom=2.0)
+    assert np.abs(zoomed[::2, ::2] - want[H // 4:H // 4 + H // 2, W // 4:W // 4 + W // 2]).max() < 2e-6
+    with pytest.raises(RuntimeError, match="Invalid training view"):
+        ctx.render_ground_truth(99, W, H)
+    ctx.close()
+    # byte images: sRGB, straight alpha
+    ctx = _ctx_with_data(native, dataset, byte_images=True)
+    got4 = ctx.render_ground_truth(3, W, H, background=(0, 0, 0, 1), color_space=0)
+    assert _psnr(got4[..., :3], img[..., :3]) > 38.0  # 8-bit quantisation of the colours and of alpha
     ctx.close()
