@@ -136,6 +136,12 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("shall_train_network", &Testbed::m_train_network)
 		.def_readwrite("training_batch_size", &Testbed::m_training_batch_size)
 		.def_readwrite("seed", &Testbed::m_seed)
+		.def("want_repl", [](Testbed&) { return false; }, "scripts/run.py polls this inside its training loop (the GUI's console key); headless: never")
+		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error("this build is headless: render() / frame() work without a window"); },
+			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
+		.def("init_vr", [](Testbed&) { throw std::runtime_error("this build is headless: no VR"); })
+		.def("load_camera_path", [](Testbed&, const std::string&) { throw std::runtime_error("camera-path rendering (load_camera_path, start_t / end_t) is not supported by the MI355X renderer"); }, py::arg("path"))
+		.def("compute_and_save_marching_cubes_mesh", [](Testbed&, py::args, py::kwargs) { throw std::runtime_error("marching cubes is outside the MI355X renderer's scope (SURVEY section 2)"); })
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>(), "Process a single frame: one training step when shall_train is set (headless, nothing is drawn).")
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>(), "Perform a single training step with a specified batch size.")
 		.def("reset", &Testbed::reset_network, py::arg("reset_density_grid") = true, "Reset training.")

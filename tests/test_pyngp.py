@@ -23,7 +23,7 @@ def test_pyngp_surface(pyngp):
               "screen_center", "root_dir", "sun_dir", "up_dir",
               # training surface (python_api.cu:416-434, 487-532)
               "train", "frame", "reset", "reload_network_from_file", "shall_train_encoding", "shall_train_network", "training_batch_size", "seed",
-              "training_step", "loss", "set_training_image"):
+              "training_step", "loss", "set_training_image", "want_repl", "render_ground_truth", "init_window", "load_camera_path"):
         assert hasattr(pyngp.Testbed, m), m
     assert pyngp.LossType.Huber != pyngp.LossType.L2 and hasattr(pyngp.LossType, "RelativeL2")
     import torch

@@ -385,6 +385,7 @@ def test_pyngp_and_cli_train_a_png_dataset(native, dataset, scene_mod, tmp_path)
     testbed.shall_train = True
     first = None
     while testbed.frame():
+        assert not testbed.want_repl()  # run.py:185
         if first is None:
             first = testbed.loss
         if testbed.training_step >= 300:
