@@ -868,6 +868,8 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			v.path = frame.at("file_path").str();
 			std::replace(v.path.begin(), v.path.end(), '\\', '/');
 			v.abs_path = resolve(v.path);
+			v.white_transparent = json.value("white_transparent", false);
+			v.black_transparent = json.value("black_transparent", false);
 			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
 			v.resolution[1] = (int)(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
 			if ((v.resolution[0] <= 0 || v.resolution[1] <= 0) && !probe_image_size(v.abs_path, v.resolution[0], v.resolution[1]))

@@ -81,6 +81,7 @@ struct TrainingView {
 	float lens_params[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	std::string path;
 	std::string abs_path; // the image file the loader resolved (extension probing, nerf_loader.cu), may not exist
+	bool white_transparent = false, black_transparent = false; // transforms.json flags (NSVF-style data), src/nerf_loader.cu:462-468
 	void* d_pixels = nullptr; // training image on the device (ngp_set_training_image), RGBA
 	int32_t image_type = 0;   // ngp_image_type
 };

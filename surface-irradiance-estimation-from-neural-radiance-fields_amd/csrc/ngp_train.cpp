@@ -600,6 +600,31 @@ int ngp_load_training_images(ngp_ctx* ctx, int32_t* n_loaded_out) {
 				std::vector<uint8_t> rgba;
 				int w = 0, h = 0;
 				if (decode_image(read_file(v.abs_path), rgba, w, h, why)) {
+					// convert_rgba32 (src/nerf_loader.cu:41-63): "white = transparent" / "black = transparent" datasets, and the
+					// dynamic mask beside the image (:596-615): masked pixels become the hot-pink sentinel no ray is drawn from
+					if (v.white_transparent || v.black_transparent) {
+						for (size_t k = 0; k < rgba.size(); k += 4) {
+							if (v.white_transparent && rgba[k] == 255 && rgba[k + 1] == 255 && rgba[k + 2] == 255) rgba[k + 3] = 0;
+							if (v.black_transparent && rgba[k] == 0 && rgba[k + 1] == 0 && rgba[k + 2] == 0) rgba[k + 3] = 0;
+						}
+					}
+					{
+						const size_t slash = v.abs_path.find_last_of('/');
+						const std::string dir = slash == std::string::npos ? std::string(".") : v.abs_path.substr(0, slash);
+						std::string stem = slash == std::string::npos ? v.abs_path : v.abs_path.substr(slash + 1);
+						const size_t dot = stem.find_last_of('.');
+						if (dot != std::string::npos) stem = stem.substr(0, dot);
+						const std::string mask_path = dir + "/dynamic_mask_" + stem + ".png";
+						if (file_exists(mask_path)) {
+							std::vector<uint8_t> mask;
+							int mw = 0, mh = 0;
+							std::string mwhy;
+							if (!decode_image(read_file(mask_path), mask, mw, mh, mwhy)) throw std::runtime_error("Dynamic mask " + mask_path + " could not be loaded.");
+							if (mw != w || mh != h) throw std::runtime_error("Dynamic mask " + mask_path + " has wrong resolution.");
+							for (size_t k = 0; k < rgba.size(); k += 4)
+								if (mask[k] != 0 || mask[k + 1] != 0 || mask[k + 2] != 0) { rgba[k] = 0xFF; rgba[k + 1] = 0x00; rgba[k + 2] = 0xFF; rgba[k + 3] = 0x00; }
+						}
+					}
 					if (ngp_set_training_image(ctx, (int)i, w, h, rgba.data(), NGP_IMAGE_BYTE) != 0) throw std::runtime_error(ctx->error);
 					++n_loaded;
 					continue;

@@ -455,3 +455,55 @@ def test_render_ground_truth_is_the_training_image(native, dataset):
     got4 = ctx.render_ground_truth(3, W, H, background=(0, 0, 0, 1), color_space=0)
     assert _psnr(got4[..., :3], img[..., :3]) > 38.0  # 8-bit quantisation of the colours and of alpha
     ctx.close()
+
+
+def test_transparency_flags_and_dynamic_masks(native, dataset, scene_mod, scene_unit, tmp_path):
+    """convert_rgba32 (src/nerf_loader.cu:41-63) and the dynamic mask beside an image (:596-615)."""
+    import json
+
+    os.makedirs(tmp_path / "train")
+    px = np.zeros((H, W, 4), np.uint8)
+    px[..., 3] = 255
+    px[: H // 2] = [255, 255, 255, 255]   # white half
+    px[H // 2:, : W // 2] = [0, 0, 0, 255]  # black quarter
+    px[H // 2:, W // 2:] = [200, 40, 90, 255]
+    for i in range(len(POSES)):
+        _write_png(str(tmp_path / "train" / f"r_{i:04d}.png"), px, filter_type=0)
+    path = scene_mod.write_transforms(str(tmp_path / "transforms.json"), dataset["mats"], W, H, FOV)
+    j = json.load(open(path))
+    j["white_transparent"] = True
+    json.dump(j, open(path, "w"))
+    ctx = native.Context(0)
+    ctx.load_training_data(path)
+    assert ctx.load_training_images() == len(POSES)
+    gt = ctx.render_ground_truth(0, W, H, background=(0.0, 0.0, 0.0, 0.0), color_space=0)
+    assert (gt[: H // 2, :, 3] == 0).all() and (gt[H // 2:, :, 3] == 1).all()  # white became transparent, black stayed
+    j["white_transparent"], j["black_transparent"] = False, True
+    json.dump(j, open(path, "w"))
+    ctx.load_training_data(path)
+    ctx.load_training_images()
+    gt = ctx.render_ground_truth(0, W, H, background=(0.0, 0.0, 0.0, 0.0), color_space=0)
+    assert (gt[: H // 2, :, 3] == 1).all() and (gt[H // 2:, : W // 2, 3] == 0).all() and (gt[H // 2:, W // 2:, 3] == 1).all()
+    # a mask that covers every image entirely: no ray can be drawn
+    mask = np.full((H, W, 4), 255, np.uint8)
+    for i in range(len(POSES)):
+        _write_png(str(tmp_path / "train" / f"dynamic_mask_r_{i:04d}.png"), mask, filter_type=0)
+    ctx.load_training_data(path)
+    ctx.load_training_images()
+    ctx.set_model(scene_unit)
+    b = ctx.train_prepare_batch(1 << 15)
+    assert b["counters"][1] == 0 and b["counters"][0] == 0
+    # half-masked: rays only from the unmasked half
+    mask[:, W // 2:] = 0
+    for i in range(len(POSES)):
+        _write_png(str(tmp_path / "train" / f"dynamic_mask_r_{i:04d}.png"), mask, filter_type=0)
+    ctx.load_training_data(path)
+    ctx.load_training_images()
+    ctx.set_model(scene_unit)
+    b = ctx.train_prepare_batch(1 << 15)
+    assert 0 < b["counters"][1] < 4096
+    _write_png(str(tmp_path / "train" / "dynamic_mask_r_0000.png"), mask[:10], filter_type=0)
+    ctx.load_training_data(path)
+    with pytest.raises(RuntimeError, match="wrong resolution"):
+        ctx.load_training_images()
+    ctx.close()
