@@ -140,7 +140,9 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error("this build is headless: render() / frame() work without a window"); },
 			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
 		.def("init_vr", [](Testbed&) { throw std::runtime_error("this build is headless: no VR"); })
-		.def("load_camera_path", [](Testbed&, const std::string&) { throw std::runtime_error("camera-path rendering (load_camera_path, start_t / end_t) is not supported by the MI355X renderer"); }, py::arg("path"))
+		.def("load_camera_path", &Testbed::load_camera_path, py::arg("path"), "Load a camera path")
+		.def("set_camera_from_time", &Testbed::set_camera_from_time, py::arg("t"), "place the camera on the loaded path, t in [0, 1]")
+		.def_readwrite("camera_smoothing", &Testbed::m_camera_smoothing)
 		.def("compute_and_save_marching_cubes_mesh", [](Testbed&, py::args, py::kwargs) { throw std::runtime_error("marching cubes is outside the MI355X renderer's scope (SURVEY section 2)"); })
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>(), "Process a single frame: one training step when shall_train is set (headless, nothing is drawn).")
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>(), "Perform a single training step with a specified batch size.")

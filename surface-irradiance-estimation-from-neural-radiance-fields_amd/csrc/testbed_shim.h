@@ -5,6 +5,7 @@
 #pragma once
 
 #include "../../include/ngp_hip.h"
+#include "minijson.h"
 
 #include <array>
 #include <cmath>
@@ -217,6 +218,92 @@ public:
 		m_testbed_mode = ETestbedMode::Geometry;
 	}
 
+	// ---- camera path (include/neural-graphics-primitives/camera_path.h, src/camera_path.cu:30-160, src/testbed.cu:3724-3740)
+	struct CameraKeyframe {
+		std::array<float, 4> R{0.f, 0.f, 0.f, 1.f}; // quaternion x, y, z, w
+		std::array<float, 3> T{0.f, 0.f, 0.f};
+		float slice = 0.f, scale = 1.f, fov = 50.f, aperture_size = 0.f;
+		std::array<float, 12> m() const { // to_mat3(normalize(R)) and T, column-major 4x3
+			float n = std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + R[3] * R[3]);
+			const float x = R[0] / n, y = R[1] / n, z = R[2] / n, w = R[3] / n;
+			return {1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y),
+			        2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x),
+			        2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y),
+			        T[0], T[1], T[2]};
+		}
+	};
+	struct CameraPath {
+		std::vector<CameraKeyframe> keyframes;
+		bool loop = false;
+		float play_time = 0.f;
+		const CameraKeyframe& get_keyframe(int i) const {
+			const int size = (int)keyframes.size();
+			return loop ? keyframes[(size_t)((i % size + size) % size)] : keyframes[(size_t)std::min(std::max(i, 0), size - 1)];
+		}
+		// cubic B-spline over the keyframes, quaternions added on the same hemisphere and renormalised (camera_path.cu:58-76)
+		CameraKeyframe eval_camera_path(float t) const {
+			if (keyframes.empty()) return {};
+			t *= (float)(loop ? keyframes.size() : keyframes.size() - 1);
+			const int t1 = (int)std::floor(t);
+			const float u = t - std::floor(t), uu = u * u, uuu = uu * u;
+			const float w[4] = {(1.f - u) * (1.f - u) * (1.f - u) * (1.f / 6.f), (3.f * uuu - 6.f * uu + 4.f) * (1.f / 6.f), (-3.f * uuu + 3.f * uu + 3.f * u + 1.f) * (1.f / 6.f), uuu * (1.f / 6.f)};
+			CameraKeyframe acc;
+			acc.R = {0.f, 0.f, 0.f, 0.f};
+			acc.T = {0.f, 0.f, 0.f};
+			acc.slice = acc.scale = acc.fov = acc.aperture_size = 0.f;
+			for (int k = 0; k < 4; ++k) {
+				const CameraKeyframe& p = get_keyframe(t1 - 1 + k);
+				// operator+ flips the right-hand quaternion onto the running sum's hemisphere
+				const float d = k == 0 ? 1.f : acc.R[0] * p.R[0] * w[k] + acc.R[1] * p.R[1] * w[k] + acc.R[2] * p.R[2] * w[k] + acc.R[3] * p.R[3] * w[k];
+				const float sgn = d < 0.f ? -1.f : 1.f;
+				for (int c = 0; c < 4; ++c) acc.R[(size_t)c] += sgn * w[k] * p.R[(size_t)c];
+				for (int c = 0; c < 3; ++c) acc.T[(size_t)c] += w[k] * p.T[(size_t)c];
+				acc.slice += w[k] * p.slice; acc.scale += w[k] * p.scale; acc.fov += w[k] * p.fov; acc.aperture_size += w[k] * p.aperture_size;
+			}
+			const float n = std::sqrt(acc.R[0] * acc.R[0] + acc.R[1] * acc.R[1] + acc.R[2] * acc.R[2] + acc.R[3] * acc.R[3]);
+			for (float& c : acc.R) c /= n;
+			return acc;
+		}
+	} m_camera_path;
+	bool m_camera_smoothing = false;
+	// CameraPath::load (src/camera_path.cu:124-148): {"loop", "time", "path": [{"R": [x, y, z, w], "T": [..], "slice", "scale", "fov", "aperture_size" | "dof"}]}
+	// (the quaternion's serialisation lives in the un-vendored tiny-cuda-nn: storage order x, y, z, w)
+	void load_camera_path(const std::string& path) {
+		FILE* f = fopen(path.c_str(), "rb");
+		if (!f) throw std::runtime_error("Camera path " + path + " does not exist.");
+		std::string text;
+		char buf[4096];
+		size_t got;
+		while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+		fclose(f);
+		const mj::Value j = mj::parse_json(text);
+		m_camera_path.keyframes.clear();
+		m_camera_path.loop = j.contains("loop") ? j.at("loop").boolean() : false;
+		m_camera_path.play_time = j.contains("time") ? (float)j.at("time").num() : 0.f;
+		if (j.contains("path")) {
+			for (size_t i = 0; i < j.at("path").size(); ++i) {
+				const mj::Value& el = j.at("path").at(i);
+				CameraKeyframe p;
+				for (size_t c = 0; c < 4; ++c) p.R[c] = (float)el.at("R").at(c).num();
+				for (size_t c = 0; c < 3; ++c) p.T[c] = (float)el.at("T").at(c).num();
+				p.slice = (float)el.at("slice").num();
+				p.scale = (float)el.at("scale").num();
+				p.fov = (float)el.at("fov").num();
+				p.aperture_size = (float)(el.contains("dof") ? el.at("dof").num() : el.at("aperture_size").num());
+				m_camera_path.keyframes.push_back(p);
+			}
+		}
+	}
+	void set_camera_from_time(float t) { // src/testbed.cu:3724-3740
+		if (m_camera_path.keyframes.empty()) return;
+		const CameraKeyframe k = m_camera_path.eval_camera_path(t);
+		m_camera = k.m();
+		m_slice_plane_z = k.slice;
+		m_scale = k.scale;
+		set_fov(k.fov);
+		m_aperture_size = k.aperture_size;
+	}
+
 	// ---- camera (src/testbed.cu:425-427, 481-496, 541-566, 3750-3764, 4474-4481)
 	void reset_camera() {
 		m_fov_axis = 1;
@@ -263,8 +350,27 @@ public:
 
 	// ---- render: Testbed::render_to_cpu (src/python_api.cu:124-202). out: height*width*4 floats.
 	void render_to_cpu(float* out, int width, int height, int spp, bool linear, float start_time = -1.f, float end_time = -1.f, float fps = 30.f, float shutter_fraction = 1.0f, float* depth_out = nullptr) {
-		(void)fps; (void)shutter_fraction;
-		if (start_time >= 0.f || end_time >= 0.f) throw std::runtime_error("camera-path rendering (start_t/end_t) is not supported by the MI355X renderer");
+		(void)fps;
+		if (start_time >= 0.f) {
+			// Testbed::render_to_cpu along the camera path (src/python_api.cu:124-202): sample i of the frame is taken at the
+			// middle of its slice of the shutter interval. The reference also interpolates the camera per pixel inside a
+			// sample (camera0 -> camera1); here a sample has one camera, so motion blur is resolved by the spp samples only.
+			if (m_camera_smoothing) throw std::runtime_error("camera_smoothing is not supported by the MI355X renderer");
+			if (end_time < 0.f) end_time = start_time;
+			std::vector<float> acc((size_t)width * height * 4, 0.f), one((size_t)width * height * 4);
+			for (int i = 0; i < spp; ++i) {
+				const float start_alpha = (float)i / (float)spp * shutter_fraction, end_alpha = ((float)i + 1.0f) / (float)spp * shutter_fraction;
+				set_camera_from_time(start_time + (end_time - start_time) * (start_alpha + end_alpha) / 2.0f);
+				render_to_cpu(one.data(), width, height, 1, true, -1.f, -1.f, fps, shutter_fraction, nullptr);
+				for (size_t k = 0; k < acc.size(); ++k) acc[k] += one[k];
+			}
+			for (size_t k = 0; k < acc.size(); ++k) {
+				float v = acc[k] / (float)spp;
+				if (!linear && (k & 3) != 3) v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 0.41666f) - 0.055f; // linear_to_srgb, common_device.cuh:58-64
+				out[k] = v;
+			}
+			return;
+		}
 		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth;
 		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, AO, Positions, Depth (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
 		ngp_camera cam{};

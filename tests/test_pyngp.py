@@ -190,3 +190,66 @@ def test_headless_command_line(tmp_path, gpu_ctx, native, scene_mod, scene_unit)
     r = subprocess.run([exe, "--frobnicate"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "unknown flag" in r.stderr
     assert subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60).stdout.startswith("ngp_hip")
+
+
+@pytest.mark.gpu
+def test_camera_path_rendering(tmp_path, pyngp, gpu_ctx, scene_mod, scene_unit):
+    """load_camera_path + render(..., start_t, end_t, fps, shutter_fraction) of scripts/run.py:304-337: the camera follows
+    the cubic B-spline of the keyframes (camera_path.h:110-119, camera_path.cu:58-76)."""
+    gpu_ctx.set_model(scene_unit)
+    snap = str(tmp_path / "m.ingp")
+    gpu_ctx.save_snapshot_file(snap)
+
+    from scipy.spatial.transform import Rotation
+
+    keys = []
+    for az in (20.0, 60.0, 100.0, 140.0, 180.0):
+        m = scene_mod.orbit_camera(az, 25.0).astype(np.float64)
+        rot = m[:, :3] if np.linalg.det(m[:, :3]) > 0 else m[:, :3] * np.array([1.0, 1.0, -1.0])  # a proper rotation for the quaternion
+        q = Rotation.from_matrix(rot).as_quat()  # x, y, z, w
+        keys.append({"R": [float(c) for c in q], "T": [float(c) for c in m[:, 3]], "slice": 0.0, "scale": 1.5, "fov": 40.0 + az / 10, "aperture_size": 0.0,
+                     "glow_mode": 0, "glow_y_cutoff": 0.0})
+    (tmp_path / "cam.json").write_text(json.dumps({"loop": False, "time": 0.0, "path": keys}))
+    testbed = pyngp.Testbed()
+    testbed.load_snapshot(snap)
+    testbed.load_camera_path(str(tmp_path / "cam.json"))
+
+    def spline(t):
+        t *= len(keys) - 1
+        t1, u = int(np.floor(t)), t - np.floor(t)
+        w = [(1 - u) ** 3 / 6, (3 * u ** 3 - 6 * u ** 2 + 4) / 6, (-3 * u ** 3 + 3 * u ** 2 + 3 * u + 1) / 6, u ** 3 / 6]
+        ks = [keys[min(max(t1 - 1 + k, 0), len(keys) - 1)] for k in range(4)]
+        q = w[0] * np.array(ks[0]["R"])
+        for wk, k in zip(w[1:], ks[1:]):  # CameraKeyframe::operator+: the right-hand quaternion joins the running sum's hemisphere
+            r = wk * np.array(k["R"])
+            q = q + (-r if np.dot(q, r) < 0 else r)
+        q /= np.linalg.norm(q)
+        T = sum(wk * np.array(k["T"]) for wk, k in zip(w, ks))
+        fov = sum(wk * k["fov"] for wk, k in zip(w, ks))
+        x, y, z, ww = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - ww * z), 2 * (x * z + ww * y)],
+                      [2 * (x * y + ww * z), 1 - 2 * (x * x + z * z), 2 * (y * z - ww * x)],
+                      [2 * (x * z - ww * y), 2 * (y * z + ww * x), 1 - 2 * (x * x + y * y)]])
+        return np.concatenate([R, T[:, None]], 1), fov
+
+    for t in (0.0, 0.13, 0.5, 0.77, 1.0):
+        testbed.set_camera_from_time(t)
+        m, fov = spline(t)
+        assert np.allclose(testbed.camera_matrix, m, atol=2e-5) and abs(testbed.fov - fov) < 1e-3
+    # end points of a B-spline with clamped neighbours: the first key frame weighs 5/6 at t = 0
+    testbed.background_color = [0.0, 0.0, 0.0, 1.0]
+    a = testbed.render(64, 36, 2, True, 0.25, 0.30, 30.0, 0.5)
+    testbed.set_camera_from_time(0.25 + 0.05 * 0.125)
+    s0 = testbed.render(64, 36, 1, True)
+    testbed.set_camera_from_time(0.25 + 0.05 * 0.375)
+    s1 = testbed.render(64, 36, 1, True)
+    assert np.isfinite(a).all() and np.abs(a - 0.5 * (s0 + s1)).max() < 1e-5
+    srgb = testbed.render(64, 36, 2, False, 0.25, 0.30, 30.0, 0.5)
+    lin = np.clip(a[..., :3], 0, None)
+    want = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** 0.41666 - 0.055)
+    assert np.abs(srgb[..., :3] - want).max() < 1e-5 and np.abs(srgb[..., 3] - a[..., 3]).max() < 1e-6
+    testbed.camera_smoothing = True
+    with pytest.raises(RuntimeError, match="camera_smoothing"):
+        testbed.render(8, 8, 1, True, 0.0, 0.1)
+    with pytest.raises(RuntimeError, match="does not exist"):
+        testbed.load_camera_path(str(tmp_path / "nope.json"))
