@@ -1,6 +1,7 @@
-// pybind11 module `pyngp`: the subset of the reference's src/python_api.cu that the inference path of scripts/run.py
-// uses (Testbed, TestbedMode, RenderMode; load_*, render, camera and render-state properties), bound to the
-// C-ABI-backed ngp::Testbed shim. Same names and defaults as python_api.cu:263-733.
+// pybind11 module `pyngp`: the subset of the reference's src/python_api.cu that scripts/run.py's training, evaluation,
+// screenshot and camera-path rendering paths use (Testbed, TestbedMode, RenderMode, LossType; load_*, train / frame,
+// render, camera and render-state properties), bound to the C-ABI-backed ngp::Testbed shim. Same names and defaults
+// as python_api.cu:263-733.
 #include "testbed_shim.h"
 
 #include <pybind11/numpy.h>
@@ -27,7 +28,7 @@ static py::array_t<float> from_colmajor(const std::array<float, 12>& m) {
 }
 
 PYBIND11_MODULE(pyngp, m) {
-	m.doc() = "MI355X-native NeRF renderer behind the instant-ngp Testbed API (inference path)";
+	m.doc() = "MI355X-native NeRF renderer and trainer behind the instant-ngp Testbed API";
 	py::enum_<ETestbedMode>(m, "TestbedMode")
 		.value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
 		.value("Volume", ETestbedMode::Volume).value("Geometry", ETestbedMode::Geometry).value("None", ETestbedMode::None)
