@@ -37,7 +37,10 @@ enum ngp_render_mode {
 	 * and shade_kernel_nerf skips the sRGB -> linear conversion (:1393). NeRF mode only. */
 	NGP_RENDER_AO = 2,        /* rgb = alpha of the sample */
 	NGP_RENDER_POSITIONS = 3, /* rgb = (pos - 0.5) / 2 + 0.5 */
-	NGP_RENDER_DEPTH = 4      /* rgb = dot(cam_fwd, pos - ray origin) * depth_scale */
+	NGP_RENDER_DEPTH = 4,     /* rgb = dot(cam_fwd, pos - ray origin) * depth_scale */
+	NGP_RENDER_COST = 5       /* ERenderMode::Cost (shade_kernel_nerf :1382-1384): grey = samples composited on the ray / 128, opaque. The reference's
+	                           * payload.n_steps holds that count for rays that saturate and the last compaction batch's for rays that leave the
+	                           * volume (:466, :730); here it is the ray's total in both cases */
 };
 
 /* ETestbedMode subset (common.h:35-43): Nerf, and the fork's Geometry mode (meshes + NeRF, depth composited) */

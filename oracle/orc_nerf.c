@@ -750,9 +750,13 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 
 /* K7: shade_kernel_nerf (testbed_nerf.cu:1361-1401), render mode Shade; with o->depth_test the
  * geometry variant (testbed_geometry_training.cu:1826-1871). */
-static void shade_one(const orc_render_opts* o, const float* rgba, float depth, uint32_t idx, float* frame_buffer, float* depth_buffer) {
+static void shade_one(const orc_render_opts* o, const float* rgba, float depth, uint32_t idx, uint32_t n_steps, float* frame_buffer, float* depth_buffer) {
 	if (o->depth_test && depth > depth_buffer[idx]) return;
 	float tmp[4] = {rgba[0], rgba[1], rgba[2], rgba[3]};
+	if (o->render_mode == 5) { /* ERenderMode::Cost, :1382-1384 (n_steps: the ray's total, see include/ngp_hip.h NGP_RENDER_COST) */
+		tmp[0] = tmp[1] = tmp[2] = (float)n_steps / 128.0f;
+		tmp[3] = 1.0f;
+	}
 	if (!o->train_in_linear_colors && o->render_mode <= 1) { /* only ERenderMode::Shade converts, :1393 */
 		tmp[0] = orc_srgb_to_linear(tmp[0]);
 		tmp[1] = orc_srgb_to_linear(tmp[1]);
@@ -787,7 +791,7 @@ void orc_render_nerf(const orc_nerf_model* m, const orc_camera* cam, const orc_r
 		 * still alive when the march loop ends never do. */
 		if (!payload.alive && rgba[3] > 0.001f) {
 			++n_hit;
-			shade_one(o, rgba, depth, payload.idx, frame_buffer, depth_buffer);
+			shade_one(o, rgba, depth, payload.idx, payload.n_steps, frame_buffer, depth_buffer);
 		}
 	}
 	if (stats) {

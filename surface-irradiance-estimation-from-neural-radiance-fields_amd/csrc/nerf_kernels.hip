@@ -64,10 +64,14 @@ NGP_DEV float4 tonemap_pixel(const FrameParams& F, f3 bg_linear, float r, float 
 }
 
 template <bool PROBE>
-NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc) {
+NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc, uint32_t n_steps) {
 	if (!(acc.a > 0.001f)) return false;
 	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
+	if (!PROBE && F.render_mode == 5) { // ERenderMode::Cost: the ray's sample count as a grey level, opaque (:1382-1384)
+		r = g = b = (float)n_steps / 128.0f;
+		a = 1.0f;
+	}
 	if (!F.linear_colors && (PROBE || F.render_mode <= 1)) { // only ERenderMode::Shade accumulates in linear colours (:1393)
 		r = srgb_to_linear(r);
 		g = srgb_to_linear(g);
@@ -241,7 +245,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
 			bool hit = false;
 			if (finished) {
-				hit = shade_ray<PROBE>(F, P, bg_linear, ray.out, acc);
+				hit = shade_ray<PROBE>(F, P, bg_linear, ray.out, acc, step - 1u); // step counts from 1 like the reference's march loop
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));

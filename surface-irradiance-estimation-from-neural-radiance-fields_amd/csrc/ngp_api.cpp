@@ -946,8 +946,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	ngp::sync_inference_model(ctx);
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
-	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_DEPTH) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, AO, Positions, Depth");
-	if (opts.render_mode > NGP_RENDER_SHADE_ENVMAP && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth) apply to NeRF mode");
+	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_COST) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, AO, Positions, Depth, Cost");
+	if (opts.render_mode > NGP_RENDER_SHADE_ENVMAP && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth, Cost) apply to NeRF mode");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);

@@ -371,8 +371,8 @@ public:
 			}
 			return;
 		}
-		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth;
-		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, AO, Positions, Depth (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
+		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth || m_render_mode == ERenderMode::Cost;
+		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, AO, Positions, Depth, Cost (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
 		ngp_camera cam{};
 		memcpy(cam.matrix, m_camera.data(), sizeof(cam.matrix));
 		cam.width = width;
@@ -393,7 +393,7 @@ public:
 		}
 		ngp_render_opts o{};
 		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
-		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : NGP_RENDER_SHADE;
+		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : m_render_mode == ERenderMode::Cost ? NGP_RENDER_COST : NGP_RENDER_SHADE;
 		o.min_transmittance = nerf.render_min_transmittance;
 		memcpy(o.background, m_background_color.data(), sizeof(o.background));
 		o.exposure = m_exposure;

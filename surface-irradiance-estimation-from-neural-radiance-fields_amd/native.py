@@ -78,7 +78,7 @@ class ProbeDesc(C.Structure):
 
 
 MODE_NERF, MODE_GEOMETRY = 0, 1
-RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH = 0, 1, 2, 3, 4
+RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH, RENDER_COST = 0, 1, 2, 3, 4, 5
 PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
