@@ -743,6 +743,9 @@ NGP_DEV half_t density_pass(const uint4* s_w, int lane, half8 enc) {
 	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
 	return (half_t)dens[0];
 }
+// RGB_MID: the number of 64x64 layers of the rgb head = its n_hidden_layers - 1 (configs/nerf/base.json: 1;
+// base_1layer.json 0, base_3layer.json 2). Their fragments follow FRAG_R1 eight at a time, the output layer's come last.
+template <int RGB_MID = 1>
 NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 	// density head: 32 -> 64 (ReLU) -> 16
@@ -762,24 +765,29 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	}
 	MlpOut out;
 	out.sigma = rin[0];
-	// rgb head: 32 -> 64 (ReLU) -> 64 (ReLU) -> 16
+	// rgb head: 32 -> 64 (ReLU) [-> 64 (ReLU)] x RGB_MID -> 16
 	d0 = mfma16(ld_frag(s_w, FRAG_R0 + 0, lane), rin, zero);
 	d1 = mfma16(ld_frag(s_w, FRAG_R0 + 1, lane), rin, zero);
 	d2 = mfma16(ld_frag(s_w, FRAG_R0 + 2, lane), rin, zero);
 	d3 = mfma16(ld_frag(s_w, FRAG_R0 + 3, lane), rin, zero);
 	b0 = relu_pack(d0, d1);
 	b1 = relu_pack(d2, d3);
-	d0 = mfma16(ld_frag(s_w, FRAG_R1 + 0, lane), b0, zero);
-	d0 = mfma16(ld_frag(s_w, FRAG_R1 + 1, lane), b1, d0);
-	d1 = mfma16(ld_frag(s_w, FRAG_R1 + 2, lane), b0, zero);
-	d1 = mfma16(ld_frag(s_w, FRAG_R1 + 3, lane), b1, d1);
-	d2 = mfma16(ld_frag(s_w, FRAG_R1 + 4, lane), b0, zero);
-	d2 = mfma16(ld_frag(s_w, FRAG_R1 + 5, lane), b1, d2);
-	d3 = mfma16(ld_frag(s_w, FRAG_R1 + 6, lane), b0, zero);
-	d3 = mfma16(ld_frag(s_w, FRAG_R1 + 7, lane), b1, d3);
-	half8 c0 = relu_pack(d0, d1), c1 = relu_pack(d2, d3);
-	floatx4 rgb = mfma16(ld_frag(s_w, FRAG_R2 + 0, lane), c0, zero);
-	rgb = mfma16(ld_frag(s_w, FRAG_R2 + 1, lane), c1, rgb);
+#pragma unroll
+	for (int k = 0; k < RGB_MID; ++k) {
+		const int f = FRAG_R1 + 8 * k;
+		d0 = mfma16(ld_frag(s_w, f + 0, lane), b0, zero);
+		d0 = mfma16(ld_frag(s_w, f + 1, lane), b1, d0);
+		d1 = mfma16(ld_frag(s_w, f + 2, lane), b0, zero);
+		d1 = mfma16(ld_frag(s_w, f + 3, lane), b1, d1);
+		d2 = mfma16(ld_frag(s_w, f + 4, lane), b0, zero);
+		d2 = mfma16(ld_frag(s_w, f + 5, lane), b1, d2);
+		d3 = mfma16(ld_frag(s_w, f + 6, lane), b0, zero);
+		d3 = mfma16(ld_frag(s_w, f + 7, lane), b1, d3);
+		b0 = relu_pack(d0, d1);
+		b1 = relu_pack(d2, d3);
+	}
+	floatx4 rgb = mfma16(ld_frag(s_w, FRAG_R1 + 8 * RGB_MID + 0, lane), b0, zero);
+	rgb = mfma16(ld_frag(s_w, FRAG_R1 + 8 * RGB_MID + 1, lane), b1, rgb);
 	out.rgb[0] = (half_t)rgb[0];
 	out.rgb[1] = (half_t)rgb[1];
 	out.rgb[2] = (half_t)rgb[2];

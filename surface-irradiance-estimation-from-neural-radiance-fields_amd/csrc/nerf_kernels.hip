@@ -166,16 +166,16 @@ NGP_DEV unsigned long long stamp() {
 // src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
 // exponential-stepping branches; the arithmetic that remains is the same expression for expression.
 // OUTSIDE: the render box may reach beyond the occupancy grid (geometry mode, a hand-set render box)
-template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true>
+template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
-	__shared__ uint4 s_w[N_FRAGS * 64];
+	__shared__ uint4 s_w[n_frags_for(RGB_MID) * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
 	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade in use: empty-space summary of the occupancy grid (the host picks an instantiation with MIPS > max_cascade)
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
 	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
-	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
 	if (threadIdx.x < NERF_CASCADES * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
@@ -491,8 +491,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			encode_issue(M.grid, M.xgrid, s_lv, hq, bx, by, bz, eb);
 			half8 enca = encode_finish(ea);
 			half8 encb = encode_finish(eb);
-			MlpOut moa = mlp_pass(s_w, lane, enca, sha);
-			MlpOut mob = mlp_pass(s_w, lane, encb, shb);
+			MlpOut moa = mlp_pass<RGB_MID>(s_w, lane, enca, sha);
+			MlpOut mob = mlp_pass<RGB_MID>(s_w, lane, encb, shb);
 			deliver(p, moa);
 			deliver(p + 1, mob);
 		}
@@ -501,7 +501,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			Sh4 sha;
 			sample_of(p, ax, ay, az, sha);
 			half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, hq, ax, ay, az);
-			MlpOut mo = mlp_pass(s_w, lane, enc, sha);
+			MlpOut mo = mlp_pass<RGB_MID>(s_w, lane, enc, sha);
 			deliver(p, mo);
 		}
 
@@ -624,6 +624,15 @@ __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5(const ModelPara
 	ProbeParams P{};
 	fused_body<false, false, false, 5, false>(M, C, F, P);
 }
+// rgb heads with 1 or 3 hidden layers (configs/nerf/base_1layer.json, base_3layer.json): the general kernel with no / two 64x64 layers
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_mid0(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, (int)NERF_CASCADES, true, 0>(M, C, F, P);
+}
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_mid2(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, (int)NERF_CASCADES, true, 2>(M, C, F, P);
+}
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
@@ -709,10 +718,11 @@ __global__ __launch_bounds__(BLOCK) void grid_encode_kernel(const ModelParams M,
 	}
 }
 
+template <int RGB_MID>
 __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
-	__shared__ uint4 s_w[N_FRAGS * 64];
+	__shared__ uint4 s_w[n_frags_for(RGB_MID) * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
-	for (int i = threadIdx.x; i < N_FRAGS * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	__syncthreads();
 	const int lane = threadIdx.x & 63, c = lane & 15;
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
 		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
-		MlpOut mo = mlp_pass(s_w, lane, enc, sh4_from_dir(lane >> 4, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]));
+		MlpOut mo = mlp_pass<RGB_MID>(s_w, lane, enc, sh4_from_dir(lane >> 4, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]));
 		if (s < n && lane < 16) {
 			union { half_t h; uint16_t u; } cv;
 			cv.h = mo.rgb[0]; out[(size_t)s * 4 + 0] = cv.u;
@@ -946,6 +956,15 @@ static int resident_blocks_per_cu(K kernel) {
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
 	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
 	const bool c5 = !unit && M.max_cascade < 5 && !F.outside_possible;
+	if (M.rgb_mid != 1) { // the base_1layer / base_3layer heads: one general kernel each
+		static const int per_cu_mid0 = resident_blocks_per_cu(render_nerf_fused_mid0), per_cu_mid2 = resident_blocks_per_cu(render_nerf_fused_mid2);
+		int nb = n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2);
+		const int need = (int)((F.n_local_tiles + 3) / 4);
+		if (nb > need) nb = need > 0 ? need : 1;
+		if (M.rgb_mid == 0) hipLaunchKernelGGL(render_nerf_fused_mid0, dim3(nb), dim3(BLOCK), 0, stream, M, C, F);
+		else hipLaunchKernelGGL(render_nerf_fused_mid2, dim3(nb), dim3(BLOCK), 0, stream, M, C, F);
+		return;
+	}
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
 	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5);
 	int per_cu = F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic;
@@ -981,7 +1000,9 @@ void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, ui
 }
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream) {
 	uint32_t n_waves = (n + 63) / 64;
-	hipLaunchKernelGGL(network_inference_kernel, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	if (M.rgb_mid == 0) hipLaunchKernelGGL(network_inference_kernel<0>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	else if (M.rgb_mid == 2) hipLaunchKernelGGL(network_inference_kernel<2>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	else hipLaunchKernelGGL(network_inference_kernel<1>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 }
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
                                 float* grid_tmp, hipStream_t stream) {

@@ -268,9 +268,9 @@ void free_model(ngp_ctx* ctx) {
 
 void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density != 1 ||
-	    d.n_hidden_rgb != 2 || d.density_out_dims != 16) {
+	    d.n_hidden_rgb < 1 || d.n_hidden_rgb > 1 + (uint32_t)MAX_RGB_MID || d.density_out_dims != 16) {
 		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json "
-		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64x2 hidden)");
+		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64 wide with 1 to 3 hidden layers)");
 	}
 	if ((d.log2_hashmap_size > 28 && d.log2_hashmap_size != 31) || d.base_resolution == 0 || !(d.per_level_scale > 0.f)) throw std::runtime_error("invalid hash grid configuration");
 	if (d.aabb_scale == 0 || (d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error("NeRF dataset's `aabb_scale` must be a power of two"); // testbed_nerf.cu:2707
@@ -321,14 +321,16 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		NGP_HIP_CHECK(hipMemcpy(ctx->d_xgrid, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
 	// weight fragments
-	std::vector<uint16_t> frags((size_t)N_FRAGS * 64 * 8);
+	std::vector<uint16_t> frags((size_t)N_FRAGS_MAX * 64 * 8, 0);
 	const uint16_t* W = ctx->params.data();
 	emit_fragments(frags, FRAG_D0, W, 64, 32);
 	emit_fragments(frags, FRAG_D1, W + 64 * 32, 16, 64);
 	const uint16_t* R = W + nd;
+	const int rgb_mid = (int)d.n_hidden_rgb - 1; // 64x64 layers between the first and the output layer of the rgb head
 	emit_fragments(frags, FRAG_R0, R, 64, 32);
-	emit_fragments(frags, FRAG_R1, R + 64 * 32, 64, 64);
-	emit_fragments(frags, FRAG_R2, R + 64 * 32 + 64 * 64, 16, 64);
+	for (int k = 0; k < rgb_mid; ++k) emit_fragments(frags, FRAG_R1 + 8 * k, R + 64 * 32 + (size_t)k * 64 * 64, 64, 64);
+	emit_fragments(frags, FRAG_R1 + 8 * rgb_mid, R + 64 * 32 + (size_t)rgb_mid * 64 * 64, 16, 64);
+	M.rgb_mid = (uint32_t)rgb_mid;
 	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 	// occupancy: fp16 grid -> fp32 -> bitfield + mips on the device (K8/K9)

@@ -20,6 +20,10 @@ constexpr int N_FEATURES = 4;
 constexpr int MLP_WIDTH = 64;
 // MFMA A-operand fragments (weights): density L1 (4), density out (2), rgb L1 (4), rgb L2 (8), rgb out (2)
 constexpr int FRAG_D0 = 0, FRAG_D1 = 4, FRAG_R0 = 6, FRAG_R1 = 10, FRAG_R2 = 18, N_FRAGS = 20;
+// other rgb heads (n_hidden_layers 1 or 3, configs/nerf/base_1layer.json / base_3layer.json): 0 or 2 layers of 64x64 at
+// FRAG_R1, the output layer behind them; the fragment buffer always holds N_FRAGS_MAX
+constexpr int MAX_RGB_MID = 2, N_FRAGS_MAX = FRAG_R1 + 8 * MAX_RGB_MID + 2;
+constexpr int n_frags_for(int rgb_mid) { return FRAG_R1 + 8 * rgb_mid + 2; }
 
 struct LevelInfo {
 	float scale;
@@ -62,6 +66,7 @@ struct ModelParams {
 	uint32_t max_cascade;
 	float cone_angle;
 	uint32_t rgb_act, density_act;
+	uint32_t rgb_mid;      // 64x64 layers of the rgb head (n_hidden_layers - 1): 1 for configs/nerf/base.json
 	uint32_t r2l_identity; // render_aabb_to_local is the identity (the usual case): skip the matrix product
 	uint32_t diag_pow2;    // every component of aabb_diag is a power of two: x / diag == x * (1/diag) bit for bit
 	float aabb_inv_diag[3];

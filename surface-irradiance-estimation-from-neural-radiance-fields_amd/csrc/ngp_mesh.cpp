@@ -400,6 +400,7 @@ int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 		NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
+		if (ctx->M.rgb_mid != 1) throw std::runtime_error("irradiance probes are built for the configs/nerf/base.json rgb head (2 hidden layers)");
 		launch_trace_probe(ctx->M, F, P, ctx->n_cus, stream);
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 		launch_probe_reduce(P, ctx->d_envmap, stream);

@@ -281,8 +281,11 @@ def test_model_validation(native):
         with pytest.raises(RuntimeError, match=msg):
             ctx.set_model(bad)
     bad = dict(sc)
-    bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=3)
+    bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=4)
     with pytest.raises(RuntimeError, match="unsupported network architecture"):
+        ctx.set_model(bad)
+    bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=3)  # base_3layer.json: accepted, but the parameter count must follow
+    with pytest.raises(RuntimeError, match="parameter count mismatch"):
         ctx.set_model(bad)
     ctx.close()
 

@@ -134,6 +134,37 @@ def test_dense_grid_encoding(gpu_ctx, oracle, native, scene_mod):
     assert_image_close(img, ref, 50.0)
 
 
+@pytest.mark.parametrize("n_hidden", [1, 3])
+def test_rgb_heads_with_one_and_three_hidden_layers(n_hidden, gpu_ctx, oracle, native, scene_mod):
+    """configs/nerf/base_1layer.json / base_3layer.json: rgb_network.n_hidden_layers 1 and 3 (2 in base.json)."""
+    from conftest import _with_bitfield
+
+    cfg = scene_mod.base_network_config()
+    cfg["rgb_network"] = dict(cfg["rgb_network"], n_hidden_layers=n_hidden)
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=31 + n_hidden, log2_hashmap_size=15, cfg=cfg))
+    gpu_ctx.set_model(sc)
+    assert gpu_ctx.get_model().n_hidden_rgb == n_hidden
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(3)
+    pos = rng.uniform(0, 1, (4096 + 5, 3)).astype(np.float32)
+    d = rng.normal(size=(pos.shape[0], 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dir01 = ((d + 1) * 0.5).astype(np.float32)
+    got = gpu_ctx.network(pos, dir01).astype(np.float32)
+    ref = oracle.network(m, pos, dir01).astype(np.float32)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)
+    err = np.abs(got - ref)
+    assert err.max() <= 8e-2 and (err <= 4 * ulp).mean() > 0.8 and np.median(err / ulp) <= 2.0  # one more layer of fp16 roundings than base.json at 3
+    oracle.release(m)
+    img, depth, st, refimg, db, ost = _render_both(gpu_ctx, oracle, native, scene_mod, sc, 160, 90, 70.0)
+    assert st["n_rays_hit"] > 1000 and abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 3
+    assert_image_close(img, refimg, 50.0)
+    with pytest.raises(RuntimeError, match="irradiance probes are built for"):
+        gpu_ctx.compute_envmap(n_theta=8, n_phi=4)
+    with pytest.raises(RuntimeError, match="training is built for"):
+        gpu_ctx.train(1, 1 << 14)
+
+
 def test_grid_encode_ragged_sizes(gpu_ctx, oracle, scene_unit):
     gpu_ctx.set_model(scene_unit)
     m = oracle.make_model(scene_unit)
