@@ -74,7 +74,8 @@ std::string read_text(const std::string& path) {
 void usage() {
 	std::cout << "ngp_hip_main [files...] [--scene PATH] [--snapshot|--load_snapshot PATH] [--width W] [--height H] [--spp N]\n"
 	             "             [--screenshot OUT.png] [--screenshot_transforms T.json --screenshot_dir DIR] [--render_mode Shade|ShadeEnvMap|AO|Positions|Depth]\n"
-	             "             [--exposure E] [--n_steps N] [--save_snapshot OUT.ingp] [--network CONFIG.json] [--no-gui] [--no-train] [--version]\n";
+	             "             [--exposure E] [--n_steps N] [--save_snapshot OUT.ingp] [--network CONFIG.json] [--no-gui] [--no-train] [--version]\n"
+	             "             [--video_camera_path PATH.json --video_output DIR/%04d.png [--video_n_seconds S] [--video_fps F] [--video_spp N]]\n";
 }
 
 } // namespace
@@ -82,8 +83,8 @@ void usage() {
 int main(int argc, char** argv) {
 	try {
 		std::vector<std::string> files;
-		std::string scene, snapshot, screenshot, shot_transforms, shot_dir, render_mode = "Shade", save_snapshot, network;
-		int width = 1920, height = 1080, spp = 1, n_steps = -1;
+		std::string scene, snapshot, screenshot, shot_transforms, shot_dir, render_mode = "Shade", save_snapshot, network, video_path, video_output = "video_%04d.png";
+		int width = 1920, height = 1080, spp = 1, n_steps = -1, video_seconds = 1, video_fps = 60, video_spp = 8;
 		bool no_train = false;
 		float exposure = 0.f;
 		for (int i = 1; i < argc; ++i) {
@@ -107,6 +108,11 @@ int main(int argc, char** argv) {
 			else if (a == "--n_steps") n_steps = std::atoi(val().c_str()); // scripts/run.py:66
 			else if (a == "--save_snapshot") save_snapshot = val();       // scripts/run.py:37
 			else if (a == "--network" || a == "--config" || a == "-n" || a == "-c") network = val(); // src/main.cu:96-101
+			else if (a == "--video_camera_path") video_path = val();   // scripts/run.py:46-54, 304-337 (frames only: no ffmpeg here)
+			else if (a == "--video_output") video_output = val();
+			else if (a == "--video_n_seconds") video_seconds = std::atoi(val().c_str());
+			else if (a == "--video_fps") video_fps = std::atoi(val().c_str());
+			else if (a == "--video_spp") video_spp = std::atoi(val().c_str());
 			else if (a == "--no-train") no_train = true;
 			else if (a == "--no-gui" || a == "--vr") { /* headless build */ }
 			else if (a == "--mode" || a == "-m") { (void)val(); std::cerr << "warning: " << a << " has no effect in this build\n"; }
@@ -148,6 +154,18 @@ int main(int argc, char** argv) {
 		if (testbed.m_render_mode == ngp::ERenderMode::ShadeEnvMap) testbed.computeEnvmapMultipleMain();
 		testbed.m_background_color = {0.f, 0.f, 0.f, 0.f};
 		std::vector<float> img((size_t)width * height * 4);
+		if (!video_path.empty()) { // scripts/run.py:304-337: one PNG per frame along the camera path
+			if (video_output.find('%') == std::string::npos) throw std::runtime_error("--video_output needs a printf pattern such as frames/%04d.png (frames are not encoded into a video here)");
+			testbed.load_camera_path(video_path);
+			const int n_frames = video_seconds * video_fps;
+			for (int i = 0; i < n_frames; ++i) {
+				testbed.render_to_cpu(img.data(), width, height, video_spp, true, (float)i / (float)n_frames, (float)(i + 1) / (float)n_frames, (float)video_fps, 0.5f);
+				char name[1024];
+				snprintf(name, sizeof(name), video_output.c_str(), i);
+				write_png(name, img, width, height, exposure);
+			}
+			std::cerr << "wrote " << n_frames << " frames\n";
+		}
 		if (!shot_transforms.empty()) { // scripts/run.py:276-299
 			mj::Value t = mj::parse_json(read_text(shot_transforms));
 			testbed.m_fov_axis = 0;
@@ -174,7 +192,7 @@ int main(int argc, char** argv) {
 			write_png(screenshot, img, width, height, exposure);
 			std::cerr << "wrote " << screenshot << "\n";
 		} else {
-			if (save_snapshot.empty()) std::cerr << "nothing to do: give --screenshot, --screenshot_transforms or --n_steps with --save_snapshot (this build has no window)\n";
+			if (save_snapshot.empty() && video_path.empty()) std::cerr << "nothing to do: give --screenshot, --screenshot_transforms or --n_steps with --save_snapshot (this build has no window)\n";
 		}
 		return 0;
 	} catch (const std::exception& e) {

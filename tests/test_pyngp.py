@@ -193,7 +193,7 @@ def test_headless_command_line(tmp_path, gpu_ctx, native, scene_mod, scene_unit)
 
 
 @pytest.mark.gpu
-def test_camera_path_rendering(tmp_path, pyngp, gpu_ctx, scene_mod, scene_unit):
+def test_camera_path_rendering(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene_unit):
     """load_camera_path + render(..., start_t, end_t, fps, shutter_fraction) of scripts/run.py:304-337: the camera follows
     the cubic B-spline of the keyframes (camera_path.h:110-119, camera_path.cu:58-76)."""
     gpu_ctx.set_model(scene_unit)
@@ -253,3 +253,13 @@ def test_camera_path_rendering(tmp_path, pyngp, gpu_ctx, scene_mod, scene_unit):
         testbed.render(8, 8, 1, True, 0.0, 0.1)
     with pytest.raises(RuntimeError, match="does not exist"):
         testbed.load_camera_path(str(tmp_path / "nope.json"))
+    # the command line writes the frames of scripts/run.py's video loop as PNG files
+    import subprocess
+
+    exe = pkg("build").build_main()
+    os.makedirs(tmp_path / "frames")
+    out = subprocess.run([exe, "--snapshot", snap, "--video_camera_path", str(tmp_path / "cam.json"), "--video_output", str(tmp_path / "frames" / "%03d.png"),
+                          "--video_n_seconds", "1", "--video_fps", "3", "--video_spp", "2", "--width", "48", "--height", "27"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert sorted(os.listdir(tmp_path / "frames")) == ["000.png", "001.png", "002.png"]
+    assert native.decode_image(open(tmp_path / "frames" / "001.png", "rb").read()).shape == (27, 48, 4)
