@@ -35,7 +35,7 @@ def pkg(sub):
     return importlib.import_module(PKG + "." + sub)
 
 
-def cpu_baseline(scene_dict, scene_mod):
+def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
     """The oracle (kind "port": the reference has no CPU path, scripts/run.py:25 hard-imports the CUDA module) on a
     bounded sample of the same workload: the same camera and model at 1280x720 (4/9 of the pixels)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -57,11 +57,24 @@ def cpu_baseline(scene_dict, scene_mod):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("NGP_BENCH_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
     t0 = time.perf_counter()
-    _, _, st = o.render_nerf(m, cam, o.make_opts(n_threads=cores))
+    fb, _, st = o.render_nerf(m, cam, o.make_opts(n_threads=cores))
     dt = time.perf_counter() - t0
     o.release(m)
-    return {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same model+camera at {w}x{h} (4/9 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+    out = {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"same model+camera at {w}x{h} (4/9 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+    if gpu_ctx is not None:
+        # the metric's "PSNR vs reference": the HIP frame of that camera against the frame the oracle just rendered (the
+        # oracle stands in for the reference, PARITY UNPINNED: oracle/orc_common.h); the oracle is the checker here, no more
+        try:
+            ref = o.tonemap(o.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+            got = gpu_ctx.render(native.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X)))
+            mse = float(np.mean((np.clip(got[..., :3], 0, 1) - np.clip(ref[..., :3], 0, 1)) ** 2))
+            out["psnr_vs_oracle_db"] = round(-10.0 * math.log10(max(mse, 1e-12)), 2)
+            out["max_abs_diff_vs_oracle"] = round(float(np.abs(got - ref).max()), 6)
+        except Exception as e:
+            out["psnr_vs_oracle_db"] = None
+            out["psnr_error"] = str(e)[:160]
+    return out
 
 
 def pmc_traffic():
@@ -273,7 +286,7 @@ def main():
         if gather_diff is not None:
             out["gathered_frame_max_abs_diff_vs_single_gpu"] = gather_diff  # rank 0's check of the assembled frame, outside the timed region
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, scene_mod)
+            out["cpu_baseline"] = cpu_baseline(sc, scene_mod, ctx, native)
         if world == 1 and not args.no_training_probe:
             out["training"] = training_probe(native, scene_mod, ctx)
         print(json.dumps(out), flush=True)
