@@ -191,6 +191,13 @@ NGP_API int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out);
  * ngp_render_device calls so that measuring does not serialise them */
 NGP_API int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out);
 
+/* Scheduling of the persistent render kernel: knobs[0..n) = refill_min [16,64], skip_steps [1,64], go_min [1,64], max_stall [0,64],
+ * chain links while tiles remain [0,3], chain links in the drain phase [0,3], block_jumps {0,1}. Performance only, except
+ * block_jumps: 1 (default) leaves empty 4^3 / 16^3 blocks of the occupancy grid in one step, 0 walks them voxel by voxel exactly
+ * as if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494) does. Out-of-range values are refused (they would
+ * hang the kernel). No counterpart in the reference; the environment variable NGP_TUNE sets the same list at ngp_create. */
+NGP_API int ngp_set_schedule(ngp_ctx* ctx, const int32_t* knobs, int n);
+
 /* --- stage entry points (what the reference launches as separate kernels; used by parity tests and tools)
  * K5a tcnn GridEncoding::inference (call site nerf_network.h:113-118): host pos01 n x 3 -> host fp16 n x (L*F) */
 NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_fp16);

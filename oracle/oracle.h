@@ -19,6 +19,7 @@ extern "C" {
 #define ORC_MAX_DEPTH 16384.0f
 #define ORC_MARCH_ITER 10000u /* src/testbed_nerf.cu:46 */
 
+enum { ORC_GRID_ACC_LEGACY = 0, ORC_GRID_ACC_FMA = 1 };
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LOGISTIC = 2, ORC_ACT_EXPONENTIAL = 3 };
 
 /* Model descriptor: what Testbed::reset_network + load_snapshot leave behind
@@ -47,6 +48,11 @@ typedef struct orc_nerf_model {
 	uint32_t max_cascade;
 	float cone_angle_constant;
 	const uint8_t* density_grid_bitfield; /* 8 levels x 128^3 bits */
+	/* How kernel_grid sums the 8 corners of a level (tiny-cuda-nn is un-vendored and un-pinned, .gitmodules:13-15; both
+	 * published sequences are restated): ORC_GRID_ACC_FMA = `result = fma((T)weight, grid_val(...), result)`, the tvec-era
+	 * kernel (the tcnn that has tcnn::vec3 / mat4x3, which the reference's sources use throughout); ORC_GRID_ACC_LEGACY =
+	 * `result[f] += (T)(weight * (float)val[f])`, the kernel before the tvec refactor. */
+	uint32_t grid_accumulate;
 	/* derived, filled by orc_nerf_prepare */
 	void* prepared;
 } orc_nerf_model;

@@ -49,6 +49,7 @@ class NerfModel(C.Structure):
         ("max_cascade", C.c_uint32),
         ("cone_angle_constant", C.c_float),
         ("density_grid_bitfield", C.c_void_p),
+        ("grid_accumulate", C.c_uint32),
         ("prepared", C.c_void_p),
     ]
 
@@ -202,6 +203,8 @@ class Oracle:
         m.max_cascade = scene["max_cascade"]
         m.cone_angle_constant = scene["cone_angle_constant"]
         m.density_grid_bitfield = bitfield.ctypes.data
+        # corner sum of the grid encoding: "fma" (tvec-era tcnn, what libngp_hip.so ships) or "legacy" (oracle.h)
+        m.grid_accumulate = {"legacy": 0, "fma": 1}[scene.get("grid_accumulate", "fma")]
         m._keep = (params, bitfield)
         rc = self.lib.orc_nerf_prepare(C.byref(m))
         if rc != 0:

@@ -143,6 +143,36 @@ static inline uint16_t orc_half_add(uint16_t a, uint16_t b) {
 	return orc_double_to_half((double)orc_half_to_float(a) + (double)orc_half_to_float(b));
 }
 
+/* fp16 fma(a, b, c) with a single rounding (__hfma / v_pk_fma_f16). The product of two halfs is exact in double
+ * (22 significant bits); the sum p + c may not be, so it is formed as an exact pair (s, e) with TwoSum and the pair
+ * is rounded: s alone decides unless it sits exactly on an fp16 rounding boundary, where the sign of e breaks the
+ * tie (RN is monotonic and every fp16 midpoint is a double, so s on one side of a midpoint means p + c is too). */
+static inline uint16_t orc_pair_to_half(double s, double e) {
+	if (e == 0.0 || s != s) return orc_double_to_half(s);
+	uint16_t sign = 0;
+	double d = s;
+	if (signbit(d)) { sign = 0x8000u; d = -d; e = -e; }
+	if (d == 65520.0) return (uint16_t)(sign | (e < 0.0 ? 0x7bffu : 0x7c00u));
+	if (d > 65520.0 || d == 0.0) return orc_double_to_half(s);
+	int ex;
+	(void)frexp(d, &ex);
+	int exp2 = ex - 1;
+	double quantum = exp2 < -14 ? 5.9604644775390625e-08 : ldexp(1.0, exp2 - 10);
+	double scaled = d / quantum; /* exact: quantum is a power of two */
+	double fl = floor(scaled);
+	if (scaled - fl != 0.5) return orc_double_to_half(s);
+	double q = e > 0.0 ? fl + 1.0 : fl;
+	return (uint16_t)(sign | orc_double_to_half(q * quantum));
+}
+static inline uint16_t orc_half_fma(uint16_t a, uint16_t b, uint16_t c) {
+	double p = (double)orc_half_to_float(a) * (double)orc_half_to_float(b);
+	double cc = (double)orc_half_to_float(c);
+	double s = p + cc;
+	double bb = s - p;
+	double e = (p - (s - bb)) + (cc - bb);
+	return orc_pair_to_half(s, e);
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,8 +223,9 @@ void orc_nerf_release(orc_nerf_model* m) {
  *   pos = fma(scale, x, 0.5); cell = floor(pos); w = pos - cell
  *   index = dense (x + y*R + z*R^2, strides stop once they exceed the level size) or
  *           (x*1 ^ y*2654435761 ^ z*805459861), then % level size
- *   result[f] += (half)(weight * (float)value[f])   -- fp16 accumulation, corner order 0..7,
- *   bit d of the corner index selects the +1 neighbour along dimension d. */
+ *   fp16 accumulation over the corners in the order 0..7 (bit d of the corner index selects the +1 neighbour along
+ *   dimension d), by one of the two published sequences (orc_nerf_model::grid_accumulate, oracle.h):
+ *     result = fma((half)weight, value, result)        or        result[f] += (half)(weight * (float)value[f]) */
 static inline uint32_t grid_index(uint32_t hashmap_size, uint32_t res, const uint32_t* pg) {
 	uint32_t stride = 1, index = 0;
 	for (uint32_t dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
@@ -266,9 +267,14 @@ static void grid_encode_one(const orc_nerf_model* m, const prepared_t* p, const 
 				}
 			}
 			const uint16_t* val = level + (uint64_t)grid_index(size, res, pgl) * F;
-			for (uint32_t f = 0; f < F; ++f) {
-				float prod = weight * orc_half_to_float(val[f]);
-				result[f] = orc_half_add(result[f], orc_float_to_half(prod));
+			if (m->grid_accumulate == ORC_GRID_ACC_FMA) { /* result = fma((T)weight, val, result): one fp16 rounding per term */
+				const uint16_t wh = orc_float_to_half(weight);
+				for (uint32_t f = 0; f < F; ++f) result[f] = orc_half_fma(wh, val[f], result[f]);
+			} else { /* result[f] += (T)(weight * (float)val[f]) */
+				for (uint32_t f = 0; f < F; ++f) {
+					float prod = weight * orc_half_to_float(val[f]);
+					result[f] = orc_half_add(result[f], orc_float_to_half(prod));
+				}
 			}
 		}
 		for (uint32_t f = 0; f < F; ++f) out[l * F + f] = result[f];

@@ -17,7 +17,7 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-LIB_EXACT = os.path.join(HERE, "libngp_hip_exact.so")  # -DNGP_EXACT_TCNN_ENCODE: tcnn's fp16 rounding sequence in the grid encode
+LIB_LEGACY = os.path.join(HERE, "libngp_hip_legacy.so")  # -DNGP_TCNN_LEGACY_ENCODE: the grid encode's corner sum as tcnn had it before its tvec refactor
 
 
 def needs_build(lib=LIB):
@@ -31,20 +31,28 @@ def needs_build(lib=LIB):
     return os.path.getmtime(inc) > t
 
 
-def build(force=False, verbose=False, exact=False):
-    """exact=True builds the variant whose hash-grid encode reproduces tcnn's rounding sequence bit for bit (the parity
-    tests' reference point for gathers and layout); the default build accumulates with packed fmas, 5 % faster."""
-    lib = LIB_EXACT if exact else LIB
+def build(force=False, verbose=False, legacy=False):
+    """The shipped library sums the grid encoding's corners as tvec-era tiny-cuda-nn does (`fma((T)weight, val, result)`),
+    bit for bit the oracle's "fma" mode. legacy=True builds the variant with the older published sequence
+    (`result[f] += (T)(weight * val[f])`, oracle mode "legacy"): tiny-cuda-nn is un-pinned in the reference, so both are
+    kept testable."""
+    lib = LIB_LEGACY if legacy else LIB
     if not force and not needs_build(lib):
         return lib
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + (["-DNGP_EXACT_TCNN_ENCODE"] if exact else []) + ["-o", lib] + srcs + ["-lz"]
+    # link to a private name and rename: another process (a rank of the same job, a test worker) may be dlopen-ing the
+    # library at this moment and must see either the old file or the complete new one
+    tmp = "%s.%d.tmp" % (lib, os.getpid())
+    cmd = [hipcc()] + FLAGS + (["-DNGP_TCNN_LEGACY_ENCODE"] if legacy else []) + ["-o", tmp] + srcs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed")
+    os.replace(tmp, lib)
     return lib
 
 
@@ -65,13 +73,14 @@ def build_pyngp(force=False, verbose=False):
         return out
     build()
     cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include(),
-           srcs[0], "-o", out, "-L", HERE, "-lngp_hip", "-Wl,-rpath,$ORIGIN"]
+           srcs[0], "-o", out + ".%d.tmp" % os.getpid(), "-L", HERE, "-lngp_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("building pyngp failed")
+    os.replace(out + ".%d.tmp" % os.getpid(), out)
     return out
 
 
@@ -86,13 +95,14 @@ def build_main(force=False, verbose=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
     build()
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", srcs[0], "-o", out, "-L", HERE, "-lngp_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", srcs[0], "-o", out + ".%d.tmp" % os.getpid(), "-L", HERE, "-lngp_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("building ngp_hip_main failed")
+    os.replace(out + ".%d.tmp" % os.getpid(), out)
     return out
 
 

@@ -1,8 +1,8 @@
 // Device-side building blocks of the NeRF inference path, written for CDNA4 (gfx950, wave64).
 //
 // Arithmetic contract (DESIGN.md "Numerics"): IEEE fp32, no FMA contraction (-ffp-contract=off), correctly
-// rounded division/sqrt; hash-grid features accumulate in fp16 (packed fmas; -DNGP_EXACT_TCNN_ENCODE: exactly tcnn's
-// kernel_grid rounding sequence, see accumulate_corner); MLP layers run on
+// rounded division/sqrt; hash-grid features accumulate in fp16 exactly as tcnn's kernel_grid does (one fp16 fma per
+// corner and feature, the tvec-era sequence; -DNGP_TCNN_LEGACY_ENCODE: the older one, see accumulate_corner); MLP layers run on
 // v_mfma_f32_16x16x32_f16 (fp16 operands, fp32 accumulate) with activations rounded to fp16 between layers.
 // Each function cites the reference kernel/device function whose behaviour it reproduces.
 #pragma once
@@ -483,7 +483,7 @@ NGP_DEV void corner_weights(const CellPos& p, float* weight) {
 NGP_DEV bool level_in_xor_range(const LevelInfo& L, const CellPos& p) {
 	uint32_t m = p.gx > p.gy ? p.gx : p.gy;
 	m = m > p.gz ? m : p.gz;
-	return m <= L.coord_max;
+	return m <= L.coord_max && !L.xor_disabled;
 }
 
 // tcnn grid_index, byte offsets into ModelParams::grid -- any position, any level shape
@@ -537,11 +537,18 @@ NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const cha
 	return (const char*)grid;
 }
 
-// result[f] += (half)(weight * (float)value[f]) with tcnn's roundings: the fp32 product is rounded to fp32, THEN
-// to fp16, then added in fp16. hipcc would fuse the first two steps into v_fma_mix*_f16, which rounds the exact
-// product once -- more accurate, but a different number in ~2e-5 of the cases (tools/micro/mix_probe.hip) -- so the
-// product is formed as an fp32 value of its own (v_fma_mix_f32). Features are accumulated as packed pairs
-// (v_cvt_pk_f16_f32 + v_pk_add_f16): 8 instructions per corner.
+// The corner sum of tcnn's kernel_grid. tiny-cuda-nn is an un-pinned, un-vendored submodule of the reference
+// (.gitmodules:13-15) and has published two sequences:
+//   tvec era (the tcnn that has tcnn::vec3 / mat4x3, which the reference's sources use throughout):
+//       result = fma((T)weight, grid_val(pos_grid_local), result);
+//     the weight is rounded to fp16 once, then one fp16 fma (single rounding) per feature. This is what ships:
+//     v_cvt_f16_f32 + two v_pk_fma_f16 per corner, bit for bit the oracle's ORC_GRID_ACC_FMA.
+//   before the tvec refactor (-DNGP_TCNN_LEGACY_ENCODE, libngp_hip_legacy.so, oracle ORC_GRID_ACC_LEGACY):
+//       result[f] += (T)(weight * (float)val[f]);
+//     the fp32 product is rounded to fp32, THEN to fp16, then added in fp16. hipcc would fuse the first two steps into
+//     v_fma_mix*_f16, which rounds the exact product once -- a different number in ~2e-5 of the cases
+//     (tools/micro/mix_probe.hip) -- so the product is formed as an fp32 value of its own (v_fma_mix_f32) and the
+//     features are accumulated as packed pairs (v_cvt_pk_f16_f32 + v_pk_add_f16): 8 instructions per corner.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 struct FeatureAcc {
 	half2_t f01, f23;
@@ -559,11 +566,7 @@ NGP_DEV float product_hi(float w, uint32_t packed) {
 	return p;
 }
 NGP_DEV void accumulate_corner(uint2 v, float w, FeatureAcc& r) {
-#ifndef NGP_EXACT_TCNN_ENCODE
-	// weight rounded to fp16 once, then one packed fma per feature pair: 3 instructions per corner instead of 8. Each
-	// term carries one fp16 rounding (of the weight) plus the fma's, where tcnn's sequence carries the product's and the
-	// add's: the same error size, different bits (<= 2 fp16 ulp of the largest term apart). -DNGP_EXACT_TCNN_ENCODE
-	// restores tcnn's sequence bit for bit (5 % slower end to end).
+#ifndef NGP_TCNN_LEGACY_ENCODE
 	const half2_t wh = {(half_t)w, (half_t)w};
 	const uint32_t wv = __builtin_bit_cast(uint32_t, wh);
 	uint32_t a01 = __builtin_bit_cast(uint32_t, r.f01), a23 = __builtin_bit_cast(uint32_t, r.f23);
@@ -571,8 +574,7 @@ NGP_DEV void accumulate_corner(uint2 v, float w, FeatureAcc& r) {
 	asm("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(a23) : "v"(wv), "v"(v.y));
 	r.f01 = __builtin_bit_cast(half2_t, a01);
 	r.f23 = __builtin_bit_cast(half2_t, a23);
-	return;
-#endif
+#else
 	half2_t a, b;
 	a[0] = (half_t)product_lo(w, v.x);
 	a[1] = (half_t)product_hi(w, v.x);
@@ -580,6 +582,7 @@ NGP_DEV void accumulate_corner(uint2 v, float w, FeatureAcc& r) {
 	b[1] = (half_t)product_hi(w, v.y);
 	r.f01 = r.f01 + a;
 	r.f23 = r.f23 + b;
+#endif
 }
 NGP_DEV void store_features(const FeatureAcc& lo, const FeatureAcc& hi, half8& out) {
 	out[0] = lo.f01[0]; out[1] = lo.f01[1]; out[2] = lo.f23[0]; out[3] = lo.f23[1];

@@ -23,6 +23,7 @@ constexpr int BLOCK = 256;
 //   skip_steps  empty-space iterations per lane between two looks at the sample queue
 //   go_min      run the network once this many samples wait ...
 //   max_stall   ... or after this many rounds of waiting for marching lanes
+//   block_jumps leave empty 4^3 / 16^3 occupancy blocks in one step (1, default) or voxel by voxel like the reference (0)
 
 struct Accum {
 	float r, g, b, a;
@@ -406,7 +407,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 						} else if (outside && to_grid > 0.0f) {
 							ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
 						} else {
-							ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, PROBE ? 1u : empty);
+							ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
 						}
 						++skip_i;
 					}

@@ -150,7 +150,7 @@ void build_levels(const ngp_model_desc& d, LevelInfo* lv, uint32_t* total_entrie
 		lv[l].offset = offset;
 		lv[l].hashed = n < stride ? 1u : 0u;
 		lv[l].mask = (n & (n - 1)) == 0 ? n - 1 : 0u;
-		lv[l].pad0 = 0;
+		lv[l].xor_disabled = 0;
 		if ((uint64_t)offset + n > 0x1FFFFFFFull) throw std::runtime_error("grid encoding too large for 32-bit gather offsets (more than 2^29 entries)");
 		offset += n;
 	}
@@ -174,13 +174,23 @@ uint64_t pow2_ceil(uint64_t v) {
 }
 void build_xor_layout(LevelInfo* lv, uint32_t n_levels, const uint16_t* grid /* tcnn order, 4 halves per entry */, std::vector<uint64_t>& table) {
 	uint64_t cursor = 0;
-	std::vector<uint32_t> bits(n_levels, 0);
+	std::vector<uint32_t> bits(n_levels, 0), wrapped(n_levels, 0);
 	for (uint32_t l = 0; l < n_levels; ++l) {
 		LevelInfo& L = lv[l];
 		uint64_t bytes;
 		if (L.hashed) {
 			if ((L.size & (L.size - 1)) != 0) throw std::runtime_error("hashed grid level whose size is not a power of two");
 			bytes = (uint64_t)L.size * 8u;
+		} else if ((uint64_t)L.res * L.res * L.res > (uint64_t)L.size) {
+			// tcnn's grid_index forms its strides in uint32: at res = 65536 (level 6 of the upstream aabb_scale-128 configuration,
+			// per_level_scale 4) res^2 wraps to 0, the loop's guard `stride <= hashmap_size` keeps going and the level is indexed
+			// as (x + y * 65536 + z * 0) % size -- dense by the code's own test, with z dropped. Same entries here: x < res and a
+			// power-of-two res keep the fields disjoint (add == xor), so the hashed form serves it with multipliers (res, 0);
+			// the corner x + 1 == res would carry into y's field, hence coord_max = res - 2 (beyond it the wave takes
+			// level_corners on the tcnn-order table, which wraps exactly like tcnn).
+			const bool pow2 = (L.res & (L.res - 1)) == 0 && (L.size & (L.size - 1)) == 0 && L.res * L.res == 0u;
+			wrapped[l] = pow2 ? 1 : 2; // 2: no xor form -- every wave takes the tcnn-order table for this level
+			bytes = pow2 ? (uint64_t)L.size * 8u : 8u;
 		} else {
 			uint32_t b = 0;
 			while ((1u << b) <= L.res) ++b; // 2^b > res: coordinates 0..res fit
@@ -195,6 +205,15 @@ void build_xor_layout(LevelInfo* lv, uint32_t n_levels, const uint16_t* grid /* 
 			L.mul_y8 = 2654435761u * 8u;
 			L.mul_z8 = 805459861u * 8u;
 			L.mask8 = (L.size - 1u) * 8u;
+		} else if (wrapped[l] == 1) {
+			L.coord_max = L.res - 2u;
+			L.mul_y8 = L.res * 8u;
+			L.mul_z8 = 0u;
+			L.mask8 = (L.size - 1u) * 8u;
+		} else if (wrapped[l] == 2) {
+			L.xor_disabled = 1u;
+			L.coord_max = 0u;
+			L.mul_y8 = L.mul_z8 = L.mask8 = 0u;
 		} else {
 			L.coord_max = L.res - 1u;
 			L.mul_y8 = 8u << bits[l];
@@ -209,10 +228,11 @@ void build_xor_layout(LevelInfo* lv, uint32_t n_levels, const uint16_t* grid /* 
 		const LevelInfo& L = lv[l];
 		uint64_t* dst = table.data() + L.base8 / 8u;
 		const uint64_t* level = src + L.offset;
-		if (L.hashed) {
+		if (L.hashed || wrapped[l] == 1) {
 			std::copy(level, level + L.size, dst);
 			continue;
 		}
+		if (wrapped[l] == 2) continue;
 		const uint32_t b = bits[l];
 		for (uint32_t z = 0; z <= L.res; ++z)
 			for (uint32_t y = 0; y <= L.res; ++y)
@@ -898,6 +918,30 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 }
 
 // ------------------------------------------------------------------------------------------------ frame
+// The scheduling knobs of the persistent render kernel (FrameParams::tune). They never change results except
+// block_jumps (0 = the reference's voxel-by-voxel walk through empty space), but values outside these ranges would
+// leave a wave spinning in fused_body's loop (a refill threshold above 64 never refills, zero march steps never
+// advance a ray): a GPU hang, not an error. Hence one gate for every way of setting them.
+void validate_schedule(const int32_t* t, int n) {
+	static const struct { const char* name; int lo, hi; } range[8] = {{"refill_min", 16, 64}, {"skip_steps", 1, 64},  {"go_min", 1, 64},      {"max_stall", 0, 64},
+	                                                                  {"links_busy", 0, 3},   {"links_drain", 0, 3},  {"block_jumps", 0, 1}, {"spare", 0, 0}};
+	if (n < 0 || n > 8) throw std::runtime_error("schedule: at most 8 knobs");
+	for (int i = 0; i < n; ++i)
+		if (t[i] < range[i].lo || t[i] > range[i].hi)
+			throw std::runtime_error(std::string("schedule knob ") + range[i].name + " = " + std::to_string(t[i]) + " outside [" + std::to_string(range[i].lo) + ", " + std::to_string(range[i].hi) + "]");
+}
+// NGP_TUNE="refill_min,skip_steps,..." (experiments: tools/sweep_tune.sh): read ONCE, at context creation
+void schedule_from_env(ngp_ctx* ctx) {
+	const char* t = getenv("NGP_TUNE");
+	if (!t || !*t) return;
+	int32_t v[8];
+	memcpy(v, ctx->tune, sizeof(v));
+	int n = sscanf(t, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
+	if (n <= 0) throw std::runtime_error("NGP_TUNE: expected a comma-separated list of integers");
+	validate_schedule(v, n);
+	memcpy(ctx->tune, v, sizeof(v));
+}
+
 void ensure_frame_buffers(ngp_ctx* ctx, size_t n_pixels) {
 	if (!ctx->d_sync) {
 		NGP_HIP_CHECK(hipMalloc(&ctx->d_sync, 64 + 32 * ngp_ctx::HISTORY));
@@ -976,7 +1020,6 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.packed = opts.packed_output ? 1 : 0;
 	F.prof = nullptr;
 	memcpy(F.tune, ctx->tune, sizeof(F.tune));
-	if (const char* t = getenv("NGP_TUNE")) sscanf(t, "%d,%d,%d,%d,%d,%d", &F.tune[0], &F.tune[1], &F.tune[2], &F.tune[3], &F.tune[4], &F.tune[5]); // experiments only
 	if (getenv("NGP_PROFILE_SECTIONS")) { // diagnostic: per-section cycle sums of the fused kernel, printed by ngp_get_render_stats
 		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 512));
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 512, stream));
@@ -1131,6 +1174,14 @@ ngp_ctx* ngp_create(int device) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
 	if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+		delete ctx;
+		return nullptr;
+	}
+	try {
+		schedule_from_env(ctx);
+	} catch (const std::exception& e) {
+		fprintf(stderr, "ngp_create: %s\n", e.what());
+		(void)hipStreamDestroy(ctx->stream);
 		delete ctx;
 		return nullptr;
 	}
@@ -1447,6 +1498,15 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
 			        100.0 * p[0] / tot, 100.0 * p[1] / tot, 100.0 * p[2] / tot, 100.0 * p[3] / tot, p[4], p[5], tot / (double)p[4], (double)p[2] / (double)p[5], p[6], p[7], (double)p[7] / (double)p[6], (double)p[1] / (double)p[6]);
 		}
+	});
+}
+
+int ngp_set_schedule(ngp_ctx* ctx, const int32_t* knobs, int n) {
+	return guarded(ctx, [&] {
+		if (!knobs) throw std::runtime_error("schedule: null");
+		validate_schedule(knobs, n);
+		if (ctx->last_stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+		for (int i = 0; i < n; ++i) ctx->tune[i] = knobs[i];
 	});
 }
 

@@ -219,7 +219,7 @@ struct ngp_ctx {
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
 	hipStream_t last_stream = nullptr;
 	unsigned long long* d_prof = nullptr;
-	int32_t tune[6] = {64, 4, 32, 1, 0, 3};
+	int32_t tune[8] = {64, 4, 32, 1, 0, 3, 1, 0}; // FrameParams::tune; changed only through validate_schedule (ngp_api.cpp)
 
 	// ---- training (ngp_train.cpp)
 	ngp::TrainState* train = nullptr;

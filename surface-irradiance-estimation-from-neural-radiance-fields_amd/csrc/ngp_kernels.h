@@ -37,7 +37,7 @@ struct LevelInfo {
 	// build_xor_layout)
 	uint32_t coord_max;
 	uint32_t mul_y8, mul_z8, mask8, base8;
-	uint32_t pad0;
+	uint32_t xor_disabled; // 1: the level has no xor form (a dense index whose uint32 strides wrapped, not a power-of-two shape)
 };
 static_assert(sizeof(LevelInfo) == 48, "LevelInfo layout");
 
@@ -98,7 +98,8 @@ struct FrameParams {
 	int32_t linear_colors;
 	int32_t depth_test;
 	int32_t packed;           // 1: pixel (local tile q, slot s) is written at q*64+s (tile-packed layout for the RCCL gather) instead of x+W*y
-	int32_t tune[6];          // refill_min, skip_steps, go_min, max_stall, chain links while tiles remain / once the queue is empty (nerf_kernels.hip)
+	int32_t tune[8];          // refill_min, skip_steps, go_min, max_stall, chain links while tiles remain / once the queue is empty,
+	                          // block_jumps (0: the reference's one-voxel steps only), spare (nerf_kernels.hip; validated by ngp_set_schedule)
 	// direct output (1 spp, no mesh pass): the kernel writes the final pixel -- accumulate_kernel + tonemap_kernel
 	// (src/render_buffer.cu:228-262, 529-561) folded into ray setup / shading -- into frame_buffer = the caller's image
 	int32_t outside_possible; // the render box is not contained in the outermost cascade's cube (kernel selection)

@@ -950,7 +950,7 @@ __global__ void train_optimizer_kernel(const AdamParams A, float* __restrict__ w
 __global__ void train_xor_layout_kernel(const LevelInfo L, const uint2* __restrict__ src, char* __restrict__ dst, uint32_t n) {
 	const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
 	if (t >= n) return;
-	if (L.hashed) {
+	if (L.mask8 != 0xFFFFFFFFu) { // hashed levels, and dense indices whose uint32 strides wrapped (build_xor_layout): entry for entry
 		*(uint2*)(dst + L.base8 + (size_t)t * 8u) = src[L.offset + t];
 		return;
 	}
@@ -1051,7 +1051,8 @@ void launch_train_optimizer(const AdamParams& A, float* weights_fp32, uint16_t* 
 void launch_train_xor_layout(const ModelParams& M, const uint2* src, char* dst, hipStream_t stream) {
 	for (int l = 0; l < N_LEVELS; ++l) {
 		const LevelInfo& L = M.levels[l];
-		const uint32_t n = L.hashed ? L.size : (L.res + 1u) * (L.res + 1u) * (L.res + 1u);
+		if (L.xor_disabled) continue; // no xor form: the render kernels read this level from the tcnn-order table
+		const uint32_t n = L.mask8 != 0xFFFFFFFFu ? L.size : (L.res + 1u) * (L.res + 1u) * (L.res + 1u);
 		hipLaunchKernelGGL(train_xor_layout_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, L, src, dst, n);
 	}
 }

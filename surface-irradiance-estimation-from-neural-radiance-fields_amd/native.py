@@ -123,7 +123,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    LIB_PATH = os.environ.get("NGP_HIP_LIBRARY") or globals()["LIB_PATH"]  # e.g. the exact-encode variant, libngp_hip_exact.so
+    LIB_PATH = os.environ.get("NGP_HIP_LIBRARY") or globals()["LIB_PATH"]  # e.g. the legacy-encode variant, libngp_hip_legacy.so
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py or the package's build.py). "
                            "There is no CPU fallback.")
@@ -156,6 +156,7 @@ def load_library():
     L.ngp_packed_tiles.restype = C.c_uint32
     L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
     L.ngp_get_render_history.argtypes = [vp, ip, C.POINTER(RenderStats)]
+    L.ngp_set_schedule.argtypes = [vp, vp, ip]
     L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
     L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.ngp_get_density_bitfield.argtypes = [vp, vp, vp]
@@ -271,6 +272,11 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError(self.L.ngp_last_error(self.h).decode(errors="replace"))
+
+    def set_schedule(self, *knobs):
+        """refill_min, skip_steps, go_min, max_stall, links_busy, links_drain, block_jumps (ngp_set_schedule: validated)"""
+        a = np.asarray(knobs, np.int32)
+        self._check(self.L.ngp_set_schedule(self.h, _p(a), a.size))
 
     # ---------------------------------------------------------------- model
     def set_model(self, scene):

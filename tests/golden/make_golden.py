@@ -1,9 +1,11 @@
-"""Generates tests/golden/nerf_unit_v1.npz: inputs and expected outputs of the CPU oracle for a small seeded scene.
+"""Generates tests/golden/nerf_unit_v{1,2}.npz: inputs and expected outputs of the CPU oracle for a small seeded scene.
+v1 = the grid encoding's corner sum as tiny-cuda-nn had it before its tvec refactor ("legacy"), v2 = the tvec-era fma
+sum ("fma", what libngp_hip.so ships); see oracle.h orc_nerf_model::grid_accumulate.
 
 The reference ships no golden vectors, cannot be built here (CUDA + absent tiny-cuda-nn) and has no CPU path, so
 these vectors come from the build's own oracle (PARITY UNPINNED, see oracle/orc_common.h). They pin the oracle
 against regressions and platform drift, and give the GPU tests a committed target that does not depend on the
-oracle being rebuilt. Run from the repo root:  python tests/golden/make_golden.py
+oracle being rebuilt. Run from the repo root:  python tests/golden/make_golden.py [1|2]
 """
 import hashlib
 import importlib
@@ -36,11 +38,15 @@ def build_inputs():
     return sc, pos, dir01, cam_matrix, focal
 
 
-def main():
+VERSIONS = {1: "legacy", 2: "fma"}
+
+
+def main(version=2):
     import oracle as orc
 
     o = orc.Oracle()
     sc, pos, dir01, cam_matrix, focal = build_inputs()
+    sc["grid_accumulate"] = VERSIONS[version]
     grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
     bf, mean = o.density_grid_to_bitfield(grid, sc["max_cascade"])
     sc["density_grid_bitfield"] = bf
@@ -63,10 +69,10 @@ def main():
         ld_vals=np.array([o.ld_random_val(i, s) for i in range(8) for s in (0, 786433, 0xdeadbeef)], np.float32),
         pixel_offsets=np.stack([o.pixel_offset(s) for s in range(6)]),
     )
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nerf_unit_v1.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nerf_unit_v%d.npz" % version)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", st)
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2)

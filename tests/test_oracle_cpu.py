@@ -11,9 +11,12 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def golden():
-    return np.load(os.path.join(HERE, "golden", "nerf_unit_v1.npz"))
+@pytest.fixture(scope="module", params=[1, 2])
+def golden(request):
+    """v1: the pre-tvec corner sum of the grid encoding ("legacy"), v2: the tvec-era fma sum (tests/golden/make_golden.py)"""
+    g = dict(np.load(os.path.join(HERE, "golden", "nerf_unit_v%d.npz" % request.param)))
+    g["grid_accumulate"] = {1: "legacy", 2: "fma"}[request.param]
+    return g
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +40,7 @@ def test_fixture_inputs_are_reproducible(golden, golden_inputs):
 
 def test_oracle_matches_golden_vectors(oracle, golden, golden_inputs):
     sc, pos, dir01, cam_matrix, focal, mg = golden_inputs
+    sc = dict(sc, grid_accumulate=golden["grid_accumulate"])
     assert np.array_equal(pos, golden["pos"]) and np.array_equal(dir01, golden["dir01"])
     sha = hashlib.sha256(sc["density_grid_bitfield"].tobytes()).digest()
     assert np.array_equal(np.frombuffer(sha, np.uint8), golden["bitfield_sha256"])
@@ -75,6 +79,7 @@ def test_fp16_emulation_matches_ieee(oracle):
         void conv(int n, const float* in, unsigned short* out) { for (int i = 0; i < n; ++i) out[i] = orc_float_to_half(in[i]); }
         void back(int n, const unsigned short* in, float* out) { for (int i = 0; i < n; ++i) out[i] = orc_half_to_float(in[i]); }
         void add(int n, const unsigned short* a, const unsigned short* b, unsigned short* out) { for (int i = 0; i < n; ++i) out[i] = orc_half_add(a[i], b[i]); }
+        void fma3(int n, const unsigned short* a, const unsigned short* b, const unsigned short* c, unsigned short* out) { for (int i = 0; i < n; ++i) out[i] = orc_half_fma(a[i], b[i], c[i]); }
     ''')
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "shim.c")
@@ -99,10 +104,94 @@ def test_fp16_emulation_matches_ieee(oracle):
         with np.errstate(over="ignore"):
             refs = (a.view(np.float16).astype(np.float64) + b.view(np.float16).astype(np.float64)).astype(np.float16)
         assert np.array_equal(s.view(np.float16).astype(np.float32), refs.astype(np.float32))
+        # single-rounding fma (the tvec-era corner sum) against exact integer arithmetic: random operands below 64, plus ties
+        # -- products that land exactly on an fp16 rounding boundary and an addend far too small to show in a double sum
+        n = 300000
+        def rnd(n):  # magnitudes in [2^-24, 64): exponent field 0..20
+            return (rng.integers(0, 21 << 10, n).astype(np.uint16) | (rng.integers(0, 2, n).astype(np.uint16) << 15))
+        fa, fb, fc = rnd(n), rnd(n), rnd(n)
+        # ties: a = 1 + 2^-10 k (11 bits), b = 1 + 2^-1 -> a*b has 12+ bits; c = +-2^-24 nudges the tie either way
+        k = rng.integers(0, 1024, 4096)
+        ta = np.float16(1.0) + (k * 2.0 ** -10).astype(np.float16)
+        tb = np.full(4096, 1.5, np.float16)
+        tc = np.where(rng.integers(0, 2, 4096) == 0, np.float16(2.0 ** -24), np.float16(-(2.0 ** -24))).astype(np.float16)
+        tc[::3] = 0
+        fa = np.concatenate([fa, ta.view(np.uint16), (ta * np.float16(32)).view(np.uint16)])
+        fb = np.concatenate([fb, tb.view(np.uint16), tb.view(np.uint16)])
+        fc = np.concatenate([fc, tc.view(np.uint16), tc.view(np.uint16)])
+        out = np.zeros(fa.size, np.uint16)
+        shim.fma3(fa.size, fa.ctypes.data_as(C.c_void_p), fb.ctypes.data_as(C.c_void_p), fc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        ref = _half_fma_exact(fa.view(np.float16), fb.view(np.float16), fc.view(np.float16))
+        assert np.array_equal(out.view(np.float16).astype(np.float32), ref.astype(np.float32))
+        # larger magnitudes (product ~2^12 on or next to a tie, addends from 2^-24 to 1): checked with Fractions
+        from fractions import Fraction
+        import math
+
+        def round_half(x):
+            if x == 0:
+                return 0.0
+            sgn, x = (-1.0, -x) if x < 0 else (1.0, x)
+            e = math.floor(math.log2(float(x)))
+            while Fraction(2) ** e > x:
+                e -= 1
+            while Fraction(2) ** (e + 1) <= x:
+                e += 1
+            quantum = Fraction(2) ** max(e - 10, -24)
+            q = x / quantum
+            fl = q.numerator // q.denominator
+            rem = q - fl
+            if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+                fl += 1
+            v = float(fl * quantum)
+            return sgn * (math.inf if v >= 65520.0 else v)
+
+        ks = rng.integers(0, 1024, 600)
+        wa = (np.float16(2.0 ** 6) * (np.float16(1.0) + (ks * 2.0 ** -10).astype(np.float16))).astype(np.float16)
+        wb = np.full(600, 48.0, np.float16)  # 1.5 * 2^5: the product sits on or next to a tie of the 2^11..2^13 binades
+        wc = np.tile(np.array([2.0 ** -24, -(2.0 ** -24), 0.0, 3.0 * 2.0 ** -24, -(2.0 ** -14), 1.0], np.float16), 100)
+        wa[1::2] = -wa[1::2]
+        out = np.zeros(600, np.uint16)
+        shim.fma3(600, wa.ctypes.data_as(C.c_void_p), wb.ctypes.data_as(C.c_void_p), wc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        want = np.array([round_half(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))) for a, b, c in zip(wa, wb, wc)], np.float32)
+        assert np.array_equal(out.view(np.float16).astype(np.float32), want)
 
 
-def _grid_encode_numpy(sc, scene_mod, pos, scales=None):
-    """Independent restatement of tcnn's kernel_grid with numpy float16 arithmetic."""
+def _half_fma_exact(a16, b16, c16):
+    """fma(a, b, c) on binary16 with ONE rounding, in exact integer arithmetic (a second implementation next to the
+    oracle's TwoSum one): every finite half is a multiple of 2^-24, so a*b + c is N * 2^-48 with N an int64 as long as
+    the magnitudes stay below 64 (asserted). Round-half-even of N to the fp16 grid of its binade."""
+    def to_int(h):  # h * 2^24 as int64 (exact)
+        v = h.astype(np.float64) * 2.0 ** 24
+        assert np.all(v == np.rint(v))
+        return v.astype(np.int64)
+    a, b, c = to_int(a16), to_int(b16), to_int(c16)
+    assert np.abs(a).max(initial=0) < 2 ** 30 and np.abs(b).max(initial=0) < 2 ** 30 and np.abs(c).max(initial=0) < 2 ** 30
+    n = a * b + (c << 24)
+    sign = np.where(n < 0, -1, 1).astype(np.int64)
+    mag = np.abs(n)
+    # floor(log2 mag): bit length - 1 (0 for mag 0)
+    bl = np.zeros(mag.shape, np.int64)
+    t = mag.copy()
+    for sh in (32, 16, 8, 4, 2, 1):
+        m = t >= (np.int64(1) << sh)
+        bl = np.where(m, bl + sh, bl)
+        t = np.where(m, t >> sh, t)
+    e = bl - 48                                   # value in [2^e, 2^(e+1))
+    q_exp = np.maximum(e - 10, -24)               # fp16 quantum of that binade (subnormals: 2^-24)
+    shift = q_exp + 48                            # >= 24
+    half = np.int64(1) << (shift - 1)
+    q = mag >> shift
+    rem = mag & ((np.int64(1) << shift) - 1)
+    q = q + ((rem > half) | ((rem == half) & ((q & 1) == 1))).astype(np.int64)
+    val = sign.astype(np.float64) * q.astype(np.float64) * np.exp2(q_exp.astype(np.float64))
+    with np.errstate(over="ignore"):
+        return val.astype(np.float16)  # exact: val is already on the fp16 grid (or beyond the range -> inf)
+
+
+def _grid_encode_numpy(sc, scene_mod, pos, scales=None, mode="fma"):
+    """Independent restatement of tcnn's kernel_grid with numpy float16 arithmetic, in both published corner sums
+    (oracle.h orc_nerf_model::grid_accumulate): "fma" = result = fma((T)weight, val, result), "legacy" =
+    result[f] += (T)(weight * (float)val[f])."""
     enc = sc["encoding"]
     F = enc["n_features_per_level"]
     offsets, resolutions, py_scales = scene_mod.grid_layout(enc)
@@ -134,15 +223,20 @@ def _grid_encode_numpy(sc, scene_mod, pos, scales=None):
             else:
                 idx = gl[0] ^ (gl[1] * np.uint32(2654435761)) ^ (gl[2] * np.uint32(805459861))
             idx = idx % np.uint32(size)
-            prod = (wt[:, None] * lvl[idx].astype(np.float32)).astype(np.float32).astype(np.float16)
-            acc = (acc.astype(np.float64) + prod.astype(np.float64)).astype(np.float16)
+            if mode == "fma":
+                wh = np.broadcast_to(wt.astype(np.float16)[:, None], acc.shape)
+                acc = _half_fma_exact(wh, lvl[idx], acc)
+            else:
+                prod = (wt[:, None] * lvl[idx].astype(np.float32)).astype(np.float32).astype(np.float16)
+                acc = (acc.astype(np.float64) + prod.astype(np.float64)).astype(np.float16)
         out[:, l * F:(l + 1) * F] = acc
     return out
 
 
+@pytest.mark.parametrize("mode", ["fma", "legacy"])
 @pytest.mark.parametrize("which", ["unit", "big"])
-def test_grid_encode_against_numpy(which, oracle, scene_mod, scene_unit, scene_big):
-    sc = scene_unit if which == "unit" else scene_big
+def test_grid_encode_against_numpy(which, mode, oracle, scene_mod, scene_unit, scene_big):
+    sc = dict(scene_unit if which == "unit" else scene_big, grid_accumulate=mode)
     m = oracle.make_model(sc)
     rng = np.random.default_rng(9)
     pos = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
@@ -151,7 +245,7 @@ def test_grid_encode_against_numpy(which, oracle, scene_mod, scene_unit, scene_b
     # build's host code); numpy's float32 exp2/log2 can differ by an ulp, so the restatement takes the scales as data
     off, res, scl = oracle.grid_layout(m)
     with np.errstate(over="ignore"):
-        ref = _grid_encode_numpy(sc, scene_mod, pos, scl)
+        ref = _grid_encode_numpy(sc, scene_mod, pos, scl, mode)
     got = oracle.grid_encode(m, pos)
     assert np.array_equal(got.astype(np.float32), ref.astype(np.float32))
     # layout agrees with the host-side table used for sizing

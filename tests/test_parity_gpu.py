@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): bit-exact for integer/bit work (occupancy bitfield, ray setup; fp16 hash-grid
-features in the exact-encode build, within 4 fp16 ulp in the shipped one); floating point within the stated tolerances: PSNR vs oracle >= 50 dB (the 0.1 dB budget against ground
+features of the hash grid); floating point within the stated tolerances: PSNR vs oracle >= 50 dB (the 0.1 dB budget against ground
 truth allows ~36 dB), per-pixel |d| < 1e-2 on radiance, fp16 network outputs within 4 ulp.
 """
 import os
@@ -44,19 +44,16 @@ def test_bitfield_bit_exact(which, gpu_ctx, oracle, scene_unit, scene_big):
 
 
 def assert_encode_close(got, ref):
-    """Default build: features accumulate with packed fp16 fmas (weight rounded to fp16, one rounding per term) where
-    tcnn rounds the fp32 product and then the fp16 sum: both carry ~1 fp16 ulp of the largest term per corner, with
-    different bits. Tolerance: 4 ulp at the scale of the largest feature (a wrong gather is ~100x that). The
-    exact-sequence build is compared bit for bit in test_exact_encode_variant."""
+    """The shipped build sums a level's corners as tvec-era tiny-cuda-nn does -- result = fma((T)weight, val, result), one
+    v_pk_fma_f16 per feature pair -- and the oracle's default ("fma") restates exactly that: compared as values (so that
+    -0 == +0) and required to be EQUAL. (The older published sum is the legacy build: test_legacy_encode_variant.)"""
     got, ref = np.asarray(got, np.float32), np.asarray(ref, np.float32)
-    scale = max(float(np.abs(ref).max()), 2.0 ** -14)
-    ulp = 2.0 ** (np.floor(np.log2(scale)) - 10)
-    err = np.abs(got - ref)
-    assert got.shape == ref.shape and err.max() <= 4 * ulp, (err.max(), ulp)
-    assert (err <= ulp).mean() > 0.97
+    assert got.shape == ref.shape
+    bad = got != ref
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} features differ, max |d| {np.abs(got - ref).max()}"
 
 
-EXACT_SCRIPT = """
+LEGACY_SCRIPT = """
 import importlib, os, sys
 import os
 
@@ -68,6 +65,7 @@ import oracle as O
 orc = O.Oracle()
 for kw in (dict(aabb_scale=1, seed=1234, log2_hashmap_size=15), dict(aabb_scale=4, seed=99, log2_hashmap_size=16, pls_rule="upstream")):
     sc = syn.make_scene(**kw)
+    sc["grid_accumulate"] = "legacy"
     g = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
     sc["density_grid_bitfield"], sc["density_grid_mean"] = orc.density_grid_to_bitfield(g, sc["max_cascade"])
     ctx = native.Context(0); ctx.set_model(sc); m = orc.make_model(sc)
@@ -81,20 +79,21 @@ for kw in (dict(aabb_scale=1, seed=1234, log2_hashmap_size=15), dict(aabb_scale=
         p = rng.uniform(0, 1, (n, 3)).astype(np.float32)
         assert np.array_equal(ctx.grid_encode(p).astype(np.float32), orc.grid_encode(m, p).astype(np.float32))
     ctx.close()
-print("EXACT-OK")
+print("LEGACY-OK")
 """
 
 
-def test_exact_encode_variant(native):
-    """libngp_hip_exact.so (-DNGP_EXACT_TCNN_ENCODE): the same gathers, the same fp16 roundings as tcnn's kernel_grid --
-    compared as values (so that -0 == +0) and required to be equal, in a process of its own."""
+def test_legacy_encode_variant(native):
+    """libngp_hip_legacy.so (-DNGP_TCNN_LEGACY_ENCODE): the corner sum tiny-cuda-nn published before its tvec refactor,
+    result[f] += (T)(weight * (float)val[f]) -- bit for bit the oracle's "legacy" mode, in a process of its own. The
+    reference pins no tiny-cuda-nn version, so both published sequences stay buildable and tested."""
     import subprocess
     import sys
 
-    lib = pkg("build").build(exact=True)
+    lib = pkg("build").build(legacy=True)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", EXACT_SCRIPT.format(root=root)], env=dict(os.environ, NGP_HIP_LIBRARY=lib), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "EXACT-OK" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-c", LEGACY_SCRIPT.format(root=root)], env=dict(os.environ, NGP_HIP_LIBRARY=lib), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LEGACY-OK" in r.stdout, r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("which", ["unit", "big"])
@@ -192,11 +191,11 @@ def test_network_outputs(which, gpu_ctx, oracle, scene_unit, scene_big):
     assert np.isfinite(got).all()
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)  # fp16 spacing at |ref|
     err = np.abs(got - ref)
-    # MFMA accumulation order differs from the oracle's exact sum, so a hidden activation can flip by one fp16 ulp
-    # and move an output logit (|logit| ~ 5, fp16 spacing 2^-8 there) by a few spacings
-    # (and the default build's encode differs from the oracle's by an fp16 ulp or two per feature, see assert_encode_close)
-    assert err.max() <= 6e-2, f"max err {err.max()} at ref {ref.ravel()[err.argmax()]}"
-    assert (err <= 4 * ulp).mean() > 0.90 and np.median(err / ulp) <= 2.0
+    # the encoded features are bit-identical (test_grid_encode); the MFMA's fp32 accumulation order differs from the oracle's
+    # exact sum, so a hidden activation can flip by one fp16 ulp and move an output logit (|logit| ~ 5, fp16 spacing 2^-8
+    # there) by a few spacings
+    assert err.max() <= 3e-2, f"max err {err.max()} at ref {ref.ravel()[err.argmax()]}"
+    assert (err == 0).mean() > 0.5 and (err <= ulp).mean() > 0.90
     oracle.release(m)
 
 
