@@ -1,6 +1,6 @@
-"""Generates tests/golden/train_unit_v1.npz: inputs and expected outputs of the training oracle (sample generation,
+"""Generates tests/golden/train_unit_v2.npz: inputs and expected outputs of the training oracle (sample generation,
 loss + dL/d output, one float64 backward, one Adam / Ema step) for the seeded scene of make_golden.py and two small
-synthetic views. Like nerf_unit_v1.npz these vectors come from the build's own oracle (PARITY UNPINNED): they pin it
+synthetic views. Like nerf_unit_v2.npz (the network forward uses the shipped, tvec-era corner sum of the grid encoding) these vectors come from the build's own oracle (PARITY UNPINNED): they pin it
 against regressions and platform drift. Run from the repo root:  python tests/golden/make_golden_train.py
 """
 import importlib
@@ -65,5 +65,5 @@ def compute():
 
 if __name__ == "__main__":
     out = compute()
-    np.savez_compressed(os.path.join(HERE, "train_unit_v1.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "train_unit_v2.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})

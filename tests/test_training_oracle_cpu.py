@@ -132,7 +132,7 @@ def test_loss_kernel_gradient_is_the_derivative_of_its_loss(loss_setup, loss_typ
 
 
 def test_training_oracle_matches_golden_vectors():
-    """tests/golden/train_unit_v1.npz (made by make_golden_train.py): the training oracle recomputed from the seeded
+    """tests/golden/train_unit_v2.npz (made by make_golden_train.py): the training oracle recomputed from the seeded
     inputs -- integers and sample positions exactly, floating point to the last few ulps across compilers / numpy."""
     import importlib.util
 
@@ -141,7 +141,7 @@ def test_training_oracle_matches_golden_vectors():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     got = mod.compute()
-    ref = np.load(os.path.join(here, "golden", "train_unit_v1.npz"))
+    ref = np.load(os.path.join(here, "golden", "train_unit_v2.npz"))
     for k in ("numsteps", "base", "total", "compacted_numsteps", "grad_index", "n_touched"):
         assert np.array_equal(got[k], ref[k]), k
     assert np.array_equal(got["coords"], ref["coords"]) and np.array_equal(got["net"], ref["net"])
