@@ -522,19 +522,14 @@ NGP_DEV void level_corners_xor(const LevelInfo& L, const CellPos& p, CornerSet& 
 	}
 }
 
-// Corner offsets + weights of the two levels a lane owns, and which table they index. Every render sample lies in
-// the xor layout's range; positions outside [0, 1] (possible through ngp_grid_encode / a render box larger than the
-// training box) take the tcnn-order table for the whole wave.
-NGP_DEV const char* level_pair_corners(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo& L0, const LevelInfo& L1, const CellPos& p0,
-                                       const CellPos& p1, CornerSet& c0, CornerSet& c1) {
-	if (__all((int)level_in_xor_range(L0, p0) & (int)level_in_xor_range(L1, p1))) {
-		level_corners_xor(L0, p0, c0);
-		level_corners_xor(L1, p1, c1);
-		return xgrid;
-	}
-	level_corners(L0, p0, c0);
-	level_corners(L1, p1, c1);
-	return (const char*)grid;
+// Gathers are buffer loads (a 128-bit resource descriptor in SGPRs + a 32-bit per-lane byte offset) rather than flat
+// loads from a 64-bit address: no 64-bit add per gather, and an out-of-range offset reads zeros instead of faulting.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t GridRsrc;
+NGP_DEV GridRsrc make_grid_rsrc(const void* table, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(table), (short)0, (int)bytes, 0x00020000); }
+NGP_DEV uint2 gather8(GridRsrc r, uint32_t offset) {
+	const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)offset, 0, 0);
+	return make_uint2(v.x, v.y);
 }
 
 // The corner sum of tcnn's kernel_grid. tiny-cuda-nn is an un-pinned, un-vendored submodule of the reference
@@ -599,17 +594,29 @@ struct EncodeInFlight {
 	uint2 v[16];
 	float wx[2], wy[2], wz[2];
 };
-NGP_DEV void encode_issue(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
+NGP_DEV void encode_issue(GridRsrc grid, GridRsrc xgrid, const LevelInfo* lv, int h, float x, float y, float z, EncodeInFlight& e) {
 	const LevelInfo& L0 = lv[h];
 	const LevelInfo& L1 = lv[h + 4];
 	const CellPos p0 = level_cell(L0, x, y, z), p1 = level_cell(L1, x, y, z);
 	CornerSet c0, c1;
-	// 32-bit byte offsets: both tables are below 4 GiB (checked by the host)
-	const char* base = level_pair_corners(grid, xgrid, L0, L1, p0, p1, c0, c1);
+	// Every render sample lies in the xor layout's range; positions outside [0, 1] (possible through ngp_grid_encode / a
+	// render box larger than the training box) take the tcnn-order table for the whole wave. 32-bit byte offsets: both
+	// tables are below 2 GiB (checked by the host).
+	if (__all((int)level_in_xor_range(L0, p0) & (int)level_in_xor_range(L1, p1))) {
+		level_corners_xor(L0, p0, c0);
+		level_corners_xor(L1, p1, c1);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) e.v[c] = *(const uint2*)(base + c0.index[c]);
+		for (int c = 0; c < 8; ++c) e.v[c] = gather8(xgrid, c0.index[c]);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) e.v[8 + c] = *(const uint2*)(base + c1.index[c]);
+		for (int c = 0; c < 8; ++c) e.v[8 + c] = gather8(xgrid, c1.index[c]);
+	} else {
+		level_corners(L0, p0, c0);
+		level_corners(L1, p1, c1);
+#pragma unroll
+		for (int c = 0; c < 8; ++c) e.v[c] = gather8(grid, c0.index[c]);
+#pragma unroll
+		for (int c = 0; c < 8; ++c) e.v[8 + c] = gather8(grid, c1.index[c]);
+	}
 	e.wx[0] = p0.wx; e.wy[0] = p0.wy; e.wz[0] = p0.wz;
 	e.wx[1] = p1.wx; e.wy[1] = p1.wy; e.wz[1] = p1.wz;
 }
@@ -629,7 +636,7 @@ NGP_DEV half8 encode_finish(const EncodeInFlight& e) {
 	store_features(acc[0], acc[1], out);
 	return out;
 }
-NGP_DEV half8 encode_level_pair(const uint2* __restrict__ grid, const char* __restrict__ xgrid, const LevelInfo* lv, int h, float x, float y, float z) {
+NGP_DEV half8 encode_level_pair(GridRsrc grid, GridRsrc xgrid, const LevelInfo* lv, int h, float x, float y, float z) {
 	EncodeInFlight e;
 	encode_issue(grid, xgrid, lv, h, x, y, z, e);
 	return encode_finish(e);

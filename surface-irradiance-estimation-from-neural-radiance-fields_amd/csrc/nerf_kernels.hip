@@ -184,6 +184,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 	const int lane = threadIdx.x & 63;
 	const int c = lane & 15;
+	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
 	// direct output: the background's trip through the tonemap is the same for every pixel
 	// (the background colour is sRGB: linearised unless the frame is averaged in sRGB, src/render_buffer.cu:537-541)
@@ -488,8 +489,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			sample_of(p, ax, ay, az, sha);
 			sample_of(p + 1, bx, by, bz, shb);
 			EncodeInFlight ea, eb;
-			encode_issue(M.grid, M.xgrid, s_lv, hq, ax, ay, az, ea);
-			encode_issue(M.grid, M.xgrid, s_lv, hq, bx, by, bz, eb);
+			encode_issue(t_grid, t_xgrid, s_lv, hq, ax, ay, az, ea);
+			encode_issue(t_grid, t_xgrid, s_lv, hq, bx, by, bz, eb);
 			half8 enca = encode_finish(ea);
 			half8 encb = encode_finish(eb);
 			MlpOut moa = mlp_pass<RGB_MID>(s_w, lane, enca, sha);
@@ -501,7 +502,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			float ax, ay, az;
 			Sh4 sha;
 			sample_of(p, ax, ay, az, sha);
-			half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, hq, ax, ay, az);
+			half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, hq, ax, ay, az);
 			MlpOut mo = mlp_pass<RGB_MID>(s_w, lane, enc, sha);
 			deliver(p, mo);
 		}
@@ -704,11 +705,12 @@ __global__ __launch_bounds__(BLOCK) void grid_encode_kernel(const ModelParams M,
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	__syncthreads();
 	const int lane = threadIdx.x & 63, c = lane & 15, h = lane >> 4;
+	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
 	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
 	for (int p = 0; p < 4; ++p) {
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
-		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, h, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, h, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
 		if (s < n) {
 			union { half_t h; uint16_t u; } cv;
 			for (int j = 0; j < 8; ++j) {
@@ -727,11 +729,12 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	__syncthreads();
 	const int lane = threadIdx.x & 63, c = lane & 15;
+	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
 	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
 	for (int p = 0; p < 4; ++p) {
 		uint32_t s = wave * 64u + 16u * p + c;
 		uint32_t sc = s < n ? s : n - 1;
-		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
+		half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, lane >> 4, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2]);
 		MlpOut mo = mlp_pass<RGB_MID>(s_w, lane, enc, sh4_from_dir(lane >> 4, dir01[3 * sc], dir01[3 * sc + 1], dir01[3 * sc + 2]));
 		if (s < n && lane < 16) {
 			union { half_t h; uint16_t u; } cv;
@@ -756,6 +759,7 @@ __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const Model
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	__syncthreads();
 	const int lane = threadIdx.x & 63, c = lane & 15;
+	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
 	// Sample i visits cell ((i + step n) A + C) mod 2^21 first -- a bijection of i's low 21 bits. The reference lets thread
 	// i take sample i, which sends neighbouring lanes to unrelated cells: every hash-grid gather of the wave misses. The
 	// set of samples is what matters (the splat is an atomic max), so thread t takes the sample whose first cell is t
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const Model
 		const float sx = __shfl(w.x, src, 64), sy = __shfl(w.y, src, 64), sz = __shfl(w.z, src, 64);
 		const uint32_t s_idx = (uint32_t)__shfl((int)idx, src, 64);
 		const int s_valid = __shfl(valid ? 1 : 0, src, 64);
-		half8 enc = encode_level_pair(M.grid, M.xgrid, s_lv, lane >> 4, sx, sy, sz);
+		half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, lane >> 4, sx, sy, sz);
 		half_t logit = density_pass(s_w, lane, enc);
 		if (lane < 16 && s_valid) {
 			// optical thickness of the smallest step (level 0, :218); positive floats order like their bit patterns

@@ -339,6 +339,9 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		build_xor_layout(M.levels, d.n_levels, ctx->params.data() + nd + nr, table);
 		NGP_HIP_CHECK(hipMalloc(&ctx->d_xgrid, table.size() * sizeof(uint64_t)));
 		NGP_HIP_CHECK(hipMemcpy(ctx->d_xgrid, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+		if (table.size() * sizeof(uint64_t) > 0x7FFFFFFFull || ng * sizeof(uint16_t) > 0x7FFFFFFFull) throw std::runtime_error("hash grid too large for 31-bit buffer-load offsets");
+		M.xgrid_bytes = (uint32_t)(table.size() * sizeof(uint64_t));
+		M.grid_bytes = (uint32_t)(ng * sizeof(uint16_t));
 	}
 	// weight fragments
 	std::vector<uint16_t> frags((size_t)N_FRAGS_MAX * 64 * 8, 0);

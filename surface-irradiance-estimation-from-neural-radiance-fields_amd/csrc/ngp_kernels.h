@@ -70,6 +70,7 @@ struct ModelParams {
 	uint32_t r2l_identity; // render_aabb_to_local is the identity (the usual case): skip the matrix product
 	uint32_t diag_pow2;    // every component of aabb_diag is a power of two: x / diag == x * (1/diag) bit for bit
 	float aabb_inv_diag[3];
+	uint32_t grid_bytes, xgrid_bytes; // sizes of the two tables (buffer-load descriptors: out-of-range gathers read zeros)
 };
 constexpr uint32_t COARSE_WORDS_PER_MIP = 32 * 32 * 32 / 32;
 
