@@ -27,8 +27,15 @@ WIDTH, HEIGHT = 1920, 1080
 FOV_X = 0.6911  # Blender Lego camera_angle_x
 AZIMUTHS = [0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16 MFMA (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 512.0  # 8 levels x 8 corners x 8 B of hash-grid gathers
 BYTES_PER_RAY = 80.0  # payload/rgba/depth once + frame-buffer scatter
+FLOP_PER_SAMPLE = 20480.0  # both MLPs
+# What binds the fused kernel is the CU's texture-address / vector-L1 path, which is paced by LANE-loads, not bytes
+# (profiles/r2_v3_pmc_l1.json; tools/micro/gather_probe.hip: a CU sustains at most 1.92 scattered lane-loads per clock from its
+# L1 whether a lane asks for 4, 8 or 16 bytes). The kernel's gathers are 8-byte lane-loads, 64 per sample = the 512
+# algorithmic bytes, so that ceiling, in the same unit as the algorithmic figure, is
+GATHER_PEAK_GBS = 1.92 * 8.0 * 256 * 2.4  # lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz = 9437 GB/s
 
 
 def pkg(sub):
@@ -37,7 +44,7 @@ def pkg(sub):
 
 def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
     """The oracle (kind "port": the reference has no CPU path, scripts/run.py:25 hard-imports the CUDA module) on a
-    bounded sample of the same workload: the same camera and model at 1280x720 (4/9 of the pixels)."""
+    bounded sample of the same workload: ONE frame of the same camera and model at 1920x1080, ~30 s on 16 cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -52,7 +59,7 @@ def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
     grid = np.asarray(sc["density_grid"], np.float16).astype(np.float32)
     sc["density_grid_bitfield"], _ = o.density_grid_to_bitfield(grid, sc["max_cascade"])
     m = o.make_model(sc)
-    w, h = WIDTH * 2 // 3, HEIGHT * 2 // 3
+    w, h = WIDTH, HEIGHT
     cam = o.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("NGP_BENCH_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
@@ -61,7 +68,7 @@ def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
     dt = time.perf_counter() - t0
     o.release(m)
     out = {"value": round(w * h / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
-           "sample": f"same model+camera at {w}x{h} (4/9 of the 1080p rays), {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
+           "sample": f"one frame (azimuth {AZIMUTHS[1]:.0f}) of the same model+camera at {w}x{h}, {st['n_samples']} samples, {dt:.1f} s, OpenMP over rays"}
     if gpu_ctx is not None:
         # the metric's "PSNR vs reference": the HIP frame of that camera against the frame the oracle just rendered (the
         # oracle stands in for the reference, PARITY UNPINNED: oracle/orc_common.h); the oracle is the checker here, no more
@@ -77,20 +84,45 @@ def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
     return out
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the fused kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read from inside the process, hence the file."""
+def latest_profile(pattern):
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            return int(json.load(f)["traffic_bytes_per_launch_corrected"])
+            return json.load(f), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
+
+
+def pmc_evidence():
+    """Counter evidence of the fused kernel from the committed rocprofv3 --pmc passes of this same command (counters cannot be
+    read from inside the process, hence the files; tools/profile_round.sh and tools/pmc_l1.sh produce them):
+    HBM-side bytes per launch (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950), issue-slot and matrix-pipe utilisation, texture-address busy fraction, L1 / L2 hit rates."""
+    out = {}
+    hbm, name = latest_profile("r*_pmc_hbm.json")
+    if hbm:
+        out["traffic"] = int(hbm["traffic_bytes_per_launch_corrected"])
+        out["traffic_source"] = "profiles/" + name
+    comp, name = latest_profile("r*_pmc_compute.json")
+    if comp:
+        out["valu_issue_util"] = round(comp["valu_issue_utilisation"], 3)
+        out["mfma_pipe_util"] = round(comp["mfma_pipe_utilisation"], 3)
+        out["issue_source"] = "profiles/" + name
+    l1, name = latest_profile("r*_pmc_l1.json")
+    if l1:
+        cyc = l1["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        out["ta_busy_avg"] = round(l1["TA_BUSY_avr"] / cyc, 3)
+        out["ta_busy_max"] = round(l1["TA_BUSY_max"] / cyc, 3)
+        out["l1_hit_rate"] = round(1.0 - l1["TCP_TCC_READ_REQ_sum"] / l1["TCP_TOTAL_CACHE_ACCESSES_sum"], 3)
+        out["l2_hit_rate"] = round(l1["TCC_HIT_sum"] / (l1["TCC_HIT_sum"] + l1["TCC_MISS_sum"]), 3)
+        lane_loads = l1["TA_FLAT_READ_WAVEFRONTS_sum"] * 64.0
+        out["lane_loads_per_clk_per_cu"] = round(lane_loads / 256.0 / cyc, 3)
+        out["l1_source"] = "profiles/" + name
+    return out
 
 
 def training_probe(native, scene_mod, gt_ctx):
@@ -163,7 +195,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    pkg("build").build()
+    # one process per node links the library (build.py renames a finished file into place); the others wait, then only load it
+    if local_rank == 0:
+        pkg("build").build()
+    if world > 1:
+        dist.barrier()
     native, synthetic, scene_mod, parallel = pkg("native"), pkg("synthetic"), pkg("scene"), pkg("parallel")
     sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)  # identical on every rank (seeded)
     ctx = native.Context(dev_index)
@@ -213,6 +249,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- outside the timed region (N = 1): one frame at a time, for the kernel's own duration and the latency of a single frame
+    # (in the timed region two launches overlap in their drain, so a per-launch HIP-event time there includes the wait for CUs),
+    # and the host-buffer entry point ngp_render (what pyngp's Testbed.render returns: render + device-to-host copy)
+    timed_hist = ctx.render_history(min(args.steps, 256))
+    solo = None
+    if world == 1 and args.steps > 0:
+        n_solo = min(args.steps, 16)
+        rgba, depth = outs[0]
+        for i in range(2):
+            ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(n_solo):
+            ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), streams[0].cuda_stream)
+            torch.cuda.synchronize(dev)
+        solo_dt = (time.perf_counter() - t1) / n_solo
+        sh = ctx.render_history(n_solo)
+        n_host = min(args.steps, 8)
+        ctx.render(cams[0], opts)
+        t1 = time.perf_counter()
+        for i in range(n_host):
+            ctx.render(cams[i % len(cams)], opts)
+        pageable_dt = (time.perf_counter() - t1) / n_host
+        ctx.render_pinned(cams[0], opts)
+        t1 = time.perf_counter()
+        for i in range(n_host):
+            ctx.render_pinned(cams[i % len(cams)], opts)  # a fresh pooled page-locked array per frame, as pyngp's Testbed.render returns
+        host_dt = (time.perf_counter() - t1) / n_host
+        solo = {"frame_s": solo_dt, "kernel_ms": float(np.mean([x["kernel_ms"] for x in sh])), "kernel_device_ms": float(np.mean([x["kernel_device_ms"] for x in sh])),
+                "n_samples": float(np.mean([x["n_samples"] for x in sh])), "n_rays": float(np.mean([x["n_rays"] for x in sh])), "host_s": host_dt, "pageable_s": pageable_dt, "n": n_solo}
+
     # outside the timed region: the frame the ranks assembled must be the frame one GPU renders alone
     gather_diff = None
     if world > 1:
@@ -224,9 +291,8 @@ def main():
             ctx.render_device(cams[last % len(cams)], native.make_opts(), solo_rgba.data_ptr(), solo_depth.data_ptr(), streams[0].cuda_stream)
             torch.cuda.synchronize(dev)
             gather_diff = max(float((img_g - solo_rgba).abs().max().item()), float((depth_g - solo_depth).abs().max().item()))
-    hist_n = min(args.steps, 256) + (1 if gather_diff is not None else 0)
-    hist = ctx.render_history(min(hist_n, 256))[:min(args.steps, 256)]
-    local = np.array([[s["n_rays"], s["n_rays_hit"], s["n_samples"], s["kernel_ms"], s["frame_ms"]] for s in hist], np.float64)
+    hist = timed_hist
+    local = np.array([[s["n_rays"], s["n_rays_hit"], s["n_samples"], s["kernel_ms"], s["frame_ms"], s["kernel_device_ms"]] for s in hist], np.float64)
     if world > 1:
         tl = torch.tensor(local, dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(tl) for _ in range(world)]
@@ -241,12 +307,38 @@ def main():
         value = n_rays / (dt / args.steps) / 1e6
         samples_per_frame = per_rank[:, :, 2].sum(0).mean()
         hits_per_frame = per_rank[:, :, 1].sum(0).mean()
-        # dominant kernel: render_nerf_fused on rank 0 (one launch per step)
-        k_ms = float(per_rank[0, :, 3].mean())
-        k_rays = float(per_rank[0, :, 0].mean())
-        k_samples = float(per_rank[0, :, 2].mean())
+        # dominant kernel: render_nerf_fused on rank 0 (one launch per step). Its duration for the roofline is the HIP-event time
+        # of launches issued one at a time (N = 1); with N > 1 the device-clock duration of the timed region's launches stands in.
+        k_ms_timed = float(per_rank[0, :, 5].mean())  # first wave in .. last wave out on the chip's 100 MHz clock, timed region
+        if solo:
+            k_ms, k_rays, k_samples = solo["kernel_ms"], solo["n_rays"], solo["n_samples"]
+        else:
+            k_ms, k_rays, k_samples = k_ms_timed, float(per_rank[0, :, 0].mean()), float(per_rank[0, :, 2].mean())
         algo_bytes = k_samples * BYTES_PER_SAMPLE + k_rays * BYTES_PER_RAY
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        ev = pmc_evidence()
+        mfma_tflops = k_samples * FLOP_PER_SAMPLE / (k_ms * 1e-3) / 1e12
+        roof = {
+            # the binder by the counters (profiles/): texture-address path ~1.5 lane-loads/clk/CU of a 1.6-1.9 ceiling, busy 53-65 %;
+            # VALU issue slots 67 %; HBM 0.37 of peak by measured traffic; MFMA pipe 12 % -- none saturated, the gather path closest
+            "bound": "ta",
+            "achieved": round(achieved, 2),
+            "peak": round(GATHER_PEAK_GBS, 1),
+            "unit": "GB/s",
+            "frac": round(achieved / GATHER_PEAK_GBS, 5),
+            "traffic": ev.get("traffic"),
+            "kernel": "render_nerf_fused",
+            "kernel_ms": round(k_ms, 4),
+            "kernel_ms_how": ("HIP events around launches issued one at a time (%d frames after the timed region)" % solo["n"]) if solo else "device clock, timed region (launches of consecutive frames overlap)",
+            "kernel_ms_timed_region_device_clock": round(k_ms_timed, 4),
+            "algorithmic_bytes_per_launch": int(algo_bytes),
+            "peak_is": "measured L1 gather ceiling for 8-byte lane-loads (tools/micro/gather_probe.hip): 1.92 lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz",
+            "hbm_algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),  # SURVEY 8(d)'s figure: algorithmic bytes against the 8 TB/s HBM peak
+            "hbm_traffic_frac": round(ev["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ev.get("traffic") else None,
+            "mfma_tflops": round(mfma_tflops, 3),
+            "mfma_frac": round(mfma_tflops / MFMA_PEAK_TFLOPS, 5),
+            "counters": ev,
+        }
         out = {
             "metric": "Mrays/s @1080p NeRF inference (Lego snapshot); PSNR vs reference",
             "value": round(value, 3),
@@ -270,19 +362,14 @@ def main():
                 "tile_sharding": f"8x8 tiles round-robin over {world} rank(s)" + (", all_gather of rgba+depth per frame (RCCL)" if world > 1 else ""),
                 "frames_in_flight": len(streams),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(),
-                "kernel": "render_nerf_fused",
-                "kernel_ms": round(k_ms, 4),
-                "algorithmic_bytes_per_launch": int(algo_bytes),
-                "mfma_tflops": round(k_samples * 20480.0 / (k_ms * 1e-3) / 1e12, 3),
-            },
+            "roofline": roof,
         }
+        if solo:
+            out["single_frame_ms"] = round(solo["frame_s"] * 1e3, 4)          # one frame at a time, image left in HBM
+            out["single_frame_mrays"] = round(n_rays / solo["frame_s"] / 1e6, 2)
+            out["with_host_copy_ms"] = round(solo["host_s"] * 1e3, 4)         # ngp_render: render + copy into a page-locked host array (PCIe-inclusive; never `value`)
+            out["with_host_copy_mrays"] = round(n_rays / solo["host_s"] / 1e6, 2)
+            out["with_host_copy_pageable_mrays"] = round(n_rays / solo["pageable_s"] / 1e6, 2)  # into ordinary (pageable) memory
         if gather_diff is not None:
             out["gathered_frame_max_abs_diff_vs_single_gpu"] = gather_diff  # rank 0's check of the assembled frame, outside the timed region
         if world == 1 and not args.no_cpu_baseline:

@@ -38,9 +38,11 @@ enum ngp_render_mode {
 	NGP_RENDER_AO = 2,        /* rgb = alpha of the sample */
 	NGP_RENDER_POSITIONS = 3, /* rgb = (pos - 0.5) / 2 + 0.5 */
 	NGP_RENDER_DEPTH = 4,     /* rgb = dot(cam_fwd, pos - ray origin) * depth_scale */
-	NGP_RENDER_COST = 5       /* ERenderMode::Cost (shade_kernel_nerf :1382-1384): grey = samples composited on the ray / 128, opaque. The reference's
+	NGP_RENDER_COST = 5,      /* ERenderMode::Cost (shade_kernel_nerf :1382-1384): grey = samples composited on the ray / 128, opaque. The reference's
 	                           * payload.n_steps holds that count for rays that saturate and the last compaction batch's for rays that leave the
 	                           * volume (:466, :730); here it is the ray's total in both cases */
+	NGP_RENDER_SHADE_GRID_ENVMAP = 6 /* ERenderMode::ShadeGridEnvMap, the fork's default (testbed.h:880): meshes lit by the GRID of NeRF-derived
+	                           * irradiance probes (ngp_compute_envmap_grid), position-dependent */
 };
 
 /* ETestbedMode subset (common.h:35-43): Nerf, and the fork's Geometry mode (meshes + NeRF, depth composited) */
@@ -128,6 +130,9 @@ typedef struct ngp_render_stats {
 	uint64_t n_samples;      /* network queries composited */
 	float kernel_ms;         /* duration of the fused march/encode/MLP/composite kernel, HIP events on its stream */
 	float frame_ms;          /* whole frame on the device (clear .. tonemap), HIP events */
+	float kernel_device_ms;  /* the fused kernel from its first wave's start to its last wave's exit, read inside the kernel from the chip's
+	                          * 100 MHz clock (s_memrealtime): unlike the HIP events it does not include the time a launch waits for CUs
+	                          * behind another frame's kernel when frames overlap on several streams */
 } ngp_render_stats;
 
 /* --- lifetime: Testbed::Testbed / ~Testbed (testbed.h:80-95). device = HIP device ordinal; -1 creates a host-only
@@ -179,6 +184,12 @@ NGP_API int ngp_get_dataset_info(const ngp_ctx* ctx, int32_t* aabb_scale, float*
  * Testbed::render_to_cpu (src/python_api.cu:197-201) does. rgba_out: host, H*W*4 floats, premultiplied alpha.
  * depth_out (nullable): host, H*W floats. */
 NGP_API int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out);
+/* Page-locked host memory for images, pooled by size (thread-safe; usable before any context exists). ngp_render copies
+ * into such a buffer with one DMA at the link's rate; into ordinary memory the runtime stages the copy (about 2.5x slower for
+ * a 1080p frame). pyngp's Testbed.render returns arrays that own such buffers. No counterpart in the reference (its
+ * render_to_cpu reads back from a CUDA array, src/python_api.cu:197-201). */
+NGP_API void* ngp_host_alloc(size_t bytes);
+NGP_API void ngp_host_free(void* p);
 /* Same frame, results left in device memory (d_rgba: W*H*4 floats, d_depth nullable: W*H floats) and enqueued on
  * `stream` (a hipStream_t, NULL = default stream) without synchronising: for callers that keep the image on the GPU
  * (RCCL gather of tiles, benchmarks). */
@@ -255,9 +266,31 @@ typedef struct ngp_probe_desc {
 	float min_transmittance;
 } ngp_probe_desc;
 NGP_API int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* desc, float* rgba_out /* nullable: n_theta*n_phi*4 */);
+/* the probe texture(s) and E(n) tabulated at the texel directions; after ngp_compute_envmap_grid: grid_x*grid_y textures back to back */
 NGP_API int ngp_get_envmap(ngp_ctx* ctx, uint32_t* n_theta, uint32_t* n_phi, float* rgba_out, float* irradiance_rgba_out);
-/* E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi/(n_theta n_phi): host normals n x 3 -> host rgb n x 3 */
+/* E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi/(n_theta n_phi), w = the direction the texel's ray travelled (for an
+ * outward probe: -frame(normalize(origin)) * texel direction): host normals n x 3 -> host rgb n x 3. One probe only. */
 NGP_API int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_out);
+
+/* Testbed::computeEnvmapGrid (declared testbed.h:743, called src/main.cu:187-188 when m_render_mode == ShadeGridEnvMap -- the
+ * fork's default, testbed.h:880 -- no body in the reference) with gridSize / m_envmap_tex (testbed.h:949-950). Definition used
+ * here: grid_x x grid_y shell positions c + shell_radius * cylindrical_to_dir_nerf(
+ * (i + .5) / grid_x, (j + .5) / grid_y) around c = render_aabb.center(); at each the K11 fan
+ * (init_rays_from_center_outward_with_payload_kernel_nerf, src/testbed_nerf.cu:1611-1673) of n_theta x n_phi rays, all probes
+ * traced in ONE launch; E_g(n) tabulated per probe. Mesh shading (NGP_RENDER_SHADE_GRID_ENVMAP) and ngp_irradiance_at blend
+ * the four probes around the direction of (surface point - c), each read bilinearly at the normal in the manner of read_envmap
+ * (envmap.cuh:24-50). */
+typedef struct ngp_probe_grid_desc {
+	uint32_t grid_x, grid_y; /* gridSize */
+	uint32_t n_theta, n_phi; /* texels per probe */
+	float shell_radius;
+	float min_transmittance;
+} ngp_probe_grid_desc;
+NGP_API int ngp_compute_envmap_grid(ngp_ctx* ctx, const ngp_probe_grid_desc* desc, float* rgba_out /* nullable: grid_x*grid_y*n_theta*n_phi*4 */);
+/* the grid as computed and its shell positions (nullable: grid_x*grid_y*3) */
+NGP_API int ngp_get_envmap_grid(ngp_ctx* ctx, ngp_probe_grid_desc* desc_out, float* origins_out);
+/* the lookup mesh shading does, at explicit surface points: positions / normals n x 3 -> rgb n x 3 (one probe: position unused) */
+NGP_API int ngp_irradiance_at(ngp_ctx* ctx, uint32_t n, const float* positions, const float* normals, float* rgb_out);
 
 
 /* --- training: Testbed::reset_network (src/testbed.cu:3820-4210), Testbed::train (:4364-4470),

@@ -99,7 +99,12 @@ class MeshOpts(C.Structure):
         ("sheen", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
         ("basecolor", C.c_float * 3), ("ambientcolor", C.c_float * 3),
         ("irradiance", C.c_void_p), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32),
+        ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("probe_center", C.c_float * 3),
     ]
+
+
+class ProbeGridDesc(C.Structure):
+    _fields_ = [("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32), ("shell_radius", C.c_float), ("center", C.c_float * 3)]
 
 
 class ProbeDesc(C.Structure):
@@ -372,6 +377,12 @@ class Oracle:
         L.orc_compute_envmap.argtypes = [C.POINTER(NerfModel), C.POINTER(ProbeDesc), C.POINTER(RenderOpts), C.c_void_p, C.POINTER(RenderStats)]
         L.orc_irradiance.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_texel_direction.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_irradiance_from.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_probe_grid_origin.argtypes = [C.POINTER(ProbeGridDesc), C.c_uint32, C.c_void_p]
+        L.orc_compute_envmap_grid.argtypes = [C.POINTER(NerfModel), C.POINTER(ProbeGridDesc), C.POINTER(RenderOpts), C.c_void_p, C.POINTER(RenderStats)]
+        L.orc_irradiance_grid_tabulate.argtypes = [C.POINTER(ProbeGridDesc), C.c_void_p, C.c_void_p]
+        L.orc_irradiance_read.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_irradiance_grid_lookup.argtypes = [C.POINTER(ProbeGridDesc), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
 
     # ------------------------------------------------------------------ probes (orc_probe.c)
     @staticmethod
@@ -394,11 +405,60 @@ class Oracle:
         self.lib.orc_compute_envmap(C.byref(m), C.byref(desc), C.byref(opts), _ptr(env), C.byref(st))
         return env, {k: getattr(st, k) for k, _ in RenderStats._fields_}
 
-    def irradiance(self, envmap, normals):
+    def irradiance(self, envmap, normals, origin=None):
+        """E(n) of one probe texture; origin = the shell position of an outward (K11) probe, whose texel (a, b) holds the
+        radiance along -frame(normalize(origin)) * texel_direction(a, b)"""
         env = np.ascontiguousarray(envmap, np.float32)
         nrm = np.ascontiguousarray(normals, np.float32)
         out = np.zeros((nrm.shape[0], 3), np.float32)
-        self.lib.orc_irradiance(env.shape[1], env.shape[0], _ptr(env), nrm.shape[0], _ptr(nrm), _ptr(out))
+        org = None if origin is None else np.ascontiguousarray(origin, np.float32)
+        self.lib.orc_irradiance_from(env.shape[1], env.shape[0], _ptr(env), None if org is None else _ptr(org), nrm.shape[0], _ptr(nrm), _ptr(out))
+        return out
+
+    # ---- the grid of probes (Testbed::computeEnvmapGrid / ShadeGridEnvMap: definition in orc_probe.h)
+    @staticmethod
+    def make_probe_grid(grid_x=4, grid_y=4, n_theta=32, n_phi=16, shell_radius=1.0, center=(0.5, 0.5, 0.5)):
+        d = ProbeGridDesc()
+        d.grid_x, d.grid_y, d.n_theta, d.n_phi, d.shell_radius = grid_x, grid_y, n_theta, n_phi, shell_radius
+        for i in range(3):
+            d.center[i] = center[i]
+        return d
+
+    def probe_grid_origins(self, d):
+        out = np.zeros((d.grid_x * d.grid_y, 3), np.float32)
+        tmp = np.zeros(3, np.float32)
+        for g in range(out.shape[0]):
+            self.lib.orc_probe_grid_origin(C.byref(d), g, _ptr(tmp))
+            out[g] = tmp
+        return out
+
+    def compute_envmap_grid(self, m, d, opts=None):
+        """m: the model with render_aabb = the box the probe rays are traced in (in Geometry mode the inflated scene box)"""
+        opts = opts or self.make_opts()
+        env = np.zeros((d.grid_x * d.grid_y, d.n_phi, d.n_theta, 4), np.float32)
+        st = RenderStats()
+        self.lib.orc_compute_envmap_grid(C.byref(m), C.byref(d), C.byref(opts), _ptr(env), C.byref(st))
+        return env, {k: getattr(st, k) for k, _ in RenderStats._fields_}
+
+    def irradiance_grid_tabulate(self, d, envmaps):
+        env = np.ascontiguousarray(envmaps, np.float32)
+        out = np.zeros_like(env)
+        self.lib.orc_irradiance_grid_tabulate(C.byref(d), _ptr(env), _ptr(out))
+        return out
+
+    def irradiance_read(self, table, normal):
+        t = np.ascontiguousarray(table, np.float32)
+        n = np.ascontiguousarray(normal, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.orc_irradiance_read(t.shape[1], t.shape[0], _ptr(t), _ptr(n), _ptr(out))
+        return out
+
+    def irradiance_grid_lookup(self, d, tables, positions, normals):
+        t = np.ascontiguousarray(tables, np.float32)
+        p = np.ascontiguousarray(positions, np.float32)
+        n = np.ascontiguousarray(normals, np.float32)
+        out = np.zeros((p.shape[0], 3), np.float32)
+        self.lib.orc_irradiance_grid_lookup(C.byref(d), _ptr(t), p.shape[0], _ptr(p), _ptr(n), _ptr(out))
         return out
 
     def texel_directions(self, n_theta, n_phi):
@@ -436,13 +496,21 @@ class Oracle:
 
     @staticmethod
     def make_mesh_opts(sun_dir=(1.0, 1.0, 1.0), up_dir=(0.0, 1.0, 0.0), metallic=0.0, subsurface=0.0, specular=1.0, roughness=0.5, sheen=0.0,
-                       clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0), irradiance=None):
+                       clearcoat=0.0, clearcoat_gloss=0.0, basecolor=(0.8, 0.8, 0.8), ambientcolor=(0.0, 0.0, 0.0), irradiance=None, grid=None,
+                       probe_center=(0.5, 0.5, 0.5)):
+        """irradiance: (n_phi, n_theta, 4) table of one probe (ShadeEnvMap) or, with grid = (grid_x, grid_y), the
+        (grid_x * grid_y, n_phi, n_theta, 4) tables of a probe grid (ShadeGridEnvMap)"""
         o = MeshOpts()
         if irradiance is not None:
             irr = np.ascontiguousarray(irradiance, np.float32)
-            assert irr.ndim == 3 and irr.shape[2] == 4
+            assert irr.shape[-1] == 4 and irr.ndim == (4 if grid else 3)
             o._keep = irr
-            o.irradiance, o.n_theta, o.n_phi = irr.ctypes.data, irr.shape[1], irr.shape[0]
+            o.irradiance, o.n_theta, o.n_phi = irr.ctypes.data, irr.shape[-2], irr.shape[-3]
+            if grid:
+                assert irr.shape[0] == grid[0] * grid[1]
+                o.grid_x, o.grid_y = grid
+                for i in range(3):
+                    o.probe_center[i] = probe_center[i]
         for i in range(3):
             o.sun_dir[i], o.up_dir[i], o.basecolor[i], o.ambientcolor[i] = sun_dir[i], up_dir[i], basecolor[i], ambientcolor[i]
         o.metallic, o.subsurface, o.specular, o.roughness = metallic, subsurface, specular, roughness

@@ -8,6 +8,7 @@
 #include "oracle.h"
 #include "orc_common.h"
 #include "orc_mesh.h"
+#include "orc_probe.h"
 
 #include <stdio.h>
 
@@ -401,14 +402,15 @@ void orc_render_mesh(const orc_mesh_scene* s, const orc_camera* cam, const orc_m
 		v3 skycol = v3_scale(v3_scale(v3_make(195.f / 255.0f, 215.f / 255.0f, 255.f / 255.0f), 4.f), skyam);
 		v3 base = v3_make(o->basecolor[0], o->basecolor[1], o->basecolor[2]);
 		v3 ambc = v3_mul(v3_make(o->ambientcolor[0], o->ambientcolor[1], o->ambientcolor[2]), skycol);
-		if (o->irradiance) { /* inverse of cylindrical_to_dir_nerf: u = (1 - z)/2, v = atan2(y,x)/(2 pi) + 0.5 */
-			float uu = (1.0f - N.z) * 0.5f;
-			float vv = atan2f(N.y, N.x) / (2.0f * PI_F) + 0.5f;
-			int ti = (int)floorf(uu * (float)o->n_theta);
-			int tj = (int)floorf(vv * (float)o->n_phi);
-			ti = ti < 0 ? 0 : (ti >= (int)o->n_theta ? (int)o->n_theta - 1 : ti);
-			tj = ((tj % (int)o->n_phi) + (int)o->n_phi) % (int)o->n_phi;
-			const float* E = o->irradiance + 4 * ((size_t)ti + (size_t)o->n_theta * tj);
+		if (o->irradiance) {
+			float E[3], n3[3] = {N.x, N.y, N.z};
+			if (o->grid_x) {
+				orc_probe_grid_desc gd = {o->grid_x, o->grid_y, o->n_theta, o->n_phi, 0.0f, {o->probe_center[0], o->probe_center[1], o->probe_center[2]}};
+				float p3[3] = {pos.x, pos.y, pos.z};
+				orc_irradiance_grid_lookup(&gd, o->irradiance, 1, p3, n3, E);
+			} else {
+				orc_irradiance_read(o->n_theta, o->n_phi, o->irradiance, n3, E);
+			}
 			ambc = v3_make(E[0] / PI_F, E[1] / PI_F, E[2] / PI_F);
 		}
 		v3 color = evaluate_shading(v3_mul(base, base), ambc, suncol, o->metallic, o->subsurface, o->specular, o->roughness, 0.f,

@@ -15,10 +15,14 @@ typedef struct orc_mesh_opts { /* BRDFParams (common.h:167-177) + m_sun_dir, m_u
 	float sun_dir[3], up_dir[3];
 	float metallic, subsurface, specular, roughness, sheen, clearcoat, clearcoat_gloss;
 	float basecolor[3], ambientcolor[3];
-	/* ShadeEnvMap: ambient light = E(N)/pi looked up (nearest texel) in an irradiance map tabulated at the probe
-	 * texture's texel directions (n_theta*n_phi*4 floats); NULL = Shade mode (sky ambient) */
+	/* ShadeEnvMap: ambient light = E(N)/pi read bilinearly (orc_irradiance_read) from an irradiance map tabulated at the
+	 * probe texture's texel directions (n_theta*n_phi*4 floats); NULL = Shade mode (sky ambient).
+	 * ShadeGridEnvMap (grid_x > 0): `irradiance` holds grid_x*grid_y such maps and the light at a surface point comes
+	 * from the probes around the direction of (point - probe_center): orc_irradiance_grid_lookup */
 	const float* irradiance;
 	uint32_t n_theta, n_phi;
+	uint32_t grid_x, grid_y;
+	float probe_center[3];
 } orc_mesh_opts;
 
 /* triangles are reordered in place */

@@ -763,7 +763,7 @@ static void shade_one(const orc_render_opts* o, const float* rgba, float depth, 
 		tmp[0] = tmp[1] = tmp[2] = (float)n_steps / 128.0f;
 		tmp[3] = 1.0f;
 	}
-	if (!o->train_in_linear_colors && o->render_mode <= 1) { /* only ERenderMode::Shade converts, :1393 */
+	if (!o->train_in_linear_colors && o->render_mode == 0) { /* only ERenderMode::Shade converts (:1393): 1 = ShadeEnvMap / ShadeGridEnvMap keep the network's sRGB values */
 		tmp[0] = orc_srgb_to_linear(tmp[0]);
 		tmp[1] = orc_srgb_to_linear(tmp[1]);
 		tmp[2] = orc_srgb_to_linear(tmp[2]);

@@ -120,8 +120,10 @@ void orc_texel_direction(uint32_t n_theta, uint32_t n_phi, uint32_t i, uint32_t 
 	out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
 }
 
-void orc_irradiance(uint32_t n_theta, uint32_t n_phi, const float* envmap, uint32_t n, const float* normals, float* out_rgb) {
+void orc_irradiance_from(uint32_t n_theta, uint32_t n_phi, const float* envmap, const float* origin3, uint32_t n, const float* normals, float* out_rgb) {
 	const double d_omega = 4.0 * 3.14159265358979323846 / ((double)n_theta * (double)n_phi);
+	float frame[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	if (origin3) compute_local_frame(v3_normalize(v3_make(origin3[0], origin3[1], origin3[2])), frame);
 #pragma omp parallel for schedule(static)
 	for (int64_t q = 0; q < (int64_t)n; ++q) {
 		double acc[3] = {0, 0, 0};
@@ -129,6 +131,7 @@ void orc_irradiance(uint32_t n_theta, uint32_t n_phi, const float* envmap, uint3
 		for (uint32_t j = 0; j < n_phi; ++j) {
 			for (uint32_t i = 0; i < n_theta; ++i) {
 				v3 w = cylindrical_to_dir_nerf((float)i / (float)n_theta, (float)j / (float)n_phi);
+				if (origin3) w = v3_scale(v3_normalize(m3_mulv(frame, w)), -1.0f); /* the K11 ray of this texel */
 				float c = v3_dot(nrm, w);
 				if (!(c > 0.0f)) continue;
 				const float* L = envmap + 4 * ((size_t)i + (size_t)n_theta * j);
@@ -138,5 +141,106 @@ void orc_irradiance(uint32_t n_theta, uint32_t n_phi, const float* envmap, uint3
 		out_rgb[3 * q] = (float)(acc[0] * d_omega);
 		out_rgb[3 * q + 1] = (float)(acc[1] * d_omega);
 		out_rgb[3 * q + 2] = (float)(acc[2] * d_omega);
+	}
+}
+void orc_irradiance(uint32_t n_theta, uint32_t n_phi, const float* envmap, uint32_t n, const float* normals, float* out_rgb) {
+	orc_irradiance_from(n_theta, n_phi, envmap, NULL, n, normals, out_rgb);
+}
+
+/* ---------------------------------------------------------------------------------------------- the grid of probes */
+void orc_probe_grid_origin(const orc_probe_grid_desc* d, uint32_t g, float* out3) {
+	v3 center = v3_make(d->center[0], d->center[1], d->center[2]);
+	const uint32_t i = g % d->grid_x, j = g / d->grid_x;
+	v3 dir = cylindrical_to_dir_nerf(((float)i + 0.5f) / (float)d->grid_x, ((float)j + 0.5f) / (float)d->grid_y);
+	v3 p = v3_add(center, v3_scale(dir, d->shell_radius));
+	out3[0] = p.x; out3[1] = p.y; out3[2] = p.z;
+}
+
+void orc_compute_envmap_grid(const orc_nerf_model* m, const orc_probe_grid_desc* d, const orc_render_opts* o, float* envmaps, orc_render_stats* stats) {
+	const uint32_t n_probes = d->grid_x * d->grid_y;
+	const size_t texels = (size_t)d->n_theta * d->n_phi;
+	orc_render_stats total = {0, 0, 0, 0};
+	for (uint32_t g = 0; g < n_probes; ++g) {
+		orc_probe_desc pd;
+		pd.mode = ORC_PROBE_CENTER_OUTWARD;
+		pd.n_theta = d->n_theta; pd.n_phi = d->n_phi; pd.n_origin = 1;
+		orc_probe_grid_origin(d, g, pd.origin);
+		orc_render_stats st;
+		orc_compute_envmap(m, &pd, o, envmaps + 4 * texels * g, &st);
+		total.n_rays += st.n_rays; total.n_rays_alive_after_init += st.n_rays_alive_after_init;
+		total.n_rays_hit += st.n_rays_hit; total.n_samples += st.n_samples;
+	}
+	if (stats) *stats = total;
+}
+
+void orc_irradiance_grid_tabulate(const orc_probe_grid_desc* d, const float* envmaps, float* tables) {
+	const uint32_t n_probes = d->grid_x * d->grid_y, texels = d->n_theta * d->n_phi;
+	float* normals = (float*)malloc(sizeof(float) * 3 * texels);
+	float* rgb = (float*)malloc(sizeof(float) * 3 * texels);
+	for (uint32_t t = 0; t < texels; ++t) orc_texel_direction(d->n_theta, d->n_phi, t % d->n_theta, t / d->n_theta, normals + 3 * t);
+	for (uint32_t g = 0; g < n_probes; ++g) {
+		float origin[3];
+		orc_probe_grid_origin(d, g, origin);
+		orc_irradiance_from(d->n_theta, d->n_phi, envmaps + 4 * (size_t)texels * g, origin, texels, normals, rgb);
+		float* out = tables + 4 * (size_t)texels * g;
+		for (uint32_t t = 0; t < texels; ++t) { out[4 * t] = rgb[3 * t]; out[4 * t + 1] = rgb[3 * t + 1]; out[4 * t + 2] = rgb[3 * t + 2]; out[4 * t + 3] = 0.f; }
+	}
+	free(normals); free(rgb);
+}
+
+/* inverse of cylindrical_to_dir_nerf: px = (1 - z) / 2, py = atan2(y, x) / (2 pi) + 0.5 */
+static void dir_to_cylindrical(v3 n, float* px, float* py) {
+	*px = (1.0f - n.z) * 0.5f;
+	*py = atan2f(n.y, n.x) / (2.0f * PI_F) + 0.5f;
+}
+/* cell + weight of a coordinate on an axis of `n` samples sitting at (k + offset) / n: clamped (theta) or periodic (phi) */
+static void axis_cell(float coord01, uint32_t n, float offset, int periodic, uint32_t* k0, uint32_t* k1, float* w) {
+	float f = coord01 * (float)n - offset;
+	float fl = floorf(f);
+	int i0 = (int)fl, i1 = i0 + 1;
+	*w = f - fl;
+	if (periodic) {
+		i0 = ((i0 % (int)n) + (int)n) % (int)n;
+		i1 = ((i1 % (int)n) + (int)n) % (int)n;
+	} else {
+		if (i0 < 0) { i0 = 0; *w = 0.0f; }
+		if (i1 > (int)n - 1) i1 = (int)n - 1;
+		if (i0 > (int)n - 1) i0 = (int)n - 1;
+	}
+	*k0 = (uint32_t)i0; *k1 = (uint32_t)i1;
+}
+
+void orc_irradiance_read(uint32_t n_theta, uint32_t n_phi, const float* table, const float* n3, float* out_rgb) {
+	float px, py, wa, wb;
+	uint32_t a0, a1, b0, b1;
+	dir_to_cylindrical(v3_make(n3[0], n3[1], n3[2]), &px, &py);
+	axis_cell(px, n_theta, 0.0f, 0, &a0, &a1, &wa); /* texel a sits at a / n_theta */
+	axis_cell(py, n_phi, 0.0f, 1, &b0, &b1, &wb);
+	const float* t00 = table + 4 * ((size_t)a0 + (size_t)n_theta * b0);
+	const float* t10 = table + 4 * ((size_t)a1 + (size_t)n_theta * b0);
+	const float* t01 = table + 4 * ((size_t)a0 + (size_t)n_theta * b1);
+	const float* t11 = table + 4 * ((size_t)a1 + (size_t)n_theta * b1);
+	for (int k = 0; k < 3; ++k)
+		out_rgb[k] = (((1.0f - wa) * (1.0f - wb)) * t00[k] + (wa * (1.0f - wb)) * t10[k]) + (((1.0f - wa) * wb) * t01[k] + (wa * wb) * t11[k]);
+}
+
+void orc_irradiance_grid_lookup(const orc_probe_grid_desc* d, const float* tables, uint32_t n, const float* positions, const float* normals, float* out_rgb) {
+	const size_t texels = (size_t)d->n_theta * d->n_phi;
+	for (uint32_t q = 0; q < n; ++q) {
+		v3 rel = v3_sub(v3_make(positions[3 * q], positions[3 * q + 1], positions[3 * q + 2]), v3_make(d->center[0], d->center[1], d->center[2]));
+		float len = v3_length(rel);
+		v3 dir = len > 0.0f ? v3_divs(rel, len) : v3_make(0.f, 0.f, 1.f);
+		float px, py, wi, wj;
+		uint32_t i0, i1, j0, j1;
+		dir_to_cylindrical(dir, &px, &py);
+		axis_cell(px, d->grid_x, 0.5f, 0, &i0, &i1, &wi); /* probe (i, j) sits at ((i + 0.5) / grid_x, (j + 0.5) / grid_y) */
+		axis_cell(py, d->grid_y, 0.5f, 1, &j0, &j1, &wj);
+		float e00[3], e10[3], e01[3], e11[3];
+		orc_irradiance_read(d->n_theta, d->n_phi, tables + 4 * texels * (i0 + (size_t)d->grid_x * j0), normals + 3 * q, e00);
+		orc_irradiance_read(d->n_theta, d->n_phi, tables + 4 * texels * (i1 + (size_t)d->grid_x * j0), normals + 3 * q, e10);
+		orc_irradiance_read(d->n_theta, d->n_phi, tables + 4 * texels * (i0 + (size_t)d->grid_x * j1), normals + 3 * q, e01);
+		orc_irradiance_read(d->n_theta, d->n_phi, tables + 4 * texels * (i1 + (size_t)d->grid_x * j1), normals + 3 * q, e11);
+		for (int k = 0; k < 3; ++k)
+			out_rgb[3 * q + k] = (((1.0f - wi) * (1.0f - wj)) * e00[k] + (wi * (1.0f - wj)) * e10[k]) + (((1.0f - wi) * wj) * e01[k] + (wi * wj) * e11[k]);
 	}
 }

@@ -168,6 +168,64 @@ NGP_DEV f3 evaluate_shading(f3 base_color, f3 ambient_color, f3 light_color, flo
 	return add3(scale3(mul3(brdf, light_color), NdotL), amb);
 }
 
+// ---- NeRF-derived irradiance (definitions: include/ngp_hip.h, ngp_compute_envmap_grid). The lookups keep one fixed
+// expression order.
+// cell + weight of a coordinate on an axis of n samples sitting at (k + offset) / n: clamped (theta) or periodic (phi)
+NGP_DEV void axis_cell(float coord01, uint32_t n, float offset, bool periodic, uint32_t& k0, uint32_t& k1, float& w) {
+	float f = coord01 * (float)n - offset;
+	float fl = __builtin_floorf(f);
+	int i0 = (int)fl, i1 = i0 + 1;
+	w = f - fl;
+	if (periodic) {
+		i0 = ((i0 % (int)n) + (int)n) % (int)n;
+		i1 = ((i1 % (int)n) + (int)n) % (int)n;
+	} else {
+		if (i0 < 0) { i0 = 0; w = 0.0f; }
+		if (i1 > (int)n - 1) i1 = (int)n - 1;
+		if (i0 > (int)n - 1) i0 = (int)n - 1;
+	}
+	k0 = (uint32_t)i0; k1 = (uint32_t)i1;
+}
+// inverse of cylindrical_to_dir_nerf (src/testbed_nerf.cu:1546-1557): px = (1 - z) / 2, py = atan2(y, x) / (2 pi) + 0.5
+NGP_DEV void dir_to_cylindrical(f3 n, float& px, float& py) {
+	px = (1.0f - n.z) * 0.5f;
+	py = atan2f(n.y, n.x) / (2.0f * PI_F) + 0.5f;
+}
+// bilinear read of one tabulated irradiance map at direction n, in the manner of read_envmap (envmap.cuh:24-50): the
+// four texels around the direction, theta clamped, phi periodic
+NGP_DEV f3 irradiance_read(const float4* __restrict__ table, uint32_t n_theta, uint32_t n_phi, f3 n) {
+	float px, py, wa, wb;
+	uint32_t a0, a1, b0, b1;
+	dir_to_cylindrical(n, px, py);
+	axis_cell(px, n_theta, 0.0f, false, a0, a1, wa);
+	axis_cell(py, n_phi, 0.0f, true, b0, b1, wb);
+	const float4 t00 = table[(size_t)a0 + (size_t)n_theta * b0], t10 = table[(size_t)a1 + (size_t)n_theta * b0];
+	const float4 t01 = table[(size_t)a0 + (size_t)n_theta * b1], t11 = table[(size_t)a1 + (size_t)n_theta * b1];
+	const float w00 = (1.0f - wa) * (1.0f - wb), w10 = wa * (1.0f - wb), w01 = (1.0f - wa) * wb, w11 = wa * wb;
+	return mk3((w00 * t00.x + w10 * t10.x) + (w01 * t01.x + w11 * t11.x), (w00 * t00.y + w10 * t10.y) + (w01 * t01.y + w11 * t11.y),
+	           (w00 * t00.z + w10 * t10.z) + (w01 * t01.z + w11 * t11.z));
+}
+// one probe (ShadeEnvMap), or the four probes of the grid around the direction of pos - center (ShadeGridEnvMap)
+NGP_DEV f3 irradiance_lookup(const IrradianceMap& I, f3 pos, f3 N) {
+	if (I.grid_x == 0u) return irradiance_read(I.irradiance, I.n_theta, I.n_phi, N);
+	const size_t texels = (size_t)I.n_theta * I.n_phi;
+	f3 rel = sub3(pos, mk3(I.center[0], I.center[1], I.center[2]));
+	float len = __builtin_sqrtf(dot3(rel, rel));
+	f3 dir = len > 0.0f ? mk3(rel.x / len, rel.y / len, rel.z / len) : mk3(0.f, 0.f, 1.f);
+	float px, py, wi, wj;
+	uint32_t i0, i1, j0, j1;
+	dir_to_cylindrical(dir, px, py);
+	axis_cell(px, I.grid_x, 0.5f, false, i0, i1, wi);
+	axis_cell(py, I.grid_y, 0.5f, true, j0, j1, wj);
+	const f3 e00 = irradiance_read(I.irradiance + texels * (i0 + (size_t)I.grid_x * j0), I.n_theta, I.n_phi, N);
+	const f3 e10 = irradiance_read(I.irradiance + texels * (i1 + (size_t)I.grid_x * j0), I.n_theta, I.n_phi, N);
+	const f3 e01 = irradiance_read(I.irradiance + texels * (i0 + (size_t)I.grid_x * j1), I.n_theta, I.n_phi, N);
+	const f3 e11 = irradiance_read(I.irradiance + texels * (i1 + (size_t)I.grid_x * j1), I.n_theta, I.n_phi, N);
+	const float w00 = (1.0f - wi) * (1.0f - wj), w10 = wi * (1.0f - wj), w01 = (1.0f - wi) * wj, w11 = wi * wj;
+	return mk3((w00 * e00.x + w10 * e10.x) + (w01 * e01.x + w11 * e11.x), (w00 * e00.y + w10 * e10.y) + (w01 * e01.y + w11 * e11.y),
+	           (w00 * e00.z + w10 * e10.z) + (w01 * e01.z + w11 * e11.z));
+}
+
 // render_geometry_mesh (src/testbed_geometry_training.cu:2202-2320), Shade mode, floor disabled, one thread per pixel
 __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams P, const IrradianceMap I, const CameraParams C, float4* __restrict__ frame_buffer,
                                   float* __restrict__ depth_buffer, uint32_t shard_index, uint32_t shard_count, int packed) {
@@ -230,14 +288,8 @@ __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams
 	f3 skycol = scale3(scale3(mk3(195.f / 255.0f, 215.f / 255.0f, 255.f / 255.0f), 4.f), skyam);
 	f3 base = ld3(P.basecolor);
 	f3 ambc = mul3(ld3(P.ambientcolor), skycol);
-	if (I.irradiance) { // ShadeEnvMap: ambient light = E(N)/pi from the NeRF-derived irradiance map (nearest texel)
-		float uu = (1.0f - N.z) * 0.5f;
-		float vv = atan2f(N.y, N.x) / (2.0f * PI_F) + 0.5f;
-		int ti = (int)__builtin_floorf(uu * (float)I.n_theta);
-		int tj = (int)__builtin_floorf(vv * (float)I.n_phi);
-		ti = ti < 0 ? 0 : (ti >= (int)I.n_theta ? (int)I.n_theta - 1 : ti);
-		tj = ((tj % (int)I.n_phi) + (int)I.n_phi) % (int)I.n_phi;
-		float4 E = I.irradiance[(size_t)ti + (size_t)I.n_theta * tj];
+	if (I.irradiance) { // ShadeEnvMap / ShadeGridEnvMap: ambient light = E(N)/pi from the NeRF-derived irradiance table(s)
+		f3 E = irradiance_lookup(I, pos, N);
 		ambc = mk3(E.x / PI_F, E.y / PI_F, E.z / PI_F);
 	}
 	f3 color = evaluate_shading(mul3(base, base), ambc, suncol, P.metallic, P.subsurface, P.specular, P.roughness, 0.f, P.sheen,
@@ -261,6 +313,16 @@ void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, cons
 	dim3 threads(16, 8, 1);
 	dim3 blocks((C.width + 15) / 16, (C.height + 7) / 8, 1);
 	hipLaunchKernelGGL(render_mesh_fused, blocks, threads, 0, stream, S, P, I, C, frame_buffer, depth_buffer, shard_index, shard_count, packed);
+}
+// stage kernel: the irradiance lookup at explicit surface points (ngp_irradiance_at)
+__global__ void irradiance_lookup_kernel(const IrradianceMap I, uint32_t n, const float* __restrict__ positions, const float* __restrict__ normals, float4* __restrict__ out) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	f3 E = irradiance_lookup(I, ld3(positions + 3 * (size_t)i), ld3(normals + 3 * (size_t)i));
+	out[i] = make_float4(E.x, E.y, E.z, 0.f);
+}
+void launch_irradiance_lookup(const IrradianceMap& I, uint32_t n, const float* positions, const float* normals, float4* out, hipStream_t stream) {
+	if (n) hipLaunchKernelGGL(irradiance_lookup_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, I, n, positions, normals, out);
 }
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream) {
 	hipLaunchKernelGGL(trace_mesh_rays_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, S, n, positions, directions);

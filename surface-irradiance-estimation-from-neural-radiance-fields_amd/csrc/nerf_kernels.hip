@@ -73,7 +73,7 @@ NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear,
 		r = g = b = (float)n_steps / 128.0f;
 		a = 1.0f;
 	}
-	if (!F.linear_colors && (PROBE || F.render_mode <= 1)) { // only ERenderMode::Shade accumulates in linear colours (:1393)
+	if (!F.linear_colors && (PROBE || F.render_mode == 0)) { // only ERenderMode::Shade accumulates in linear colours (:1393) -- ShadeEnvMap / ShadeGridEnvMap, the fork's additions, do not
 		r = srgb_to_linear(r);
 		g = srgb_to_linear(g);
 		b = srgb_to_linear(b);
@@ -115,30 +115,45 @@ NGP_DEV f3 cylindrical_to_dir_nerf(float px, float py) { // src/testbed_nerf.cu:
 	const float sin_theta = __builtin_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
 	return mk3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
 }
+// compute_local_frame (random_val.cuh:167-186), column-major: columns (localX, localY, localZ = n)
+NGP_DEV void local_frame(f3 n, float* frame) {
+	float sz = (n.z >= 0) ? 1.0f : -1.0f;
+	float a = 1 / (sz + n.z);
+	float ya = n.y * a;
+	float b = n.x * ya;
+	float c = n.x * sz;
+	frame[0] = c * n.x * a - 1; frame[1] = sz * b; frame[2] = c;
+	frame[3] = b; frame[4] = n.y * ya - sz; frame[5] = n.y;
+	frame[6] = n.x; frame[7] = n.y; frame[8] = n.z;
+}
+// shell position of probe g of the grid (Testbed::computeEnvmapGrid; definition: include/ngp_hip.h, ngp_compute_envmap_grid)
+NGP_DEV f3 probe_grid_origin(const float* center, uint32_t grid_x, uint32_t grid_y, float shell_radius, uint32_t g) {
+	const uint32_t i = g % grid_x, j = g / grid_x;
+	f3 dir = cylindrical_to_dir_nerf(((float)i + 0.5f) / (float)grid_x, ((float)j + 0.5f) / (float)grid_y);
+	return add3(mk3(center[0], center[1], center[2]), scale3(dir, shell_radius));
+}
 NGP_DEV void init_probe_ray(const ProbeParams& P, uint32_t q, RayState& r) {
 	const uint32_t no = P.mode == 2 ? P.n_origin : 1u;
 	const uint32_t w = P.n_theta * no;
-	uint32_t tm = q % w, pm = q / w;
+	const uint32_t per_probe = P.n_theta * P.n_phi * no * no;
+	const uint32_t g = P.mode == 3 ? q / per_probe : 0u, ql = P.mode == 3 ? q % per_probe : q;
+	uint32_t tm = ql % w, pm = ql / w;
 	uint32_t theta_mul = tm / no, theta_rem = tm % no, phi_mul = pm / no, phi_rem = pm % no;
 	f3 local = cylindrical_to_dir_nerf((float)theta_mul / (float)P.n_theta, (float)phi_mul / (float)P.n_phi);
 	f3 origin = mk3(P.center[0], P.center[1], P.center[2]);
 	f3 dir = local;
-	if (P.mode == 1) {
-		origin = mk3(P.origin[0], P.origin[1], P.origin[2]);
-		f3 n = normalize3(origin); // compute_local_frame, random_val.cuh:167-186
-		float sz = (n.z >= 0) ? 1.0f : -1.0f;
-		float a = 1 / (sz + n.z);
-		float ya = n.y * a;
-		float b = n.x * ya;
-		float c = n.x * sz;
-		float frame[9] = {c * n.x * a - 1, sz * b, c, b, n.y * ya - sz, n.y, n.x, n.y, n.z};
+	const bool outward = P.mode == 1 || P.mode == 3;
+	if (outward) {
+		origin = P.mode == 3 ? probe_grid_origin(P.center, P.grid_x, P.grid_y, P.shell_radius, g) : mk3(P.origin[0], P.origin[1], P.origin[2]);
+		float frame[9];
+		local_frame(normalize3(origin), frame);
 		dir = m3_mulv(frame, local);
 	} else if (P.mode == 2) {
 		uint32_t hi = theta_rem * no + phi_rem;
 		origin = add3(origin, mk3(halton(2, hi) - 0.5f, halton(3, hi) - 0.5f, halton(5, hi) - 0.5f));
 	}
 	dir = normalize3(dir);
-	if (P.mode == 1) dir = scale3(dir, -1.0f);
+	if (outward) dir = scale3(dir, -1.0f);
 	r.o = origin;
 	r.d = dir;
 	r.t = 0.0f;
@@ -184,6 +199,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 	const int lane = threadIdx.x & 63;
 	const int c = lane & 15;
+	if (lane == 0 && (threadIdx.x >> 6) == 0) atomicMax(&F.results[4], ~realtime()); // start stamp (one per workgroup): max of the complements = the earliest
 	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
 	// direct output: the background's trip through the tonemap is the same for every pixel
@@ -604,11 +620,27 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		atomicAdd(&F.prof[16 + bucket], 1ull);
 	}
 
-	// ---- counters (one atomic per wave and counter)
+	// ---- counters (one atomic per wave and counter). The last wave to leave moves the launch's totals to the slot the host
+	// reads and hands the accumulators, the tile queue and the exit count back as zeros: the slot's next launch needs no
+	// memset (a dependent dispatch per frame behind a persistent kernel). Everything goes through device-scope atomics,
+	// which execute at the memory side -- no cache holds a stale copy; the release orders this wave's adds before its exit.
 	if (lane == 0) {
 		atomicAdd(&F.counters[0], (unsigned long long)n_alive_init);
 		atomicAdd(&F.counters[1], (unsigned long long)n_hit);
 		atomicAdd(&F.counters[2], (unsigned long long)n_samples);
+		const uint32_t left = __hip_atomic_fetch_add(F.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (left + 1u == F.n_waves) {
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				const unsigned long long total = atomicExch(&F.counters[k], 0ull);
+				F.results[k] = F.add_results ? F.results[k] + total : total;
+			}
+			// the launch on the chip's 100 MHz clock: first wave in (min over the waves' start stamps) to last wave out
+			const unsigned long long t_start = ~atomicExch(&F.results[4], 0ull), ticks = realtime() - t_start;
+			F.results[3] = F.add_results ? F.results[3] + ticks : ticks;
+			atomicExch(F.queue, 0u);
+			atomicExch(F.done, 0u);
+		}
 	}
 }
 
@@ -647,10 +679,15 @@ __global__ __launch_bounds__(BLOCK, 2) void trace_probe_fused(const ModelParams 
 	fused_body<true>(M, C, F, P);
 }
 
-// probe texture: texel = mean of its rays' shaded RGBA, summed in increasing ray index
+// probe texture: texel = mean of its rays' shaded RGBA, summed in increasing ray index (mode 3: one texture per probe of the grid)
 __global__ void probe_reduce_kernel(const ProbeParams P, float4* __restrict__ envmap) {
 	uint32_t texel = blockIdx.x * blockDim.x + threadIdx.x;
-	if (texel >= P.n_theta * P.n_phi) return;
+	const uint32_t per_probe = P.n_theta * P.n_phi, n_probes = P.mode == 3 ? P.grid_x * P.grid_y : 1u;
+	if (texel >= per_probe * n_probes) return;
+	if (P.mode == 3) { // one ray per texel
+		envmap[texel] = P.ray_rgba[texel];
+		return;
+	}
 	const uint32_t no = P.mode == 2 ? P.n_origin : 1u;
 	uint32_t i = texel % P.n_theta, j = texel / P.n_theta;
 	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -664,18 +701,39 @@ __global__ void probe_reduce_kernel(const ProbeParams P, float4* __restrict__ en
 	envmap[texel] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
-// E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi / (n_theta n_phi); one block per query normal
-__global__ void irradiance_kernel(uint32_t n_theta, uint32_t n_phi, const float4* __restrict__ envmap, uint32_t n, const float* __restrict__ normals,
-                                  int normals_are_texels, float4* __restrict__ out) {
+// E(n) = sum_texels L(w) max(0, n.w) dOmega, dOmega = 4 pi / (n_theta n_phi), w = the direction the texel's ray travelled:
+// the texel direction for the centre fans, -frame(normalize(origin)) * texel direction for an outward (K11) probe.
+// One block per query; queries are explicit normals (one probe) or every texel direction of every probe (tabulation).
+struct IrradianceQuery {
+	uint32_t n_theta, n_phi;
+	const float4* envmap;  // n_probes textures
+	uint32_t n;            // queries
+	const float* normals;  // n x 3, or nullptr: query q = texel q % (n_theta n_phi) of probe q / (n_theta n_phi)
+	int32_t outward;       // 0: centre fans; 1: one outward probe at origin; 3: the grid
+	float origin[3], center[3];
+	uint32_t grid_x, grid_y;
+	float shell_radius;
+	float4* out;
+};
+__global__ void irradiance_kernel(const IrradianceQuery Q) {
 	__shared__ double s[3][256];
 	const uint32_t q = blockIdx.x;
-	if (q >= n) return;
+	if (q >= Q.n) return;
+	const uint32_t texels = Q.n_theta * Q.n_phi;
+	const uint32_t probe = Q.normals ? 0u : q / texels;
 	f3 nrm;
-	if (normals_are_texels) nrm = cylindrical_to_dir_nerf((float)(q % n_theta) / (float)n_theta, (float)(q / n_theta) / (float)n_phi);
-	else nrm = mk3(normals[3 * (size_t)q], normals[3 * (size_t)q + 1], normals[3 * (size_t)q + 2]);
+	if (!Q.normals) nrm = cylindrical_to_dir_nerf((float)((q % texels) % Q.n_theta) / (float)Q.n_theta, (float)((q % texels) / Q.n_theta) / (float)Q.n_phi);
+	else nrm = mk3(Q.normals[3 * (size_t)q], Q.normals[3 * (size_t)q + 1], Q.normals[3 * (size_t)q + 2]);
+	float frame[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	if (Q.outward) {
+		const f3 origin = Q.outward == 3 ? probe_grid_origin(Q.center, Q.grid_x, Q.grid_y, Q.shell_radius, probe) : mk3(Q.origin[0], Q.origin[1], Q.origin[2]);
+		local_frame(normalize3(origin), frame);
+	}
+	const float4* envmap = Q.envmap + (size_t)texels * probe;
 	double a0 = 0, a1 = 0, a2 = 0;
-	for (uint32_t t = threadIdx.x; t < n_theta * n_phi; t += blockDim.x) {
-		f3 w = cylindrical_to_dir_nerf((float)(t % n_theta) / (float)n_theta, (float)(t / n_theta) / (float)n_phi);
+	for (uint32_t t = threadIdx.x; t < texels; t += blockDim.x) {
+		f3 w = cylindrical_to_dir_nerf((float)(t % Q.n_theta) / (float)Q.n_theta, (float)(t / Q.n_theta) / (float)Q.n_phi);
+		if (Q.outward) w = scale3(normalize3(m3_mulv(frame, w)), -1.0f);
 		float c = dot3(nrm, w);
 		if (c > 0.0f) {
 			float4 L = envmap[t];
@@ -693,8 +751,8 @@ __global__ void irradiance_kernel(uint32_t n_theta, uint32_t n_phi, const float4
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
-		const double d_omega = 4.0 * 3.14159265358979323846 / ((double)n_theta * (double)n_phi);
-		out[q] = make_float4((float)(s[0][0] * d_omega), (float)(s[1][0] * d_omega), (float)(s[2][0] * d_omega), 0.f);
+		const double d_omega = 4.0 * 3.14159265358979323846 / ((double)Q.n_theta * (double)Q.n_phi);
+		Q.out[q] = make_float4((float)(s[0][0] * d_omega), (float)(s[1][0] * d_omega), (float)(s[2][0] * d_omega), 0.f);
 	}
 }
 
@@ -966,8 +1024,10 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 		int nb = n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2);
 		const int need = (int)((F.n_local_tiles + 3) / 4);
 		if (nb > need) nb = need > 0 ? need : 1;
-		if (M.rgb_mid == 0) hipLaunchKernelGGL(render_nerf_fused_mid0, dim3(nb), dim3(BLOCK), 0, stream, M, C, F);
-		else hipLaunchKernelGGL(render_nerf_fused_mid2, dim3(nb), dim3(BLOCK), 0, stream, M, C, F);
+		FrameParams G = F;
+		G.n_waves = (uint32_t)nb * (BLOCK / 64);
+		if (M.rgb_mid == 0) hipLaunchKernelGGL(render_nerf_fused_mid0, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
+		else hipLaunchKernelGGL(render_nerf_fused_mid2, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		return;
 	}
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
@@ -980,24 +1040,39 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	int n_blocks = n_cus * per_cu;
 	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
-	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
-	else if (c5) hipLaunchKernelGGL(render_nerf_fused_c5, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
-	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, F);
+	FrameParams G = F;
+	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
+	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (c5) hipLaunchKernelGGL(render_nerf_fused_c5, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 }
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {
 	static const int per_cu = resident_blocks_per_cu(trace_probe_fused);
 	int n_blocks = n_cus * per_cu;
 	const int needed = (int)((F.n_local_tiles + 3) / 4);
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, F, P);
+	FrameParams G = F;
+	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
+	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, G, P);
 }
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream) {
-	uint32_t n = P.n_theta * P.n_phi;
+	uint32_t n = P.n_theta * P.n_phi * (P.mode == 3 ? P.grid_x * P.grid_y : 1u);
 	hipLaunchKernelGGL(probe_reduce_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, P, envmap);
 }
-void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream) {
-	hipLaunchKernelGGL(irradiance_kernel, dim3(n), dim3(256), 0, stream, n_theta, n_phi, envmap, n, normals, normals_are_texels, out);
+// E(n) of the probe texture(s) described by P (modes and shell positions as traced): normals == nullptr tabulates every
+// probe at its texel directions (n = probes * texels)
+void launch_irradiance(const ProbeParams& P, const float4* envmap, uint32_t n, const float* normals, float4* out, hipStream_t stream) {
+	IrradianceQuery Q{};
+	Q.n_theta = P.n_theta; Q.n_phi = P.n_phi;
+	Q.envmap = envmap;
+	Q.n = n;
+	Q.normals = normals;
+	Q.outward = P.mode == 1 ? 1 : (P.mode == 3 ? 3 : 0);
+	for (int i = 0; i < 3; ++i) { Q.origin[i] = P.origin[i]; Q.center[i] = P.center[i]; }
+	Q.grid_x = P.grid_x; Q.grid_y = P.grid_y; Q.shell_radius = P.shell_radius;
+	Q.out = out;
+	if (n) hipLaunchKernelGGL(irradiance_kernel, dim3(n), dim3(256), 0, stream, Q);
 }
 void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream) {
 	uint32_t n_waves = (n + 63) / 64;

@@ -3,6 +3,9 @@
 // that computes needs a HIP device and fails with an error otherwise.
 #include "ngp_host.h"
 
+#include <map>
+#include <mutex>
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -947,7 +950,8 @@ void schedule_from_env(ngp_ctx* ctx) {
 
 void ensure_frame_buffers(ngp_ctx* ctx, size_t n_pixels) {
 	if (!ctx->d_sync) {
-		NGP_HIP_CHECK(hipMalloc(&ctx->d_sync, 64 + 32 * ngp_ctx::HISTORY));
+		NGP_HIP_CHECK(hipMalloc(&ctx->d_sync, ngp_ctx::SLOT_BYTES * ngp_ctx::HISTORY));
+		NGP_HIP_CHECK(hipMemset(ctx->d_sync, 0, ngp_ctx::SLOT_BYTES * ngp_ctx::HISTORY));
 		for (int i = 0; i < ngp_ctx::HISTORY; ++i) {
 			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_frame0[i]));
 			NGP_HIP_CHECK(hipEventCreate(&ctx->ev_frame1[i]));
@@ -995,8 +999,9 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	ngp::sync_inference_model(ctx);
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
-	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_COST) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, AO, Positions, Depth, Cost");
-	if (opts.render_mode > NGP_RENDER_SHADE_ENVMAP && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth, Cost) apply to NeRF mode");
+	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_SHADE_GRID_ENVMAP) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Positions, Depth, Cost");
+	const bool gbuffer_mode = opts.render_mode >= NGP_RENDER_AO && opts.render_mode <= NGP_RENDER_COST;
+	if (gbuffer_mode && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth, Cost) apply to NeRF mode");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
@@ -1010,8 +1015,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.frame_buffer = ctx->d_frame;
 	F.depth_buffer = d_depth_out ? d_depth_out : ctx->d_depth;
 	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
-	F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
-	F.queue = (uint32_t*)(F.counters + 3); // every call has its own queue word: frames on different streams may overlap
+	ctx->bind_slot(F, slot); // every call has its own queue word and counters: frames on different streams may overlap
 	F.tiles_x = (uint32_t)(cam.width + 7) / 8;
 	F.tiles_y = (uint32_t)(cam.height + 7) / 8;
 	const uint32_t n_tiles = F.tiles_x * F.tiles_y;
@@ -1044,7 +1048,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	// (a rank's share in image layout keeps the general path: the other ranks' pixels must read as an empty frame)
 	F.direct = (spp == 1 && !have_meshes && !geometry && (shard_count == 1 || opts.packed_output)) ? 1 : 0;
 	F.to_srgb = opts.to_srgb;
-	F.render_mode = opts.render_mode;
+	F.render_mode = opts.render_mode == NGP_RENDER_SHADE_GRID_ENVMAP ? NGP_RENDER_SHADE_ENVMAP : opts.render_mode; // (the NeRF pass treats both like Shade)
 	F.color_space = opts.color_space;
 	if (opts.color_space != 0 && opts.color_space != 1) throw std::runtime_error("color_space: 0 (Linear) or 1 (SRGB)");
 	F.depth_scale = opts.depth_scale != 0.f ? opts.depth_scale : 1.0f / 0.33f;
@@ -1057,7 +1061,6 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		F.outside_possible = inside ? 0 : 1;
 	}
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
-	NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
 	if (F.direct) {
 		F.frame_buffer = d_rgba_out;
 		CameraParams C = make_camera_params(cam, cam.spp_index);
@@ -1075,20 +1078,22 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		// CudaRenderBufferView::clear (src/render_buffer.cu:603-607)
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_frame, 0, n_pixels * sizeof(float4), stream));
 		NGP_HIP_CHECK(hipMemsetAsync(F.depth_buffer, 0, n_pixels * sizeof(float), stream));
-		NGP_HIP_CHECK(hipMemsetAsync(F.queue, 0, 8, stream));
+		F.add_results = s > 0 ? 1 : 0; // the call's counters are the sums over its samples per pixel
 		const bool last = s == spp - 1;
 		if (have_meshes) {
 			IrradianceMap I{};
 			if (opts.render_mode == NGP_RENDER_SHADE_ENVMAP) {
-				if (!ctx->d_irradiance) throw std::runtime_error("render_mode ShadeEnvMap needs ngp_compute_envmap first");
-				I.irradiance = ctx->d_irradiance;
-				I.n_theta = ctx->env_n_theta;
-				I.n_phi = ctx->env_n_phi;
+				if (!ctx->d_irradiance || ctx->env_probe.mode == 3) throw std::runtime_error("render_mode ShadeEnvMap needs ngp_compute_envmap first");
+				I = ngp::irradiance_map_of(ctx);
+			} else if (opts.render_mode == NGP_RENDER_SHADE_GRID_ENVMAP) {
+				if (!ctx->d_irradiance || ctx->env_probe.mode != 3) throw std::runtime_error("render_mode ShadeGridEnvMap needs ngp_compute_envmap_grid first");
+				I = ngp::irradiance_map_of(ctx);
 			}
 			launch_render_mesh(ctx->mesh_scene, ctx->shade, I, C, ctx->d_frame, F.depth_buffer, F.shard_index, F.shard_count, F.packed, stream);
 		}
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
 		if (ctx->model_loaded) launch_render_nerf(M, C, F, ctx->n_cus, stream); // persistent grid sized by the launcher
+		else if (s == 0) NGP_HIP_CHECK(hipMemsetAsync(F.results, 0, 24, stream)); // meshes only: no NeRF launch reports counters
 		if (last) NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 		launch_accumulate_tonemap((uint32_t)n_pixels, ctx->d_frame, ctx->d_accum, (float)s, opts.background, opts.exposure, opts.to_srgb, opts.color_space, last ? d_rgba_out : nullptr, stream);
 	}
@@ -1463,16 +1468,78 @@ int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts,
 		const size_t n_pixels = (size_t)cam->width * cam->height;
 		ensure_frame_buffers(ctx, n_pixels);
 		render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
+		// (a destination from ngp_host_alloc is page-locked: the copy is one DMA at the link's rate instead of a staged one)
 		NGP_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_rgba, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
 		if (depth_out) NGP_HIP_CHECK(hipMemcpyAsync(depth_out, ctx->d_depth, n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	});
 }
 
+// ---- page-locked host images. Testbed::render_to_cpu returns a fresh numpy array per call (src/python_api.cu:124-202); a
+// pageable destination makes the runtime stage the 33 MB of a 1080p frame through its own bounce buffers (1.7 ms, against
+// 2.1 ms of rendering). Buffers from this pool are pinned once and recycled by size, so a binding can hand out "fresh"
+// arrays that the copy engine writes directly.
+namespace {
+struct HostPool {
+	std::mutex mu;
+	std::multimap<size_t, void*> free_list;
+	std::map<void*, size_t> live;
+	~HostPool() { // (process exit: the runtime may already be gone; leave the pages to the OS)
+	}
+} g_host_pool;
+constexpr size_t HOST_POOL_KEEP = 8; // buffers kept for reuse per process
+} // namespace
+
+void* ngp_host_alloc(size_t bytes) {
+	if (bytes == 0) return nullptr;
+	const size_t rounded = (bytes + 4095) & ~(size_t)4095;
+	{
+		std::lock_guard<std::mutex> lock(g_host_pool.mu);
+		auto it = g_host_pool.free_list.find(rounded);
+		if (it != g_host_pool.free_list.end()) {
+			void* p = it->second;
+			g_host_pool.free_list.erase(it);
+			g_host_pool.live[p] = rounded;
+			return p;
+		}
+	}
+	void* p = nullptr;
+	if (hipHostMalloc(&p, rounded, hipHostMallocDefault) != hipSuccess) { // no device / no pinned memory left: plain memory still works, only slower
+		(void)hipGetLastError();
+		p = aligned_alloc(4096, rounded);
+		if (!p) return nullptr;
+		std::lock_guard<std::mutex> lock(g_host_pool.mu);
+		g_host_pool.live[p] = 0; // 0: malloc'ed, never pooled
+		return p;
+	}
+	std::lock_guard<std::mutex> lock(g_host_pool.mu);
+	g_host_pool.live[p] = rounded;
+	return p;
+}
+
+void ngp_host_free(void* p) {
+	if (!p) return;
+	size_t size = 0;
+	bool release = false;
+	{
+		std::lock_guard<std::mutex> lock(g_host_pool.mu);
+		auto it = g_host_pool.live.find(p);
+		if (it == g_host_pool.live.end()) return; // not ours
+		size = it->second;
+		g_host_pool.live.erase(it);
+		if (size != 0 && g_host_pool.free_list.size() < HOST_POOL_KEEP) g_host_pool.free_list.emplace(size, p);
+		else release = true;
+	}
+	if (!release) return;
+	if (size == 0) free(p);
+	else (void)hipHostFree(p);
+}
+
 static void read_history_slot(ngp_ctx* ctx, uint64_t call, ngp_render_stats* out) {
 	const int slot = (int)(call % ngp_ctx::HISTORY);
-	unsigned long long c[3];
-	NGP_HIP_CHECK(hipMemcpy(c, (char*)ctx->d_sync + 64 + 32 * slot, sizeof(c), hipMemcpyDeviceToHost));
+	unsigned long long c[4];
+	NGP_HIP_CHECK(hipMemcpy(c, (char*)ctx->d_sync + ngp_ctx::SLOT_BYTES * (size_t)slot + 32, sizeof(c), hipMemcpyDeviceToHost)); // the slot's results (ngp_ctx::bind_slot)
+	out->kernel_device_ms = (float)((double)c[3] * 1e-5); // 100 MHz ticks
 	out->n_rays = ctx->hist_n_rays[slot];
 	out->n_rays_alive_after_init = c[0];
 	out->n_rays_hit = c[1];

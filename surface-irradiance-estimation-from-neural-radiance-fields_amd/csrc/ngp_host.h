@@ -43,7 +43,8 @@ void launch_render_mesh(const MeshSceneParams& S, const MeshShadeParams& P, cons
                         uint32_t shard_index, uint32_t shard_count, int packed, hipStream_t stream);
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream);
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream);
-void launch_irradiance(uint32_t n_theta, uint32_t n_phi, const float4* envmap, uint32_t n, const float* normals, int normals_are_texels, float4* out, hipStream_t stream);
+void launch_irradiance(const ProbeParams& P, const float4* envmap, uint32_t n, const float* normals, float4* out, hipStream_t stream);
+void launch_irradiance_lookup(const IrradianceMap& I, uint32_t n, const float* positions, const float* normals, float4* out, hipStream_t stream);
 void launch_trace_mesh_rays(const MeshSceneParams& S, uint32_t n, float* positions, float* directions, hipStream_t stream);
 
 // kernel launchers, train_kernels.hip
@@ -200,10 +201,11 @@ struct ngp_ctx {
 	ngp::MeshSceneParams mesh_scene{};
 	ngp::MeshShadeParams shade{{0.57735026f, 0.57735026f, 0.57735026f}, {0.f, 1.f, 0.f}, 0.f, 0.f, 1.f, 0.5f, 0.f, 0.f, 0.f, {0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}};
 
-	// ---- irradiance probe texture (m_envmap_tex / gridSize, testbed.h:949-950) and E(n) tabulated at its texels
+	// ---- irradiance probe texture(s) (m_envmap_tex / gridSize, testbed.h:949-950) and E(n) tabulated at their texels
 	float4* d_envmap = nullptr;
 	float4* d_irradiance = nullptr;
 	uint32_t env_n_theta = 0, env_n_phi = 0;
+	ngp::ProbeParams env_probe{}; // what was traced: mode, shell position(s), grid
 
 	// ---- frame
 	size_t n_pixels_alloc = 0;
@@ -211,9 +213,19 @@ struct ngp_ctx {
 	float* d_depth = nullptr;
 	float4* d_accum = nullptr;
 	float4* d_rgba = nullptr;
-	// queue word (64 B) followed by a ring of per-call counter slots (32 B each: alive, hit, samples, pad)
+	// a ring of per-call slots of 80 B: accumulators [alive, hit, samples], {tile queue, exited waves}, results [alive, hit, samples, device ticks], start stamp.
+	// Zeroed once; every launch's last wave leaves its slot's first four words zero again (nerf_kernels.hip fused_body)
 	static constexpr int HISTORY = 256;
+	static constexpr size_t SLOT_BYTES = 128;
 	void* d_sync = nullptr;
+	void bind_slot(ngp::FrameParams& F, int slot) const {
+		unsigned long long* w = (unsigned long long*)((char*)d_sync + SLOT_BYTES * (size_t)slot);
+		F.counters = w;
+		F.queue = (uint32_t*)(w + 3);
+		F.done = F.queue + 1;
+		F.results = w + 4;
+		F.add_results = 0;
+	}
 	hipEvent_t ev_frame0[HISTORY] = {}, ev_frame1[HISTORY] = {}, ev_kern0[HISTORY] = {}, ev_kern1[HISTORY] = {};
 	uint64_t hist_n_rays[HISTORY] = {};
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
@@ -282,4 +294,16 @@ void sync_inference_model(ngp_ctx* ctx); // render what has been trained (no-op 
 void sync_host_params(ngp_ctx* ctx);     // ctx->params <- training parameters, for snapshots
 
 void ensure_sync_buffers(ngp_ctx* ctx);
+inline IrradianceMap irradiance_map_of(const ngp_ctx* ctx) {
+	IrradianceMap I{};
+	I.irradiance = ctx->d_irradiance;
+	I.n_theta = ctx->env_n_theta;
+	I.n_phi = ctx->env_n_phi;
+	if (ctx->env_probe.mode == 3) {
+		I.grid_x = ctx->env_probe.grid_x;
+		I.grid_y = ctx->env_probe.grid_y;
+	}
+	for (int i = 0; i < 3; ++i) I.center[i] = ctx->env_probe.center[i];
+	return I;
+}
 } // namespace ngp

@@ -91,7 +91,11 @@ struct FrameParams {
 	float4* frame_buffer;
 	float* depth_buffer;
 	uint32_t* queue;               // [0]: next strip (quarter tile) of this rank's share
-	unsigned long long* counters;  // [0] alive after init, [1] hit, [2] samples
+	unsigned long long* counters;  // [0] alive after init, [1] hit, [2] samples: accumulators of the launch; its last wave moves them to `results` and leaves the slot zeroed
+	unsigned long long* results;   // [0..2]: what ngp_get_render_stats reads; [3] the launch(es) in ticks of the 100 MHz device clock; [4] scratch (start stamp, left zero)
+	uint32_t* done;                // waves of this launch that have left
+	uint32_t n_waves;              // waves launched (set by the launcher)
+	int32_t add_results;           // 0: the launch's totals replace results (first launch of a call), 1: they are added (further samples per pixel)
 	uint32_t tiles_x, tiles_y;
 	uint32_t n_local_tiles;
 	uint32_t shard_index, shard_count;
@@ -114,12 +118,14 @@ struct FrameParams {
 
 // ---- irradiance probes
 struct ProbeParams {
-	int32_t mode; // 0 centre fan (K10), 1 shell position looking inward (K11), 2 Halton-jittered centres (K12)
+	int32_t mode; // 0 centre fan (K10), 1 shell position looking inward (K11), 2 Halton-jittered centres (K12), 3 a grid_x x grid_y lattice of K11 probes
 	uint32_t n_theta, n_phi, n_origin;
 	float origin[3];
 	float center[3]; // render_aabb.center()
 	uint32_t n_rays;
 	float4* ray_rgba; // one shaded RGBA per probe ray (zero when the ray saw nothing)
+	uint32_t grid_x, grid_y; // mode 3: probe g = i + grid_x * j sits at center + shell_radius * cylindrical_to_dir_nerf((i + .5) / grid_x, (j + .5) / grid_y)
+	float shell_radius;
 };
 
 // ---- geometry mode (meshes)
@@ -148,8 +154,10 @@ struct MeshShadeParams { // BRDFParams (common.h:167-177) + m_sun_dir / m_up_dir
 	float basecolor[3], ambientcolor[3];
 };
 struct IrradianceMap { // E(n) tabulated at the probe texture's texel directions; nullptr = not computed
-	const float4* irradiance;
+	const float4* irradiance; // grid_x * grid_y tables (one when grid_x == 0) of n_theta * n_phi texels
 	uint32_t n_theta, n_phi;
+	uint32_t grid_x, grid_y;  // ShadeGridEnvMap: the probes around the direction of (surface point - center) are blended
+	float center[3];
 };
 
 } // namespace ngp

@@ -73,7 +73,7 @@ std::string read_text(const std::string& path) {
 
 void usage() {
 	std::cout << "ngp_hip_main [files...] [--scene PATH] [--snapshot|--load_snapshot PATH] [--width W] [--height H] [--spp N]\n"
-	             "             [--screenshot OUT.png] [--screenshot_transforms T.json --screenshot_dir DIR] [--render_mode Shade|ShadeEnvMap|AO|Positions|Depth]\n"
+	             "             [--screenshot OUT.png] [--screenshot_transforms T.json --screenshot_dir DIR] [--render_mode Shade|ShadeEnvMap|ShadeGridEnvMap|AO|Positions|Depth]\n"
 	             "             [--exposure E] [--n_steps N] [--save_snapshot OUT.ingp] [--network CONFIG.json] [--no-gui] [--no-train] [--version]\n"
 	             "             [--video_camera_path PATH.json --video_output DIR/%04d.png [--video_n_seconds S] [--video_fps F] [--video_spp N]]\n";
 }
@@ -145,13 +145,16 @@ int main(int argc, char** argv) {
 			testbed.save_snapshot(save_snapshot, false);
 			std::cerr << "wrote " << save_snapshot << "\n";
 		}
-		if (render_mode == "ShadeEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeEnvMap;
+		if (render_mode == "Shade") testbed.m_render_mode = ngp::ERenderMode::Shade;
+		else if (render_mode == "ShadeGridEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeGridEnvMap;
+		else if (render_mode == "ShadeEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeEnvMap;
 		else if (render_mode == "AO") testbed.m_render_mode = ngp::ERenderMode::AO;
 		else if (render_mode == "Positions") testbed.m_render_mode = ngp::ERenderMode::Positions;
 		else if (render_mode == "Depth") testbed.m_render_mode = ngp::ERenderMode::Depth;
-		else if (render_mode != "Shade") throw std::runtime_error("unknown render mode " + render_mode);
+		else throw std::runtime_error("unknown render mode " + render_mode);
 		// pre computation of the envmap, src/main.cu:184-188
 		if (testbed.m_render_mode == ngp::ERenderMode::ShadeEnvMap) testbed.computeEnvmapMultipleMain();
+		else if (testbed.m_render_mode == ngp::ERenderMode::ShadeGridEnvMap && testbed.m_testbed_mode == ngp::ETestbedMode::Geometry) testbed.computeEnvmapGrid();
 		testbed.m_background_color = {0.f, 0.f, 0.f, 0.f};
 		std::vector<float> img((size_t)width * height * 4);
 		if (!video_path.empty()) { // scripts/run.py:304-337: one PNG per frame along the camera path

@@ -357,64 +357,100 @@ int ngp_trace_mesh_rays(ngp_ctx* ctx, uint32_t n, float* positions, float* direc
 
 
 // ------------------------------------------------------------------------------------------------ irradiance probes
+namespace {
+// trace the fan(s) described by P in ONE persistent launch, reduce to the probe texture(s), tabulate E(n) at the texel directions
+void compute_probes(ngp_ctx* ctx, ngp::ProbeParams P, float min_transmittance) {
+	using namespace ngp;
+	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+	if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+	ngp::sync_inference_model(ctx);
+	if (ctx->M.rgb_mid != 1) throw std::runtime_error("irradiance probes are built for the configs/nerf/base.json rgb head (2 hidden layers)");
+	ensure_sync_buffers(ctx);
+	for (int i = 0; i < 3; ++i) P.center[i] = 0.5f * (ctx->M.raabb_max[i] + ctx->M.raabb_min[i]); // render_aabb.center()
+	const uint32_t no = P.mode == NGP_PROBE_MULTI_CENTER ? P.n_origin : 1u;
+	const uint32_t n_probes = P.mode == 3 ? P.grid_x * P.grid_y : 1u;
+	const uint64_t n_rays64 = (uint64_t)P.n_theta * P.n_phi * no * no * n_probes;
+	if (n_rays64 > (1ull << 28)) throw std::runtime_error("probe too large");
+	P.n_rays = (uint32_t)n_rays64;
+	const uint32_t n_texels = P.n_theta * P.n_phi * n_probes;
+	NGP_HIP_CHECK(hipMalloc((void**)&P.ray_rgba, (size_t)P.n_rays * sizeof(float4)));
+	if (ctx->d_envmap) (void)hipFree(ctx->d_envmap);
+	if (ctx->d_irradiance) (void)hipFree(ctx->d_irradiance);
+	ctx->d_envmap = ctx->d_irradiance = nullptr;
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_envmap, (size_t)n_texels * sizeof(float4)));
+	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_irradiance, (size_t)n_texels * sizeof(float4)));
+	hipStream_t stream = ctx->stream;
+	if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
+	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
+	FrameParams F{};
+	ctx->bind_slot(F, slot);
+	F.n_local_tiles = (P.n_rays + 63) / 64;
+	F.shard_index = 0;
+	F.shard_count = 1;
+	F.min_transmittance = min_transmittance > 0.f ? min_transmittance : 0.01f;
+	F.linear_colors = ctx->desc.linear_colors;
+	memcpy(F.tune, ctx->tune, sizeof(F.tune));
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
+	NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
+	ModelParams M = ctx->M;
+	if (!ctx->meshes.empty()) { // Geometry mode: load_scene made the inflated mesh box the render box (testbed_geometry_training.cu:3185-3189); the shell positions lie inside it
+		for (int i = 0; i < 3; ++i) { M.raabb_min[i] = ctx->mesh_scene.scene_min[i]; M.raabb_max[i] = ctx->mesh_scene.scene_max[i]; }
+		const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		memcpy(M.r2l, ident, sizeof(ident));
+		M.r2l_identity = 1u;
+	}
+	launch_trace_probe(M, F, P, ctx->n_cus, stream);
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
+	launch_probe_reduce(P, ctx->d_envmap, stream);
+	launch_irradiance(P, ctx->d_envmap, n_texels, nullptr, ctx->d_irradiance, stream);
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame1[slot], stream));
+	ctx->hist_n_rays[slot] = P.n_rays;
+	ctx->last_stream = stream;
+	++ctx->n_calls;
+	NGP_HIP_CHECK(hipStreamSynchronize(stream));
+	NGP_HIP_CHECK(hipGetLastError());
+	(void)hipFree(P.ray_rgba);
+	P.ray_rgba = nullptr;
+	ctx->env_probe = P;
+	ctx->env_n_theta = P.n_theta;
+	ctx->env_n_phi = P.n_phi;
+}
+size_t env_texels(const ngp_ctx* ctx) {
+	const ngp::ProbeParams& P = ctx->env_probe;
+	return (size_t)P.n_theta * P.n_phi * (P.mode == 3 ? P.grid_x * P.grid_y : 1u);
+}
+} // namespace
+
 int ngp_compute_envmap(ngp_ctx* ctx, const ngp_probe_desc* d, float* rgba_out) {
 	return guarded(ctx, [&] {
-		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
-		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
-		ngp::sync_inference_model(ctx);
 		if (!d || d->n_theta == 0 || d->n_phi == 0 || d->mode < 0 || d->mode > 2) throw std::runtime_error("invalid probe descriptor");
-		const uint32_t no = d->mode == NGP_PROBE_MULTI_CENTER ? d->n_origin : 1u;
-		if (no == 0) throw std::runtime_error("invalid probe descriptor: n_origin");
-		ensure_sync_buffers(ctx);
-		ProbeParams P{};
+		if (d->mode == NGP_PROBE_MULTI_CENTER && d->n_origin == 0) throw std::runtime_error("invalid probe descriptor: n_origin");
+		ngp::ProbeParams P{};
 		P.mode = d->mode;
 		P.n_theta = d->n_theta;
 		P.n_phi = d->n_phi;
-		P.n_origin = no;
-		for (int i = 0; i < 3; ++i) {
-			P.origin[i] = d->origin[i];
-			P.center[i] = 0.5f * (ctx->M.raabb_max[i] + ctx->M.raabb_min[i]); // render_aabb.center()
-		}
-		const uint64_t n_rays64 = (uint64_t)d->n_theta * d->n_phi * no * no;
-		if (n_rays64 > (1ull << 28)) throw std::runtime_error("probe too large");
-		P.n_rays = (uint32_t)n_rays64;
-		const uint32_t n_texels = d->n_theta * d->n_phi;
-		NGP_HIP_CHECK(hipMalloc((void**)&P.ray_rgba, (size_t)P.n_rays * sizeof(float4)));
-		if (ctx->d_envmap) (void)hipFree(ctx->d_envmap);
-		if (ctx->d_irradiance) (void)hipFree(ctx->d_irradiance);
-		ctx->d_envmap = ctx->d_irradiance = nullptr;
-		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_envmap, (size_t)n_texels * sizeof(float4)));
-		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_irradiance, (size_t)n_texels * sizeof(float4)));
-		hipStream_t stream = ctx->stream;
-		const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
-		FrameParams F{};
-		F.counters = (unsigned long long*)((char*)ctx->d_sync + 64 + 32 * slot);
-		F.queue = (uint32_t*)(F.counters + 3);
-		F.n_local_tiles = (P.n_rays + 63) / 64;
-		F.shard_index = 0;
-		F.shard_count = 1;
-		F.min_transmittance = d->min_transmittance > 0.f ? d->min_transmittance : 0.01f;
-		F.linear_colors = ctx->desc.linear_colors;
-		memcpy(F.tune, ctx->tune, sizeof(F.tune));
-		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
-		NGP_HIP_CHECK(hipMemsetAsync(P.ray_rgba, 0, (size_t)P.n_rays * sizeof(float4), stream));
-		NGP_HIP_CHECK(hipMemsetAsync(F.counters, 0, 32, stream));
-		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern0[slot], stream));
-		if (ctx->M.rgb_mid != 1) throw std::runtime_error("irradiance probes are built for the configs/nerf/base.json rgb head (2 hidden layers)");
-		launch_trace_probe(ctx->M, F, P, ctx->n_cus, stream);
-		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
-		launch_probe_reduce(P, ctx->d_envmap, stream);
-		launch_irradiance(d->n_theta, d->n_phi, ctx->d_envmap, n_texels, nullptr, 1, ctx->d_irradiance, stream);
-		NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame1[slot], stream));
-		ctx->hist_n_rays[slot] = P.n_rays;
-		ctx->last_stream = stream;
-		++ctx->n_calls;
-		NGP_HIP_CHECK(hipStreamSynchronize(stream));
-		NGP_HIP_CHECK(hipGetLastError());
-		(void)hipFree(P.ray_rgba);
-		ctx->env_n_theta = d->n_theta;
-		ctx->env_n_phi = d->n_phi;
-		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, (size_t)n_texels * sizeof(float4), hipMemcpyDeviceToHost));
+		P.n_origin = d->mode == NGP_PROBE_MULTI_CENTER ? d->n_origin : 1u;
+		for (int i = 0; i < 3; ++i) P.origin[i] = d->origin[i];
+		compute_probes(ctx, P, d->min_transmittance);
+		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, env_texels(ctx) * sizeof(float4), hipMemcpyDeviceToHost));
+	});
+}
+
+int ngp_compute_envmap_grid(ngp_ctx* ctx, const ngp_probe_grid_desc* d, float* rgba_out) {
+	return guarded(ctx, [&] {
+		if (!d || d->n_theta == 0 || d->n_phi == 0 || d->grid_x == 0 || d->grid_y == 0 || !(d->shell_radius > 0.f)) throw std::runtime_error("invalid probe grid descriptor");
+		if ((uint64_t)d->grid_x * d->grid_y > 65536ull) throw std::runtime_error("probe grid too large");
+		ngp::ProbeParams P{};
+		P.mode = 3;
+		P.n_theta = d->n_theta;
+		P.n_phi = d->n_phi;
+		P.n_origin = 1;
+		P.grid_x = d->grid_x;
+		P.grid_y = d->grid_y;
+		P.shell_radius = d->shell_radius;
+		compute_probes(ctx, P, d->min_transmittance);
+		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, env_texels(ctx) * sizeof(float4), hipMemcpyDeviceToHost));
 	});
 }
 
@@ -423,15 +459,49 @@ int ngp_get_envmap(ngp_ctx* ctx, uint32_t* n_theta, uint32_t* n_phi, float* rgba
 		if (!ctx->d_envmap) throw std::runtime_error("no probe texture: call ngp_compute_envmap first");
 		if (n_theta) *n_theta = ctx->env_n_theta;
 		if (n_phi) *n_phi = ctx->env_n_phi;
-		const size_t bytes = (size_t)ctx->env_n_theta * ctx->env_n_phi * sizeof(float4);
+		const size_t bytes = env_texels(ctx) * sizeof(float4); // a grid returns grid_x * grid_y textures back to back (ngp_get_envmap_grid tells how many)
 		if (rgba_out) NGP_HIP_CHECK(hipMemcpy(rgba_out, ctx->d_envmap, bytes, hipMemcpyDeviceToHost));
 		if (irradiance_rgba_out) NGP_HIP_CHECK(hipMemcpy(irradiance_rgba_out, ctx->d_irradiance, bytes, hipMemcpyDeviceToHost));
 	});
 }
 
+int ngp_get_envmap_grid(ngp_ctx* ctx, ngp_probe_grid_desc* desc_out, float* origins_out) {
+	return guarded(ctx, [&] {
+		if (!ctx->d_envmap || ctx->env_probe.mode != 3) throw std::runtime_error("no probe grid: call ngp_compute_envmap_grid first");
+		const ngp::ProbeParams& P = ctx->env_probe;
+		if (desc_out) {
+			desc_out->grid_x = P.grid_x; desc_out->grid_y = P.grid_y; desc_out->n_theta = P.n_theta; desc_out->n_phi = P.n_phi;
+			desc_out->shell_radius = P.shell_radius;
+			desc_out->min_transmittance = 0.f;
+		}
+		if (origins_out) { // shell positions, for callers that place things: the same arithmetic as the kernel's probe_grid_origin
+			const float PI = 3.14159265358979323846f;
+			for (uint32_t g = 0; g < P.grid_x * P.grid_y; ++g) {
+				const uint32_t i = g % P.grid_x, j = g / P.grid_x;
+				const float px = ((float)i + 0.5f) / (float)P.grid_x, py = ((float)j + 0.5f) / (float)P.grid_y;
+				const float cos_theta = -2.0f * px + 1.0f, phi = 2.0f * PI * (py - 0.5f);
+				const float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+				origins_out[3 * g] = P.center[0] + sin_theta * cosf(phi) * P.shell_radius;
+				origins_out[3 * g + 1] = P.center[1] + sin_theta * sinf(phi) * P.shell_radius;
+				origins_out[3 * g + 2] = P.center[2] + cos_theta * P.shell_radius;
+			}
+		}
+	});
+}
+
+namespace {
+void download_rgb(ngp_ctx* ctx, const float4* d_o, uint32_t n, float* rgb_out) {
+	NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	std::vector<float4> tmp(n);
+	NGP_HIP_CHECK(hipMemcpy(tmp.data(), d_o, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
+}
+} // namespace
+
 int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_out) {
 	return guarded(ctx, [&] {
 		if (!ctx->d_envmap) throw std::runtime_error("no probe texture: call ngp_compute_envmap first");
+		if (ctx->env_probe.mode == 3) throw std::runtime_error("the probe texture is a grid: use ngp_irradiance_at (position + normal)");
 		if (n == 0) return;
 		if (!normals || !rgb_out) throw std::runtime_error("null argument");
 		float* d_n = nullptr;
@@ -439,11 +509,29 @@ int ngp_irradiance(ngp_ctx* ctx, uint32_t n, const float* normals, float* rgb_ou
 		NGP_HIP_CHECK(hipMalloc((void**)&d_n, (size_t)n * 3 * sizeof(float)));
 		NGP_HIP_CHECK(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
 		NGP_HIP_CHECK(hipMemcpy(d_n, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-		launch_irradiance(ctx->env_n_theta, ctx->env_n_phi, ctx->d_envmap, n, d_n, 0, d_o, ctx->stream);
-		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-		std::vector<float4> tmp(n);
-		NGP_HIP_CHECK(hipMemcpy(tmp.data(), d_o, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-		for (uint32_t i = 0; i < n; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
+		launch_irradiance(ctx->env_probe, ctx->d_envmap, n, d_n, d_o, ctx->stream);
+		download_rgb(ctx, d_o, n, rgb_out);
+		(void)hipFree(d_n);
+		(void)hipFree(d_o);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int ngp_irradiance_at(ngp_ctx* ctx, uint32_t n, const float* positions, const float* normals, float* rgb_out) {
+	return guarded(ctx, [&] {
+		if (!ctx->d_irradiance) throw std::runtime_error("no probe texture: call ngp_compute_envmap / ngp_compute_envmap_grid first");
+		if (n == 0) return;
+		if (!positions || !normals || !rgb_out) throw std::runtime_error("null argument");
+		float *d_p = nullptr, *d_n = nullptr;
+		float4* d_o = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_p, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_n, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
+		NGP_HIP_CHECK(hipMemcpy(d_p, positions, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		NGP_HIP_CHECK(hipMemcpy(d_n, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		launch_irradiance_lookup(ngp::irradiance_map_of(ctx), n, d_p, d_n, d_o, ctx->stream);
+		download_rgb(ctx, d_o, n, rgb_out);
+		(void)hipFree(d_p);
 		(void)hipFree(d_n);
 		(void)hipFree(d_o);
 		NGP_HIP_CHECK(hipGetLastError());

@@ -95,8 +95,15 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& a) { t.set_nerf_camera_matrix(to_colmajor(a)); })
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
 		.def("compute_envmap", &Testbed::computeEnvmapMultipleMain, py::arg("n_theta") = 256, py::arg("n_phi") = 128, py::arg("n_origin") = 1)
+		.def("compute_envmap_grid", &Testbed::computeEnvmapGrid, py::arg("grid_x") = 8, py::arg("grid_y") = 8, py::arg("n_theta") = 64, py::arg("n_phi") = 32, py::arg("shell_radius") = 1.0f)
 		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float start_t, float end_t, float fps, float shutter_fraction) {
-				py::array_t<float> result({height, width, 4});
+				// a fresh array per call, like python_api.cu:124-202 -- whose memory is page-locked and pooled (ngp_host_alloc), so the
+				// device-to-host copy is a single DMA; the array owns its buffer and returns it to the pool when collected
+				const size_t bytes = (size_t)height * width * 4 * sizeof(float);
+				float* mem = (float*)ngp_host_alloc(bytes);
+				if (!mem) throw std::runtime_error("out of host memory");
+				py::capsule owner(mem, [](void* p) { ngp_host_free(p); });
+				py::array_t<float> result({(py::ssize_t)height, (py::ssize_t)width, (py::ssize_t)4}, mem, owner);
 				{
 					py::gil_scoped_release release;
 					t.render_to_cpu(result.mutable_data(), width, height, spp, linear, start_t, end_t, fps, shutter_fraction);

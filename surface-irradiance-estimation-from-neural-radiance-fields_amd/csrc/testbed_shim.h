@@ -20,7 +20,7 @@ namespace ngp {
 enum class ETestbedMode : int { Nerf, Sdf, Image, Volume, Geometry, None }; // common.h:35-43
 enum class ELossType : int { L2, L1, Mape, Smape, Huber, LogL1, RelativeL2 }; // common.h:84-92
 enum class EColorSpace : int { Linear, SRGB, VisPosNeg }; // common.h
-enum class ERenderMode : int { AO, Shade, Normals, Positions, Depth, Distortion, Cost, Slice, ShadeNerf, ShadeEnvMap, ShadeGridEnvMap, EncodingVis }; // common.h:58-72
+enum class ERenderMode : int { AO, Shade, ShadeNerf, ShadeEnvMap, ShadeGridEnvMap, Normals, Positions, Depth, Distortion, Cost, Slice, NumRenderModes, EncodingVis }; // common.h:58-72
 
 class Testbed {
 public:
@@ -372,7 +372,14 @@ public:
 			return;
 		}
 		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth || m_render_mode == ERenderMode::Cost;
-		if (m_render_mode != ERenderMode::Shade && m_render_mode != ERenderMode::ShadeEnvMap && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, AO, Positions, Depth, Cost (the fork's default ShadeGridEnvMap has no implementation in the reference either)");
+		const bool shade_family = m_render_mode == ERenderMode::Shade || m_render_mode == ERenderMode::ShadeEnvMap || m_render_mode == ERenderMode::ShadeGridEnvMap;
+		if (!shade_family && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Positions, Depth, Cost");
+		// pre computation of the envmap: src/main.cu:184-188 runs it before the first frame; a Python session has no such hook
+		// (python_api.cu binds neither function), so the first Geometry-mode render in these modes runs it with the defaults
+		if (m_testbed_mode == ETestbedMode::Geometry && ngp_n_meshes(m_ctx) > 0) {
+			if (m_render_mode == ERenderMode::ShadeGridEnvMap && !m_envmap_grid_ready) computeEnvmapGrid();
+			if (m_render_mode == ERenderMode::ShadeEnvMap && !m_envmap_ready) computeEnvmapMultipleMain();
+		}
 		ngp_camera cam{};
 		memcpy(cam.matrix, m_camera.data(), sizeof(cam.matrix));
 		cam.width = width;
@@ -392,7 +399,7 @@ public:
 			memcpy(cam.lens_params, m_render_lens_params.data(), sizeof(cam.lens_params));
 		}
 		ngp_render_opts o{};
-		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
+		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::ShadeGridEnvMap ? NGP_RENDER_SHADE_GRID_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
 		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : m_render_mode == ERenderMode::Cost ? NGP_RENDER_COST : NGP_RENDER_SHADE;
 		o.min_transmittance = nerf.render_min_transmittance;
 		memcpy(o.background, m_background_color.data(), sizeof(o.background));
@@ -430,7 +437,20 @@ public:
 		d.n_theta = n_theta; d.n_phi = n_phi; d.n_origin = n_origin;
 		d.min_transmittance = nerf.render_min_transmittance;
 		check(ngp_compute_envmap(m_ctx, &d, nullptr));
+		m_envmap_ready = true;
+		m_envmap_grid_ready = false;
 	}
+	// Testbed::computeEnvmapGrid (testbed.h:743; src/main.cu:187-188 in ShadeGridEnvMap mode): gridSize probes on a shell around the NeRF
+	void computeEnvmapGrid(uint32_t grid_x = 8, uint32_t grid_y = 8, uint32_t n_theta = 64, uint32_t n_phi = 32, float shell_radius = 1.0f) {
+		ngp_probe_grid_desc d{};
+		d.grid_x = grid_x; d.grid_y = grid_y; d.n_theta = n_theta; d.n_phi = n_phi;
+		d.shell_radius = shell_radius;
+		d.min_transmittance = nerf.render_min_transmittance;
+		check(ngp_compute_envmap_grid(m_ctx, &d, nullptr));
+		m_envmap_grid_ready = true;
+		m_envmap_ready = false;
+	}
+	bool m_envmap_ready = false, m_envmap_grid_ready = false;
 
 	struct BRDFParams { // common.h:167-177
 		float metallic = 0.f, subsurface = 0.f, specular = 1.f, roughness = 0.5f, sheen = 0.f, clearcoat = 0.f, clearcoat_gloss = 0.f;
@@ -451,8 +471,9 @@ public:
 	std::array<float, 3> m_up_dir{0.f, 1.f, 0.f};
 	std::array<float, 3> m_sun_dir{0.57735026f, 0.57735026f, 0.57735026f};
 	float m_exposure = 0.f;
-	// The fork defaults to ShadeGridEnvMap, for which the reference has no kernel; every BASELINE run pins Shade.
-	ERenderMode m_render_mode = ERenderMode::Shade;
+	// testbed.h:880. In Nerf mode the fork's default renders like Shade WITHOUT the sRGB -> linear step of shade_kernel_nerf
+	// (src/testbed_nerf.cu:1392-1395 tests for Shade / Slice only); every BASELINE run pins Shade.
+	ERenderMode m_render_mode = ERenderMode::ShadeGridEnvMap;
 	EColorSpace m_color_space = EColorSpace::Linear; // testbed.color_space (run.py:160)
 	float m_aperture_size = 0.f, m_slice_plane_z = 0.f; // testbed.aperture_size, testbed.slice_plane_z (focus = slice_plane_z + scale)
 	int32_t m_render_lens_mode = 0;                  // m_nerf.render_lens

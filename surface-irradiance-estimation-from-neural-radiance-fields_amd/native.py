@@ -77,8 +77,13 @@ class ProbeDesc(C.Structure):
                 ("min_transmittance", C.c_float)]
 
 
+class ProbeGridDesc(C.Structure):
+    _fields_ = [("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("n_theta", C.c_uint32), ("n_phi", C.c_uint32), ("shell_radius", C.c_float),
+                ("min_transmittance", C.c_float)]
+
+
 MODE_NERF, MODE_GEOMETRY = 0, 1
-RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH, RENDER_COST = 0, 1, 2, 3, 4, 5
+RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH, RENDER_COST, RENDER_SHADE_GRID_ENVMAP = 0, 1, 2, 3, 4, 5, 6
 PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
@@ -87,7 +92,7 @@ TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
 class RenderStats(C.Structure):
     _fields_ = [
         ("n_rays", C.c_uint64), ("n_rays_alive_after_init", C.c_uint64), ("n_rays_hit", C.c_uint64), ("n_samples", C.c_uint64),
-        ("kernel_ms", C.c_float), ("frame_ms", C.c_float),
+        ("kernel_ms", C.c_float), ("frame_ms", C.c_float), ("kernel_device_ms", C.c_float),
     ]
 
 
@@ -152,6 +157,8 @@ def load_library():
     L.ngp_get_dataset_info.argtypes = [vp, vp, vp, vp, vp]
     L.ngp_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp]
     L.ngp_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), vp, vp, vp]
+    L.ngp_host_alloc.argtypes = [C.c_size_t]; L.ngp_host_alloc.restype = vp
+    L.ngp_host_free.argtypes = [vp]; L.ngp_host_free.restype = None
     L.ngp_packed_tiles.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
     L.ngp_packed_tiles.restype = C.c_uint32
     L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
@@ -173,6 +180,9 @@ def load_library():
     L.ngp_compute_envmap.argtypes = [vp, C.POINTER(ProbeDesc), vp]
     L.ngp_get_envmap.argtypes = [vp, vp, vp, vp, vp]
     L.ngp_irradiance.argtypes = [vp, C.c_uint32, vp, vp]
+    L.ngp_compute_envmap_grid.argtypes = [vp, C.POINTER(ProbeGridDesc), vp]
+    L.ngp_get_envmap_grid.argtypes = [vp, C.POINTER(ProbeGridDesc), vp]
+    L.ngp_irradiance_at.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.ngp_reset_network.argtypes = [vp, C.c_uint32, C.c_uint64]
     L.ngp_default_training_opts.argtypes = [C.POINTER(TrainingOpts)]; L.ngp_default_training_opts.restype = None
     L.ngp_set_training_opts.argtypes = [vp, C.POINTER(TrainingOpts)]
@@ -196,6 +206,20 @@ def _p(a):
 
 
 LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR = range(6)
+
+
+def host_image(shape):
+    """float32 array in page-locked memory from ngp_host_alloc; the buffer returns to the pool when the array is collected"""
+    import weakref
+
+    L = load_library()
+    count = int(np.prod(shape))
+    p = L.ngp_host_alloc(count * 4)
+    if not p:
+        raise MemoryError("ngp_host_alloc failed")
+    buf = (C.c_float * count).from_address(p)
+    weakref.finalize(buf, L.ngp_host_free, p)
+    return np.ctypeslib.as_array(buf).reshape(shape)
 
 
 def decode_image(data):
@@ -367,6 +391,13 @@ class Context:
         self._check(self.L.ngp_render(self.h, C.byref(cam), C.byref(opts), _p(rgba), _p(depth) if want_depth else None))
         return (rgba, depth) if want_depth else rgba
 
+    def render_pinned(self, cam, opts=None):
+        """ngp_render into a page-locked buffer from the library's pool (what pyngp's Testbed.render does): one DMA, no staging"""
+        opts = opts or make_opts()
+        rgba = host_image((cam.height, cam.width, 4))
+        self._check(self.L.ngp_render(self.h, C.byref(cam), C.byref(opts), _p(rgba), None))
+        return rgba
+
     def render_device(self, cam, opts, d_rgba_ptr, d_depth_ptr=None, stream=None):
         self._check(self.L.ngp_render_device(self.h, C.byref(cam), C.byref(opts), d_rgba_ptr, d_depth_ptr, stream))
 
@@ -452,6 +483,33 @@ class Context:
         nrm = np.ascontiguousarray(normals, np.float32)
         out = np.zeros((nrm.shape[0], 3), np.float32)
         self._check(self.L.ngp_irradiance(self.h, nrm.shape[0], _p(nrm), _p(out)))
+        return out
+
+    def compute_envmap_grid(self, grid_x=4, grid_y=4, n_theta=32, n_phi=16, shell_radius=1.0, min_transmittance=0.01):
+        """Testbed::computeEnvmapGrid: (grid_x * grid_y, n_phi, n_theta, 4) probe textures, all traced in one launch"""
+        d = ProbeGridDesc()
+        d.grid_x, d.grid_y, d.n_theta, d.n_phi, d.shell_radius, d.min_transmittance = grid_x, grid_y, n_theta, n_phi, shell_radius, min_transmittance
+        env = np.zeros((grid_x * grid_y, n_phi, n_theta, 4), np.float32)
+        self._check(self.L.ngp_compute_envmap_grid(self.h, C.byref(d), _p(env)))
+        return env
+
+    def get_envmap_grid(self):
+        """(desc, shell positions (G, 3), textures (G, n_phi, n_theta, 4), irradiance tables (G, n_phi, n_theta, 4))"""
+        d = ProbeGridDesc()
+        self._check(self.L.ngp_get_envmap_grid(self.h, C.byref(d), None))
+        g = d.grid_x * d.grid_y
+        org = np.zeros((g, 3), np.float32)
+        self._check(self.L.ngp_get_envmap_grid(self.h, C.byref(d), _p(org)))
+        env = np.zeros((g, d.n_phi, d.n_theta, 4), np.float32)
+        irr = np.zeros((g, d.n_phi, d.n_theta, 4), np.float32)
+        self._check(self.L.ngp_get_envmap(self.h, None, None, _p(env), _p(irr)))
+        return d, org, env, irr
+
+    def irradiance_at(self, positions, normals):
+        pos = np.ascontiguousarray(positions, np.float32)
+        nrm = np.ascontiguousarray(normals, np.float32)
+        out = np.zeros((nrm.shape[0], 3), np.float32)
+        self._check(self.L.ngp_irradiance_at(self.h, nrm.shape[0], _p(pos), _p(nrm), _p(out)))
         return out
 
     # ---------------------------------------------------------------- stages

@@ -68,6 +68,17 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     assert list(res) == [160, 90]
     testbed.fov_axis = 0
     testbed.fov = 0.6911 * 180 / np.pi
+    # the fork's default render mode (testbed.h:880): in Nerf mode it shades like Shade but, not being Shade, skips the
+    # sRGB -> linear step of shade_kernel_nerf (src/testbed_nerf.cu:1392-1395); BASELINE runs pin Shade
+    assert testbed.render_mode == pyngp.RenderMode.ShadeGridEnvMap
+    testbed.camera_matrix = scene_mod.orbit_camera(30.0)
+    quirk = testbed.render(160, 90, 1, True)
+    cam0 = native.make_camera(scene_mod.orbit_camera(30.0), 160, 90, scene_mod.focal_from_fov_x(160, 0.6911))
+    same_mode = gpu_ctx.render(cam0, native.make_opts(min_transmittance=1e-4, render_mode=native.RENDER_SHADE_GRID_ENVMAP))
+    shade = gpu_ctx.render(cam0, native.make_opts(min_transmittance=1e-4))
+    assert psnr(quirk[..., :3], same_mode[..., :3]) > 45.0  # (the focal length goes through fov in degrees and back)
+    assert psnr(quirk[..., :3], shade[..., :3]) < 30.0 and quirk[..., :3].mean() > shade[..., :3].mean()  # not linearised: brighter
+    testbed.render_mode = pyngp.RenderMode.Shade
     with open(tj) as f:
         ref_transforms = json.load(f)
     for idx, fr in enumerate(ref_transforms["frames"]):
@@ -90,6 +101,7 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     t2 = pyngp.Testbed()
     t2.load_snapshot(str(tmp_path / "again.msgpack"))
     t2.snap_to_pixel_centers = True
+    t2.render_mode = pyngp.RenderMode.Shade
     t2.nerf.render_min_transmittance = 1e-4
     t2.camera_matrix = testbed.camera_matrix
     t2.fov_axis = 0
@@ -132,6 +144,7 @@ def test_run_py_style_session(tmp_path, pyngp, gpu_ctx, native, scene_mod, scene
     assert np.allclose(t3.camera_matrix, testbed.camera_matrix) and t3.fov_axis == testbed.fov_axis and abs(t3.fov - testbed.fov) < 1e-4
     # (settings a snapshot does not store -- pixel-centre snapping, the transmittance threshold -- are set by hand, as in the reference)
     t3.snap_to_pixel_centers = testbed.snap_to_pixel_centers
+    t3.render_mode = testbed.render_mode
     t3.nerf.render_min_transmittance = testbed.nerf.render_min_transmittance
     assert np.array_equal(t3.render(64, 36, 1, True), testbed.render(64, 36, 1, True))
     testbed.render_mode = pyngp.RenderMode.Normals
