@@ -4,8 +4,8 @@
 A step is one frame (1 spp) of the fixed 1080p orbit camera over the Lego-shaped scene (configs[1]: HashGrid
 L8/F4/T19 + 64-wide MLPs; synthetic weights and occupancy, there is no pretrained snapshot in the reference mount).
 With N GPUs the frame's 8x8-pixel camera tiles are dealt round-robin to the ranks (one process per GPU, launched by
-torch.distributed.run) and one RCCL all_gather per frame returns rgba+depth to every rank: total work is fixed, so
-this is strong scaling. Inputs (model, camera) are resident in HBM before the timed region.
+torch.distributed.run) and one RCCL gather per frame brings every rank's tile-packed rgba+depth to rank 0, which scatters the
+tiles into the image: total work is fixed, so this is strong scaling. Inputs (model, camera) are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -228,7 +228,7 @@ def main():
         with torch.cuda.stream(streams[b]):
             ctx.render_device(cams[i % len(cams)], opts, rgba.data_ptr(), depth.data_ptr(), streams[b].cuda_stream)
             if world > 1:
-                return gatherers[b].gather()  # every rank ends the step holding the full frame
+                return gatherers[b].gather(dst=0, rank=rank)  # rank 0 ends the step holding the full frame
         return rgba, depth
 
     def fence():
@@ -282,7 +282,7 @@ def main():
 
     # outside the timed region: the frame the ranks assembled must be the frame one GPU renders alone
     gather_diff = None
-    if world > 1:
+    if world > 1 and rank == 0:
         last = args.steps - 1
         img_g, depth_g = gatherers[last % len(streams)].img.view(h, w, 4), gatherers[last % len(streams)].depth.view(h, w)
         solo_rgba = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
@@ -359,7 +359,7 @@ def main():
                 "samples_per_hit_ray": round(samples_per_frame / max(hits_per_frame, 1.0), 2),
                 "hit_fraction": round(hits_per_frame / n_rays, 4),
                 "samples_per_step": int(samples_per_frame),
-                "tile_sharding": f"8x8 tiles round-robin over {world} rank(s)" + (", all_gather of rgba+depth per frame (RCCL)" if world > 1 else ""),
+                "tile_sharding": f"8x8 tiles round-robin over {world} rank(s)" + (", gather of tile-packed rgba+depth to rank 0 per frame (RCCL send/recv)" if world > 1 else ""),
                 "frames_in_flight": len(streams),
             },
             "roofline": roof,

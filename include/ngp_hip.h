@@ -138,6 +138,14 @@ typedef struct ngp_render_stats {
 /* --- lifetime: Testbed::Testbed / ~Testbed (testbed.h:80-95). device = HIP device ordinal; -1 creates a host-only
  * context that can read/validate/write the file formats but cannot render (there is no CPU renderer). NULL on failure. */
 NGP_API ngp_ctx* ngp_create(int device);
+/* Several GPUs behind one context: Testbed's device list (m_devices, src/testbed.cu:5490-5616 -- a replica per device kept in step
+ * by sync_device, auxiliary devices render on their own streams, peer copies return frame + depth to the primary). devices[0] is
+ * the primary; every other call takes the returned context as if it had one device. ngp_render / ngp_render_device deal the camera's
+ * 8x8 tiles round-robin to the devices, each renders its share tile-packed and pushes it to device 0 (hipMemcpyPeerAsync over xGMI),
+ * which scatters the tiles into the image; nothing waits on the host. NeRF mode. The same ordinal may be listed twice (a rehearsal
+ * of the path on one GPU). NULL on failure. */
+NGP_API ngp_ctx* ngp_create_multi(const int* devices, int n_devices);
+NGP_API int ngp_n_devices(const ngp_ctx* ctx);
 NGP_API void ngp_destroy(ngp_ctx* ctx);
 NGP_API const char* ngp_last_error(const ngp_ctx* ctx);
 NGP_API const char* ngp_version(void);
@@ -198,6 +206,8 @@ NGP_API int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_ren
 NGP_API uint32_t ngp_packed_tiles(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count);
 /* counters + timings of the last ngp_render / ngp_render_device (synchronises the stream) */
 NGP_API int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out);
+/* per device of a multi-device context (0 = primary): the last frame's counters and timings of that device's share */
+NGP_API int ngp_get_device_render_stats(ngp_ctx* ctx, int device_index, ngp_render_stats* out);
 /* the same for the last n calls (oldest first; the context keeps 256), read once after a batch of asynchronous
  * ngp_render_device calls so that measuring does not serialise them */
 NGP_API int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out);

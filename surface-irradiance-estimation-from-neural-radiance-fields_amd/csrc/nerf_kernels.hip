@@ -1120,6 +1120,22 @@ void launch_coarse_occupancy(const uint8_t* bitfield, uint32_t* coarse, hipStrea
 	hipLaunchKernelGGL(coarse_occupancy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bitfield, coarse);
 	hipLaunchKernelGGL(coarse16_occupancy_kernel, dim3(1), dim3(128), 0, stream, coarse);
 }
+// tile gather at the primary device of a multi-device context: pixel (x, y) lives in device (tile % n) 's block at
+// (tile / n) * 64 + slot -- the layout FrameParams::packed writes
+__global__ void unpack_tiles_kernel(const float4* __restrict__ g_rgba, const float* __restrict__ g_depth, uint32_t n_devices, uint32_t n_slots, int width, int height,
+                                    float4* __restrict__ rgba, float* __restrict__ depth) {
+	const uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= (uint32_t)width || y >= (uint32_t)height) return;
+	const uint32_t tile = (y >> 3) * (((uint32_t)width + 7u) >> 3) + (x >> 3);
+	const size_t src = ((size_t)(tile % n_devices) * n_slots + tile / n_devices) * 64u + (x & 7u) + 8u * (y & 7u);
+	rgba[x + (size_t)width * y] = g_rgba[src];
+	depth[x + (size_t)width * y] = g_depth[src];
+}
+void launch_unpack_tiles(const float4* gathered_rgba, const float* gathered_depth, uint32_t n_devices, uint32_t n_slots, int width, int height, float4* rgba, float* depth,
+                         hipStream_t stream) {
+	hipLaunchKernelGGL(unpack_tiles_kernel, dim3((width + 15) / 16, (height + 7) / 8), dim3(16, 8), 0, stream, gathered_rgba, gathered_depth, n_devices, n_slots, width, height,
+	                   rgba, depth);
+}
 void launch_accumulate_tonemap(uint32_t n_pixels, const float4* frame_buffer, float4* accumulate_buffer, float sample_count, const float* background,
                                float exposure, int to_srgb, int color_space, float4* rgba_out, hipStream_t stream) {
 	float4 bg = make_float4(background[0], background[1], background[2], background[3]);

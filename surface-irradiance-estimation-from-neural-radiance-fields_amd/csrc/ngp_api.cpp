@@ -314,6 +314,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	const uint64_t n_grid_expected = (uint64_t)NERF_GRID_N_CELLS * (max_cascade + 1);
 	if (d.n_density_grid != 0 && d.n_density_grid != n_grid_expected) throw std::runtime_error("Incompatible number of grid cascades."); // testbed.cu:5350
 
+	if (ctx->device >= 0) NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight read the tables about to be freed
 	free_model(ctx);
 	ctx->params.assign(d.params_fp16, d.params_fp16 + d.n_params);
 	ctx->density_grid.assign(d.density_grid_fp16, d.density_grid_fp16 + d.n_density_grid);
@@ -407,6 +408,8 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	M.density_act = d.density_activation;
 	ctx->M = M;
 	ctx->model_loaded = true;
+	++ctx->model_generation;
+	ctx->grid_generation = ctx->params_generation = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ snapshot
@@ -1068,11 +1071,14 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		launch_render_nerf(M, C, F, ctx->n_cus, stream);
 		NGP_HIP_CHECK(hipEventRecord(ctx->ev_kern1[slot], stream));
 	}
-	if (!F.direct && ctx->n_calls > 0 && ctx->last_stream && ctx->last_stream != stream) {
-		// the general path goes through the context's own frame / accumulate buffers: a frame on another stream must
-		// have left them (only direct-output frames may overlap each other)
-		NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_frame1[(ctx->n_calls - 1) % ngp_ctx::HISTORY], 0));
+	if (!F.direct && ctx->n_calls > 0 && (ctx->streams_mixed || (ctx->last_stream && ctx->last_stream != stream))) {
+		// the general path goes through the context's own frame / accumulate buffers: frames on other streams must have
+		// left them (only direct-output frames may overlap each other). Several may still be in flight, one event would
+		// not cover them all: wait for the device.
+		NGP_HIP_CHECK(hipDeviceSynchronize());
+		ctx->streams_mixed = false;
 	}
+	if (ctx->last_stream && ctx->last_stream != stream) ctx->streams_mixed = true;
 	for (int s = 0; s < spp && !F.direct; ++s) {
 		CameraParams C = make_camera_params(cam, cam.spp_index + (uint32_t)s);
 		// CudaRenderBufferView::clear (src/render_buffer.cu:603-607)
@@ -1101,6 +1107,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	NGP_HIP_CHECK(hipGetLastError());
 	ctx->last_stream = stream;
 	ctx->hist_n_rays[slot] = (uint64_t)F.n_local_tiles * 64u * (uint64_t)spp;
+	ctx->last_was_multi = false;
 	++ctx->n_calls;
 }
 
@@ -1108,13 +1115,15 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 
 namespace ngp {
 void ensure_sync_buffers(ngp_ctx* ctx) { ensure_frame_buffers(ctx, 0); }
+void render_frames_on(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba, float* d_depth, hipStream_t stream) { render_frames(ctx, cam, opts, d_rgba, d_depth, stream); }
+void ensure_frame_buffers_for(ngp_ctx* ctx, size_t n_pixels) { ensure_frame_buffers(ctx, n_pixels); }
 void install_model(ngp_ctx* ctx, const ngp_model_desc& d) { set_model_impl(ctx, d); }
 uint16_t half_from_float(float f) { return float_to_half(f); }
 void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations) {
 	const uint32_t n_cascades = ctx->max_cascade + 1;
 	const uint32_t n_elements = NERF_GRID_N_CELLS * n_cascades;
 	hipStream_t stream = ctx->stream;
-	if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream)); // frames in flight read the bitfield
+	NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight on ANY stream read the bitfield and its summaries
 	if (!ctx->d_density_tmp) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_tmp, (size_t)n_elements * sizeof(float)));
 	Pcg32 rng;
 	rng.state = ctx->grid_rng_state;
@@ -1140,6 +1149,7 @@ void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, u
 	launch_density_grid_to_bitfield(nullptr, 0, ctx->max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield, &ctx->bitfield_mean, stream);
 	launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, stream);
 	ctx->density_grid_host_dirty = true;
+	++ctx->grid_generation;
 }
 // keep the snapshot copy (fp16, as the reference serialises it) in step
 void refresh_density_grid_host(ngp_ctx* ctx) {
@@ -1198,6 +1208,9 @@ ngp_ctx* ngp_create(int device) {
 
 void ngp_destroy(ngp_ctx* ctx) {
 	if (!ctx) return;
+	for (ngp_ctx* p : ctx->peers) ngp_destroy(p);
+	ctx->peers.clear();
+	if (ctx->device >= 0) ngp::free_multi_buffers(ctx);
 	if (ctx->device < 0) { delete ctx->train; delete ctx; return; }
 	(void)hipSetDevice(ctx->device);
 	if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
@@ -1450,6 +1463,10 @@ int ngp_get_dataset_info(const ngp_ctx* ctx, int32_t* aabb_scale, float* scale, 
 int ngp_render_device(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, void* d_rgba, void* d_depth, void* stream) {
 	return guarded(ctx, [&] {
 		if (!cam || !opts || !d_rgba) throw std::runtime_error("null argument");
+		if (!ctx->peers.empty() && opts->shard_count <= 1) { // a multi-device context: every device renders its tiles, device 0 assembles
+			ngp::render_frames_multi(ctx, *cam, *opts, (float4*)d_rgba, (float*)d_depth, stream ? (hipStream_t)stream : ctx->stream);
+			return;
+		}
 		render_frames(ctx, *cam, *opts, (float4*)d_rgba, (float*)d_depth, stream ? (hipStream_t)stream : ctx->stream);
 	});
 }
@@ -1467,7 +1484,8 @@ int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts,
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 		const size_t n_pixels = (size_t)cam->width * cam->height;
 		ensure_frame_buffers(ctx, n_pixels);
-		render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
+		if (!ctx->peers.empty() && opts->shard_count <= 1) ngp::render_frames_multi(ctx, *cam, *opts, ctx->d_rgba, ctx->d_depth, ctx->stream);
+		else render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
 		// (a destination from ngp_host_alloc is page-locked: the copy is one DMA at the link's rate instead of a staged one)
 		NGP_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_rgba, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
 		if (depth_out) NGP_HIP_CHECK(hipMemcpyAsync(depth_out, ctx->d_depth, n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1554,6 +1572,18 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 		if (!ctx->n_calls) throw std::runtime_error("nothing rendered yet");
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
 		read_history_slot(ctx, ctx->n_calls - 1, out);
+		if (ctx->last_was_multi) { // a frame over several devices: totals over the devices' shares, the slowest share's times
+			for (ngp_ctx* p : ctx->peers) {
+				ngp_render_stats s{};
+				NGP_HIP_CHECK(hipSetDevice(p->device));
+				if (ngp_get_render_stats(p, &s) != 0) throw std::runtime_error(p->error);
+				out->n_rays += s.n_rays; out->n_rays_alive_after_init += s.n_rays_alive_after_init; out->n_rays_hit += s.n_rays_hit; out->n_samples += s.n_samples;
+				out->kernel_ms = std::max(out->kernel_ms, s.kernel_ms);
+				out->frame_ms = std::max(out->frame_ms, s.frame_ms);
+				out->kernel_device_ms = std::max(out->kernel_device_ms, s.kernel_device_ms);
+			}
+			NGP_HIP_CHECK(hipSetDevice(ctx->device));
+		}
 		if (ctx->d_prof && getenv("NGP_PROFILE_SECTIONS")) {
 			unsigned long long p[64];
 			NGP_HIP_CHECK(hipMemcpy(p, ctx->d_prof, sizeof(p), hipMemcpyDeviceToHost));

@@ -233,6 +233,23 @@ struct ngp_ctx {
 	unsigned long long* d_prof = nullptr;
 	int32_t tune[8] = {64, 4, 32, 1, 0, 3, 1, 0}; // FrameParams::tune; changed only through validate_schedule (ngp_api.cpp)
 
+	// ---- several devices behind this context (ngp_multi.cpp): replicas on the auxiliary devices, tile gather at the primary
+	std::vector<ngp_ctx*> peers;  // owned; empty for a single-device context
+	ngp_ctx* primary = nullptr;   // set on a peer
+	uint64_t model_generation = 0, synced_generation = 0;               // the model was replaced (set_model, snapshot)
+	uint64_t grid_generation = 0, synced_grid_generation = 0;           // the occupancy grid was refreshed from the network
+	uint64_t params_generation = 0, synced_params_generation = 0;       // the inference parameters followed a training step
+	float4* d_pack_rgba = nullptr;   // this device's tiles of the current frame, tile-packed
+	float* d_pack_depth = nullptr;
+	size_t pack_alloc = 0;
+	float4* d_gather_rgba = nullptr; // primary: [device][slots * 64]
+	float* d_gather_depth = nullptr;
+	size_t gather_alloc = 0;
+	hipEvent_t ev_pack = nullptr, ev_unpacked = nullptr;
+	uint64_t n_multi_frames = 0;
+	bool last_was_multi = false; // the last frame was rendered over all devices (ngp_get_render_stats sums the shares)
+	bool streams_mixed = false; // frames were issued on more than one stream since the last device-wide wait
+
 	// ---- training (ngp_train.cpp)
 	ngp::TrainState* train = nullptr;
 	bool density_grid_host_dirty = false; // ctx->density_grid lags d_density_f32
@@ -294,6 +311,11 @@ void sync_inference_model(ngp_ctx* ctx); // render what has been trained (no-op 
 void sync_host_params(ngp_ctx* ctx);     // ctx->params <- training parameters, for snapshots
 
 void ensure_sync_buffers(ngp_ctx* ctx);
+// ngp_multi.cpp / ngp_api.cpp
+void render_frames_on(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba, float* d_depth, hipStream_t stream);
+void ensure_frame_buffers_for(ngp_ctx* ctx, size_t n_pixels);
+void render_frames_multi(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba, float* d_depth, hipStream_t stream);
+void free_multi_buffers(ngp_ctx* ctx);
 inline IrradianceMap irradiance_map_of(const ngp_ctx* ctx) {
 	IrradianceMap I{};
 	I.irradiance = ctx->d_irradiance;

@@ -433,7 +433,7 @@ void sync_inference_model(ngp_ctx* ctx) {
 	if (!ctx->train || !ctx->train->inference_dirty || ctx->device < 0 || !ctx->model_loaded) return;
 	TrainState& T = *ctx->train;
 	hipStream_t stream = ctx->stream;
-	if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream)); // frames in flight read the tables
+	NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight on any stream read the tables
 	const uint16_t* src = T.opts.ema_decay > 0.f ? T.d_weights_ema : T.d_weights;
 	const size_t ng = (size_t)T.n_params - T.n_matrix;
 	NGP_HIP_CHECK(hipMemcpyAsync(ctx->d_params, src + T.n_matrix, ng * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
@@ -443,6 +443,7 @@ void sync_inference_model(ngp_ctx* ctx) {
 	NGP_HIP_CHECK(hipStreamSynchronize(stream));
 	NGP_HIP_CHECK(hipGetLastError());
 	T.inference_dirty = false;
+	++ctx->params_generation;
 }
 
 // Trainer::serialize writes the training parameters (fp16), like the reference's snapshots without optimizer state

@@ -86,6 +86,8 @@ PYBIND11_MODULE(pyngp, m) {
 	testbed
 		.def(py::init<ETestbedMode, int>(), py::arg("mode") = ETestbedMode::None, py::arg("device") = 0)
 		.def(py::init<ETestbedMode, const std::string&, int>(), py::arg("mode"), py::arg("data_path"), py::arg("device") = 0)
+		.def(py::init<ETestbedMode, const std::vector<int>&>(), py::arg("mode"), py::arg("devices"), "Several GPUs behind one Testbed: the camera's tiles are dealt to all of them (devices[0] assembles the frame)")
+		.def_property_readonly("n_devices", &Testbed::n_devices)
 		.def("load_training_data", &Testbed::load_training_data, py::call_guard<py::gil_scoped_release>(), "Load training data from a given path.")
 		.def("load_snapshot", &Testbed::load_snapshot, py::arg("path"), "Load a previously saved snapshot")
 		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false, py::arg("compress") = true)

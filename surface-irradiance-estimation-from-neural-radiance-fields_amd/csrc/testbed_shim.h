@@ -64,6 +64,13 @@ public:
 		reset_camera();
 	}
 	Testbed(ETestbedMode mode, const std::string& data_path, int device = 0) : Testbed(mode, device) { load_training_data(data_path); }
+	// m_devices (testbed.h:1211-1253): several GPUs behind this Testbed -- devices[0] is the primary, a frame's camera tiles are dealt to all of them
+	Testbed(ETestbedMode mode, const std::vector<int>& devices) : m_testbed_mode(mode) {
+		m_ctx = devices.empty() ? ngp_create(0) : ngp_create_multi(devices.data(), (int)devices.size());
+		if (!m_ctx) throw std::runtime_error("Testbed: the requested HIP devices are not available (the MI355X renderer has no CPU fallback)");
+		reset_camera();
+	}
+	int n_devices() const { return ngp_n_devices(m_ctx); }
 	~Testbed() { ngp_destroy(m_ctx); }
 	Testbed(const Testbed&) = delete;
 	Testbed& operator=(const Testbed&) = delete;

@@ -135,6 +135,9 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.c_int
     L.ngp_create.argtypes = [ip]; L.ngp_create.restype = vp
+    L.ngp_create_multi.argtypes = [vp, ip]; L.ngp_create_multi.restype = vp
+    L.ngp_n_devices.argtypes = [vp]
+    L.ngp_get_device_render_stats.argtypes = [vp, ip, C.POINTER(RenderStats)]
     L.ngp_destroy.argtypes = [vp]; L.ngp_destroy.restype = None
     L.ngp_last_error.argtypes = [vp]; L.ngp_last_error.restype = C.c_char_p
     L.ngp_version.restype = C.c_char_p
@@ -276,11 +279,24 @@ def make_opts(min_transmittance=0.01, background=(0.0, 0.0, 0.0, 1.0), exposure=
 class Context:
     """One ngp_ctx. Errors from the C ABI become RuntimeError (like the reference's exceptions through pybind11)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one HIP ordinal (-1: host-only). devices: a list of ordinals -> ngp_create_multi (the first is the primary)."""
         self.L = load_library()
-        self.h = self.L.ngp_create(device)
+        if devices is not None:
+            arr = np.asarray(devices, np.int32)
+            self.h = self.L.ngp_create_multi(_p(arr), arr.size)
+        else:
+            self.h = self.L.ngp_create(device)
         if not self.h:
             raise RuntimeError("ngp_create failed: no HIP device available (libngp_hip has no CPU fallback)")
+
+    def n_devices(self):
+        return self.L.ngp_n_devices(self.h)
+
+    def device_render_stats(self, index):
+        st = RenderStats()
+        self._check(self.L.ngp_get_device_render_stats(self.h, index, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in RenderStats._fields_}
 
     def close(self):
         if getattr(self, "h", None):

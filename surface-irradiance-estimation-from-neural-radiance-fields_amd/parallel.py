@@ -3,7 +3,7 @@
 The reference replicates the model on every GPU and assigns whole views round-robin (src/testbed.cu:2487,
 5523-5616, peer copies). Here ONE camera is split into 8x8-pixel tiles, tile t goes to rank t % world_size
 (interleaved, so sky and object tiles are spread evenly), every rank renders its tiles with the fused kernel into
-a full-resolution buffer, packs them, and one all_gather per frame moves 20 B/pixel (rgba + depth) to every rank.
+a tile-packed buffer, and one gather per frame moves each rank's 20 B/pixel (rgba + depth) to rank 0.
 There is no other data-path collective: rays are independent and the model is read-only. `broadcast_snapshot` is the
 one-off distribution of a model that only one rank can read.
 """
@@ -95,7 +95,7 @@ def broadcast_snapshot(ctx, path, rank, src=0, device=None, group=None):
 # ----------------------------------------------------------------------------------------------------------------------
 # Tile-packed path (what bench.py uses for N > 1): the renderer writes this rank's finished pixels straight into the
 # buffer the collective moves (ngp_render_opts.packed_output) -- [n x rgba | n x depth], n = slots * 64 pixels -- so
-# a frame costs: fused kernel -> ONE all_gather_into_tensor of 20 B/pixel -> two index_select that scatter the tiles
+# a frame costs: fused kernel -> ONE gather of 20 B/pixel to rank 0 -> two index_select there that scatter the tiles
 # into the image. Index tables and every buffer are built once; gather() allocates nothing, so instances can be
 # used round-robin on different streams (frame i's gather overlaps frame i+1's render).
 class PackedFrameGather:
@@ -125,13 +125,22 @@ class PackedFrameGather:
         n = self.n
         return self.send[: 4 * n].view(n, 4), self.send[4 * n:]
 
-    def gather(self, group=None):
-        """All-gather what the renderer wrote into buffers(); returns (image (H, W, 4), depth (H, W)) views of
-        buffers that the next gather() of this instance overwrites."""
+    def gather(self, group=None, dst=0, rank=None):
+        """Gather what the renderers wrote into buffers() at rank `dst` (north_star: "RCCL gather over xGMI": grouped
+        ncclSend / ncclRecv, every rank's 20 B/pixel share travels once, on its own link to the root). Returns (image
+        (H, W, 4), depth (H, W)) views of buffers that the next gather() of this instance overwrites on `dst`, None on the
+        other ranks. dst=None: all_gather -- every rank ends up with the frame (world x the bytes)."""
         import torch.distributed as dist
 
         if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send, group=group)
+            if dst is None:
+                dist.all_gather_into_tensor(self.recv, self.send, group=group)
+            else:
+                rank = dist.get_rank(group) if rank is None else rank
+                blocks = list(self.recv.view(self.world, -1).unbind(0)) if rank == dst else None
+                dist.gather(self.send, gather_list=blocks, dst=dst, group=group)
+                if rank != dst:
+                    return None
         else:
             self.recv.copy_(self.send)
         torch.index_select(self.recv.view(-1, 4), 0, self.src_rgba, out=self.img)

@@ -337,7 +337,13 @@ def _gloo_worker(rank, world, port, w, h, q):
             th, tw = min(8, h - y0), min(8, w - x0)
             rgba.view(-1, 8, 8, 4)[slot, :th, :tw] = img_full[y0:y0 + th, x0:x0 + tw]
             depth.view(-1, 8, 8)[slot, :th, :tw] = dep_full[y0:y0 + th, x0:x0 + tw]
-        img, dep = g_.gather()
+        res = g_.gather(dst=0, rank=rank)  # what bench.py does: the frame is assembled at rank 0 only
+        if rank == 0:
+            img, dep = res
+            ok = ok and bool(torch.equal(img, img_full)) and bool(torch.equal(dep, dep_full))
+        else:
+            ok = ok and res is None
+        img, dep = g_.gather(dst=None)  # all_gather: every rank gets the frame
         ok = ok and bool(torch.equal(img, img_full)) and bool(torch.equal(dep, dep_full))
     q.put((rank, ok))
     dist.barrier()

@@ -289,3 +289,48 @@ def test_schedule_knobs_are_validated(native):
     ctx.set_schedule(32, 8, 16, 2, 1, 2, 0)
     ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------- several devices behind one context
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_multi_device_context_assembles_the_single_device_frame(n_dev, native, scene_mod, scene_unit):
+    """ngp_create_multi (Testbed's device list, src/testbed.cu:5490-5616): replicas kept in step by generation, every device
+    renders its tiles tile-packed, peer copies bring them to the primary, which scatters them into the image. Rehearsed on
+    ONE GPU by listing its ordinal several times (separate contexts, streams and buffers; the peer copies are local)."""
+    single = native.Context(0)
+    single.set_model(scene_unit)
+    multi = native.Context(devices=[0] * n_dev)
+    assert multi.n_devices() == n_dev
+    multi.set_model(scene_unit)
+    for (w, h) in ((200, 112), (101, 67)):  # the second: neither a multiple of the tile nor of the device count
+        cam = native.make_camera(scene_mod.orbit_camera(60.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+        ref, ref_depth = single.render(cam, native.make_opts(), want_depth=True)
+        st1 = single.render_stats()
+        img, depth = multi.render(cam, native.make_opts(), want_depth=True)
+        st = multi.render_stats()
+        assert np.array_equal(img, ref) and np.array_equal(depth, ref_depth)
+        assert st["n_rays_hit"] == st1["n_rays_hit"] and st["n_samples"] == st1["n_samples"]
+        shares = [multi.device_render_stats(i)["n_rays"] for i in range(n_dev)]
+        assert sum(shares) == st["n_rays"] and max(shares) - min(shares) <= 64  # tiles dealt round-robin
+    # the replicas follow the primary: a new model, a render box, a refreshed occupancy grid
+    other = dict(scene_unit, render_aabb=((0.1, 0.0, 0.0), (0.9, 1.0, 1.0)))
+    single.set_model(other)
+    multi.set_model(other)
+    cam = native.make_camera(scene_mod.orbit_camera(200.0), 160, 90, scene_mod.focal_from_fov_x(160, 0.6911))
+    assert np.array_equal(multi.render(cam), single.render(cam))
+    single.set_render_aabb((0.0, 0.0, 0.2), (1.0, 1.0, 0.8))
+    multi.set_render_aabb((0.0, 0.0, 0.2), (1.0, 1.0, 0.8))
+    assert np.array_equal(multi.render(cam), single.render(cam))
+    single.update_density_grid(0.95, 1 << 18, 1 << 16, 2)
+    multi.update_density_grid(0.95, 1 << 18, 1 << 16, 2)
+    assert np.array_equal(multi.render(cam), single.render(cam))
+    # several samples per pixel and sRGB output go through the same assembly
+    o = native.make_opts(spp=3, to_srgb=True, background=(0.2, 0.3, 0.4, 1.0))
+    a, b = multi.render(native.make_camera(scene_mod.orbit_camera(200.0), 96, 54, scene_mod.focal_from_fov_x(96, 0.6911), snap=False), o), None
+    b = single.render(native.make_camera(scene_mod.orbit_camera(200.0), 96, 54, scene_mod.focal_from_fov_x(96, 0.6911), snap=False), o)
+    assert np.abs(a - b).max() < 1e-6
+    with pytest.raises(RuntimeError, match="multi-device context renders NeRF mode"):
+        multi.render(cam, native.make_opts(testbed_mode=native.MODE_GEOMETRY))
+    multi.close()
+    single.close()

@@ -379,6 +379,7 @@ def test_pyngp_and_cli_train_a_png_dataset(native, dataset, scene_mod, tmp_path)
     scene_mod.write_transforms(str(tmp_path / "transforms.json"), dataset["mats"], W, H, FOV)
     ngp = pkg("build").import_pyngp()
     testbed = ngp.Testbed()
+    testbed.render_mode = ngp.RenderMode.Shade  # (the fork's default, ShadeGridEnvMap, leaves NeRF colours un-linearised: tests/test_pyngp.py)
     testbed.load_training_data(str(tmp_path))
     assert testbed.nerf.training.n_images_for_training == len(POSES) and testbed.nerf.training.loss_type == ngp.LossType.Huber
     testbed.training_batch_size = 1 << 16
