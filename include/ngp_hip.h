@@ -27,7 +27,7 @@ typedef struct ngp_ctx ngp_ctx;
 enum ngp_activation { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
 
 /* ERenderMode subset (common.h:58-72). Only Shade is on the hot path; AO..Cost are "next" (SURVEY 8f-3). */
-/* ELensMode, common.h:223-230 (FTheta is not implemented) */
+/* ELensMode, common.h:223-230 */
 enum ngp_lens_mode { NGP_LENS_PERSPECTIVE = 0, NGP_LENS_OPENCV = 1, NGP_LENS_FTHETA = 2, NGP_LENS_LATLONG = 3, NGP_LENS_OPENCV_FISHEYE = 4, NGP_LENS_EQUIRECTANGULAR = 5 };
 
 enum ngp_render_mode {
@@ -88,12 +88,21 @@ typedef struct ngp_camera {
 	int32_t snap_to_pixel_centers;
 	float near_distance;    /* m_render_near_distance */
 	/* m_nerf.render_lens when m_nerf.render_with_lens_distortion (uv_to_ray, common_device.cuh:416-483): ngp_lens_mode +
-	 * parameters (OpenCV: k1 k2 p1 p2; OpenCVFisheye: k1 k2 k3 k4). All zero = perspective. */
+	 * parameters (OpenCV: k1 k2 p1 p2; OpenCVFisheye: k1 k2 k3 k4; FTheta: r0..r4 of the angle polynomial, then the resolution
+	 * x, y the intrinsics refer to -- f_theta_undistortion, common_device.cuh:361-375). All zero = perspective. */
 	int32_t lens_mode;
 	float lens_params[7];
 	/* depth of field (uv_to_ray, common_device.cuh:471-477): m_aperture_size and the focus distance plane_z = m_slice_plane_z + m_scale
 	 * (src/testbed_nerf.cu:2342); aperture_size 0 or focus_z < 0 = pinhole */
 	float aperture_size, focus_z;
+	/* camera_matrix1 and rolling_shutter of Testbed::render_frame (testbed.h:561-575): when has_matrix1 is set and matrix1 differs
+	 * from matrix (= camera_matrix0), every pixel is rendered by the camera of its own time
+	 *   t = rolling_shutter[0] + [1] u + [2] v + [3] ld_random_val(spp_index, pixel * 72239731),  camera_slerp(matrix, matrix1, t)
+	 * (get_xform_given_rolling_shutter, common_device.cuh:651-659; src/testbed_nerf.cu:1468) and depth is measured along matrix1.
+	 * rolling_shutter (0, 0, 0, 1) -- what Testbed::render passes -- is motion blur over the whole interval. NeRF mode. */
+	int32_t has_matrix1;
+	float matrix1[12];
+	float rolling_shutter[4];
 } ngp_camera;
 
 typedef struct ngp_render_opts {
@@ -229,6 +238,11 @@ NGP_API int ngp_get_density_bitfield(ngp_ctx* ctx, uint8_t* out, float* out_mean
 /* m_render_aabb / m_render_aabb_to_local (python_api.cu: testbed.render_aabb, .render_aabb_to_local): the crop box of the render,
  * min/max in ngp space; to_local9 column-major mat3 or NULL for identity */
 NGP_API int ngp_set_render_aabb(ngp_ctx* ctx, const float* min3, const float* max3, const float* to_local9);
+/* m_envmap (testbed.h:1297-1316; filled from the dataset's environment image or trained, src/testbed.cu:4194-4208): a lat-long RGBA
+ * radiance map of width x height texels behind the NeRF. Every pixel with a valid ray starts from read_envmap(map, ray direction)
+ * (envmap.cuh:24-50: bilinear, x periodic, y clamped; src/testbed_nerf.cu:1526-1528) and the NeRF is composited over it. NeRF mode.
+ * rgba = NULL (or a zero size) removes the map. */
+NGP_API int ngp_set_envmap(ngp_ctx* ctx, int32_t width, int32_t height, const float* rgba);
 /* m_nerf.cone_angle_constant (python_api.cu: testbed.nerf.cone_angle_constant, run.py:167): 0 = fixed step size */
 NGP_API int ngp_set_cone_angle_constant(ngp_ctx* ctx, float cone_angle_constant);
 /* Testbed::update_density_grid_nerf (src/testbed_nerf.cu:2772-2861; kernels :185-232, :253-276): refresh the occupancy

@@ -69,7 +69,16 @@ typedef struct orc_camera {
 	float lens_params[7]; /* OpenCV: k1 k2 p1 p2; fisheye: k1 k2 k3 k4 */
 	float aperture_size;  /* depth of field (uv_to_ray, common_device.cuh:471-477); 0 = pinhole */
 	float focus_z;        /* plane_z = m_slice_plane_z + m_scale */
+	/* camera_matrix1 + rolling_shutter of Testbed::render_frame: when has_matrix1 is set (and matrix1 differs from matrix), pixel (u, v)
+	 * is rendered by camera_slerp(matrix, matrix1, rs.x + rs.y u + rs.z v + rs.w ld_random_val(spp, idx * 72239731))
+	 * (get_xform_given_rolling_shutter, common_device.cuh:651-659); depth is measured along matrix1 (src/testbed_nerf.cu:2412).
+	 * tcnn's slerp(mat3, mat3, t) is not in the mount: restated from the GLM-derived quat_cast / slerp / mat3_cast its vec.h is built on. */
+	int32_t has_matrix1;
+	float matrix1[12];
+	float rolling_shutter[4];
 } orc_camera;
+/* the camera of one pixel of such a frame (out12: column-major 4x3) */
+void orc_camera_at_pixel(const orc_camera* cam, float u, float v, uint32_t idx, float* out12);
 
 /* camera-space direction of image coordinate (u, v) under the camera's lens (uv_to_ray, common_device.cuh:441-462) */
 void orc_lens_direction(const orc_camera* cam, float u, float v, float* dir3);
@@ -84,7 +93,10 @@ typedef struct orc_render_opts {
 	int32_t n_threads;            /* OpenMP threads, <=0: all */
 	int32_t render_mode;          /* 0/1 Shade; 2 AO, 3 Positions, 4 Depth (composite_kernel_nerf, testbed_nerf.cu:689-702) */
 	float depth_scale;            /* Depth mode: 1 / dataset scale */
+	const float* envmap;          /* m_envmap.inference_view(): env_w x env_h RGBA, lat-long (read_envmap, envmap.cuh:24-50); NULL = none */
+	int32_t env_w, env_h;
 } orc_render_opts;
+void orc_read_envmap(const float* envmap, int32_t res_x, int32_t res_y, const float* dir3, float* out4);
 
 typedef struct orc_render_stats {
 	uint64_t n_rays;

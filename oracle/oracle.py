@@ -68,6 +68,9 @@ class Camera(C.Structure):
         ("lens_params", C.c_float * 7),
         ("aperture_size", C.c_float),
         ("focus_z", C.c_float),
+        ("has_matrix1", C.c_int32),
+        ("matrix1", C.c_float * 12),
+        ("rolling_shutter", C.c_float * 4),
     ]
 
 
@@ -80,6 +83,9 @@ class RenderOpts(C.Structure):
         ("n_threads", C.c_int32),
         ("render_mode", C.c_int32),
         ("depth_scale", C.c_float),
+        ("envmap", C.c_void_p),
+        ("env_w", C.c_int32),
+        ("env_h", C.c_int32),
     ]
 
 
@@ -285,7 +291,8 @@ class Oracle:
         return out
 
     @staticmethod
-    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0):
+    def make_camera(matrix_4x3, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0,
+                    matrix1_4x3=None, rolling_shutter=(0.0, 0.0, 0.0, 1.0)):
         """matrix_4x3: numpy (3,4) [R|t] camera-to-world in NGP convention."""
         cam = Camera()
         mat = np.asarray(matrix_4x3, np.float32)
@@ -303,10 +310,18 @@ class Oracle:
         for i, q in enumerate(lens_params):
             cam.lens_params[i] = q
         cam.aperture_size, cam.focus_z = aperture_size, focus_z
+        if matrix1_4x3 is not None:
+            m1 = np.asarray(matrix1_4x3, np.float32)
+            cam.has_matrix1 = 1
+            for c in range(4):
+                for r in range(3):
+                    cam.matrix1[c * 3 + r] = m1[r, c]
+            for i in range(4):
+                cam.rolling_shutter[i] = rolling_shutter[i]
         return cam
 
     @staticmethod
-    def make_opts(min_transmittance=0.01, linear_colors=False, depth_test=False, capped_skip=False, n_threads=0, render_mode=0, depth_scale=1.0 / 0.33):
+    def make_opts(min_transmittance=0.01, linear_colors=False, depth_test=False, capped_skip=False, n_threads=0, render_mode=0, depth_scale=1.0 / 0.33, envmap=None):
         o = RenderOpts()
         o.min_transmittance = min_transmittance
         o.train_in_linear_colors = int(linear_colors)
@@ -315,6 +330,10 @@ class Oracle:
         o.n_threads = n_threads
         o.render_mode = render_mode
         o.depth_scale = depth_scale
+        if envmap is not None:  # (H, W, 4) lat-long radiance behind the NeRF
+            env = np.ascontiguousarray(envmap, np.float32)
+            o._keep = env
+            o.envmap, o.env_w, o.env_h = env.ctypes.data, env.shape[1], env.shape[0]
         return o
 
     def init_rays(self, m, cam, advance=True):

@@ -574,6 +574,17 @@ static v3 lens_direction(const orc_camera* cam, float u, float v) {
 		float phi = (u - 0.5f) * PI * 2.0f;
 		return v3_make(sinf(phi) * st, ct, cosf(phi) * st);
 	}
+	if (cam->lens_mode == 2) { /* FTheta: f_theta_undistortion(uv - screen_center, params, error_direction = 0), common_device.cuh:361-375, 441-446.
+	                            * params: polynomial r0..r4 of the angle in the pixel radius, then the resolution the intrinsics were given at */
+		const float* q = cam->lens_params;
+		float xpix = (u - cam->screen_center[0]) * q[5], ypix = (v - cam->screen_center[1]) * q[6];
+		float norm = sqrtf(xpix * xpix + ypix * ypix);
+		float alpha = q[0] + norm * (q[1] + norm * (q[2] + norm * (q[3] + norm * q[4])));
+		float sin_alpha = sinf(alpha), cos_alpha = cosf(alpha);
+		if (cos_alpha <= FLT_MIN || norm == 0.f) return v3_make(0.f, 0.f, 0.f); /* Ray::invalid() */
+		sin_alpha *= 1.f / norm;
+		return v3_make(sin_alpha * xpix, sin_alpha * ypix, cos_alpha);
+	}
 	v3 dir = v3_make((u - cam->screen_center[0]) * (float)cam->width / cam->focal_length[0],
 	                 (v - cam->screen_center[1]) * (float)cam->height / cam->focal_length[1], 1.0f);
 	if (cam->lens_mode == 1) lens_undistort(0, cam->lens_params, &dir.x, &dir.y);
@@ -606,19 +617,71 @@ void orc_apply_aperture(const orc_camera* cam, float u, float v, float* origin3,
 	dir3[0] = dir.x; dir3[1] = dir.y; dir3[2] = dir.z;
 }
 
+static int camera_moves(const orc_camera* cam) { return cam->has_matrix1 && memcmp(cam->matrix, cam->matrix1, sizeof(cam->matrix)) != 0; }
+static void quat_cast(const float* m, float* q /* w x y z */) { /* m[3 c + r] */
+	const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+	const float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
+	int biggest = 0;
+	float fb = fw;
+	if (fx > fb) { fb = fx; biggest = 1; }
+	if (fy > fb) { fb = fy; biggest = 2; }
+	if (fz > fb) { fb = fz; biggest = 3; }
+	const float bv = sqrtf(fb + 1.0f) * 0.5f, mult = 0.25f / bv;
+	if (biggest == 0) { q[0] = bv; q[1] = (m12 - m21) * mult; q[2] = (m20 - m02) * mult; q[3] = (m01 - m10) * mult; }
+	else if (biggest == 1) { q[0] = (m12 - m21) * mult; q[1] = bv; q[2] = (m01 + m10) * mult; q[3] = (m20 + m02) * mult; }
+	else if (biggest == 2) { q[0] = (m20 - m02) * mult; q[1] = (m01 + m10) * mult; q[2] = bv; q[3] = (m12 + m21) * mult; }
+	else { q[0] = (m01 - m10) * mult; q[1] = (m20 + m02) * mult; q[2] = (m12 + m21) * mult; q[3] = bv; }
+}
+void orc_camera_at_pixel(const orc_camera* cam, float u, float v, uint32_t idx, float* out12) {
+	if (!camera_moves(cam)) { memcpy(out12, cam->matrix, sizeof(cam->matrix)); return; }
+	const float* rs = cam->rolling_shutter;
+	const float t = rs[0] + rs[1] * u + rs[2] * v + rs[3] * orc_ld_random_val(cam->spp_index, idx * 72239731u, 0);
+	float qa[4], qb[4], q[4];
+	quat_cast(cam->matrix, qa);
+	quat_cast(cam->matrix1, qb);
+	float cos_theta = ((qa[0] * qb[0] + qa[1] * qb[1]) + qa[2] * qb[2]) + qa[3] * qb[3];
+	if (cos_theta < 0.0f) {
+		for (int i = 0; i < 4; ++i) qb[i] = -qb[i];
+		cos_theta = -cos_theta;
+	}
+	if (cos_theta > 1.0f - 1.1920929e-07f) {
+		for (int i = 0; i < 4; ++i) q[i] = qa[i] + (qb[i] - qa[i]) * t;
+	} else {
+		const float angle = acosf(cos_theta);
+		const float sa = sinf((1.0f - t) * angle), sb = sinf(t * angle), sn = sinf(angle);
+		for (int i = 0; i < 4; ++i) q[i] = (sa * qa[i] + sb * qb[i]) / sn;
+	}
+	const float len = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+	const float w = q[0] / len, x = q[1] / len, y = q[2] / len, z = q[3] / len;
+	const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+	out12[0] = 1.0f - 2.0f * (yy + zz); out12[1] = 2.0f * (xy + wz); out12[2] = 2.0f * (xz - wy);
+	out12[3] = 2.0f * (xy - wz); out12[4] = 1.0f - 2.0f * (xx + zz); out12[5] = 2.0f * (yz + wx);
+	out12[6] = 2.0f * (xz + wy); out12[7] = 2.0f * (yz - wx); out12[8] = 1.0f - 2.0f * (xx + yy);
+	for (int i = 0; i < 3; ++i) out12[9 + i] = cam->matrix[9 + i] * (1.0f - t) + cam->matrix1[9 + i] * t;
+}
+static void init_ray_dir(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload, float* unit_dir3);
 void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload) {
+	float d3[3];
+	init_ray_dir(m, cam, x, y, payload, d3);
+}
+/* unit_dir3: the normalised ray direction of the pixel ((0,0,0) for a pixel without a ray) -- the reference reads the
+ * environment map along it before the render-box test (src/testbed_nerf.cu:1524-1528), the payload keeps it only for rays that enter the box */
+static void init_ray_dir(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, uint32_t y, orc_payload* payload, float* unit_dir3) {
 	const prepared_t* p = (const prepared_t*)m->prepared;
+	unit_dir3[0] = unit_dir3[1] = unit_dir3[2] = 0.0f;
 	uint32_t idx = x + (uint32_t)cam->width * y;
 	float off[2];
 	orc_ld_random_pixel_offset(cam->snap_to_pixel_centers ? 0u : cam->spp_index, off);
 	float u = ((float)x + off[0]) / (float)cam->width;
 	float v = ((float)y + off[1]) / (float)cam->height;
 	v3 dir = lens_direction(cam, u, v);
-	dir = m3_mulv(cam->matrix, dir);
-	v3 origin = v3_make(cam->matrix[9], cam->matrix[10], cam->matrix[11]);
+	orc_camera pc = *cam; /* the camera of this pixel (src/testbed_nerf.cu:1468) */
+	orc_camera_at_pixel(cam, u, v, idx, pc.matrix);
+	dir = m3_mulv(pc.matrix, dir);
+	v3 origin = v3_make(pc.matrix[9], pc.matrix[10], pc.matrix[11]);
 	{
 		float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z};
-		orc_apply_aperture(cam, u, v, o3, d3);
+		orc_apply_aperture(&pc, u, v, o3, d3);
 		origin = v3_make(o3[0], o3[1], o3[2]);
 		dir = v3_make(d3[0], d3[1], d3[2]);
 	}
@@ -632,6 +695,7 @@ void orc_init_ray(const orc_nerf_model* m, const orc_camera* cam, uint32_t x, ui
 		return;
 	}
 	dir = v3_normalize(dir);
+	unit_dir3[0] = dir.x; unit_dir3[1] = dir.y; unit_dir3[2] = dir.z;
 	float tmin, tmax;
 	aabb_ray_intersect(&p->render_aabb, m3_mulv(m->render_aabb_to_local, origin), m3_mulv(m->render_aabb_to_local, dir), &tmin, &tmax);
 	float t = fmaxf(tmin, 0.0f) + 1e-6f;
@@ -774,6 +838,30 @@ static void shade_one(const orc_render_opts* o, const float* rgba, float depth, 
 	if (tmp[3] > 0.2f) depth_buffer[idx] = depth;
 }
 
+/* read_envmap, envmap.cuh:24-50, with dir_to_spherical_unorm (random_val.cuh:62-72): bilinear, x wraps, y clamps */
+void orc_read_envmap(const float* envmap, int32_t res_x, int32_t res_y, const float* dir3, float* out4) {
+	const float PI = 3.14159265358979323846f;
+	const float dx = dir3[2], dy = -dir3[0], dz = dir3[1];
+	const float cos_theta = fminf(fmaxf(dz, -1.0f), 1.0f);
+	const float theta = acosf(cos_theta);
+	const float phi = atan2f(dy, dx);
+	const float cyl_x = theta / PI, cyl_y = phi / (2.0f * PI) + 0.5f;
+	const float fx = cyl_y * (float)(res_x - 1), fy = cyl_x * (float)(res_y - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	const float* v[4];
+	for (int k = 0; k < 4; ++k) {
+		int px = tx + (k & 1), py = ty + (k >> 1);
+		if (px < 0) px += res_x;
+		else if (px >= res_x) px -= res_x;
+		py = py > res_y - 1 ? res_y - 1 : py;
+		py = py < 0 ? 0 : py;
+		v[k] = envmap + 4 * ((size_t)px + (size_t)py * res_x);
+	}
+	const float w00 = (1 - wx) * (1 - wy), w10 = wx * (1 - wy), w01 = (1 - wx) * wy, w11 = wx * wy;
+	for (int c = 0; c < 4; ++c) out4[c] = ((w00 * v[0][c] + w10 * v[1][c]) + w01 * v[2][c]) + w11 * v[3][c];
+}
+
 void orc_render_nerf(const orc_nerf_model* m, const orc_camera* cam, const orc_render_opts* o, float* frame_buffer, float* depth_buffer, orc_render_stats* stats) {
 	const int64_t n_pixels = (int64_t)cam->width * cam->height;
 	uint64_t n_alive = 0, n_hit = 0, n_samples = 0;
@@ -784,15 +872,17 @@ void orc_render_nerf(const orc_nerf_model* m, const orc_camera* cam, const orc_r
 	for (int64_t i = 0; i < n_pixels; ++i) {
 		uint32_t x = (uint32_t)(i % cam->width), y = (uint32_t)(i / cam->width);
 		orc_payload payload;
-		orc_init_ray(m, cam, x, y, &payload);
+		float d3[3];
+		init_ray_dir(m, cam, x, y, &payload, d3);
 		/* testbed_nerf.cu:1490-1493 */
 		if (depth_buffer[i] < 0.01f) depth_buffer[i] = MAX_DEPTH;
+		if (o->envmap && (d3[0] != 0.0f || d3[1] != 0.0f || d3[2] != 0.0f)) orc_read_envmap(o->envmap, o->env_w, o->env_h, d3, frame_buffer + 4 * i); /* :1526-1528 */
 		orc_advance_pos(m, cam, &payload);
 		if (!payload.alive) continue;
 		++n_alive;
 		float rgba[4] = {0, 0, 0, 0};
 		float depth = 0.0f;
-		n_samples += orc_trace_ray(m, cam->matrix, o, &payload, rgba, &depth);
+		n_samples += orc_trace_ray(m, camera_moves(cam) ? cam->matrix1 : cam->matrix, o, &payload, rgba, &depth); /* depth along camera_matrix1 (:2412) */
 		/* compact_kernel_nerf (:1403-1426): dead rays with alpha > 0.001 reach shading; rays that are
 		 * still alive when the march loop ends never do. */
 		if (!payload.alive && rgba[3] > 0.001f) {

@@ -237,6 +237,7 @@ __global__ void render_mesh_fused(const MeshSceneParams S, const MeshShadeParams
 	if (tile % shard_count != shard_index) return;
 	// tile-packed layout: local tile q = tile / shard_count, slot = (x & 7) + 8 * (y & 7)
 	const uint32_t idx = packed ? (tile / shard_count) * 64u + (x & 7u) + 8u * (y & 7u) : x + (uint32_t)C.width * y;
+	if (C.moving) return; // (a moving camera is a NeRF-mode feature here; the host refuses the combination)
 	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
 	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
 	// M1: init_rays_with_payload_kernel_mesh_geometry (:488-579)

@@ -360,6 +360,17 @@ __device__ __attribute__((noinline)) void lens_direction_general(int lens_mode, 
 	if (lens_mode == 3) { // LatLong
 		float theta = (v - 0.5f) * PI, phi = (u - 0.5f) * PI * 2.0f;
 		dir = mk3(sinf(phi) * cosf(theta), sinf(theta), cosf(phi) * cosf(theta));
+	} else if (lens_mode == 2) { // FTheta: f_theta_undistortion(uv - screen_center, params, {0, 0, 0}) (common_device.cuh:361-375); sx, sy carry uv - screen_center here
+		float xpix = sx * lens_params[5], ypix = sy * lens_params[6];
+		float norm = __builtin_sqrtf(xpix * xpix + ypix * ypix);
+		float alpha = lens_params[0] + norm * (lens_params[1] + norm * (lens_params[2] + norm * (lens_params[3] + norm * lens_params[4])));
+		float sin_alpha = sinf(alpha), cos_alpha = cosf(alpha);
+		if (cos_alpha <= 1.17549435e-38f || norm == 0.f) {
+			dir = mk3(0.f, 0.f, 0.f); // Ray::invalid(): the zero direction marks the pixel dead downstream
+		} else {
+			sin_alpha *= 1.f / norm;
+			dir = mk3(sin_alpha * xpix, sin_alpha * ypix, cos_alpha);
+		}
 	} else if (lens_mode == 5) { // Equirectangular
 		float ct = (v - 0.5f) * 2.0f;
 		float st = __builtin_sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
@@ -377,7 +388,8 @@ NGP_DEV bool lens_direction(const CameraParams& C, float u, float v, f3& dir) {
 	if (C.lens_mode != 0) {
 		float q[7], o[3];
 		for (int i = 0; i < 7; ++i) q[i] = C.lens_params[i];
-		lens_direction_general(C.lens_mode, q, u, v, dir.x, dir.y, o);
+		if (C.lens_mode == 2) lens_direction_general(C.lens_mode, q, u, v, u - C.screen_center[0], v - C.screen_center[1], o);
+		else lens_direction_general(C.lens_mode, q, u, v, dir.x, dir.y, o);
 		dir = mk3(o[0], o[1], o[2]);
 	}
 	return true;
@@ -412,22 +424,114 @@ __device__ __attribute__((noinline)) void apply_aperture(const float* cam_m, flo
 	dir3[0] = dir.x; dir3[1] = dir.y; dir3[2] = dir.z;
 }
 
+// get_xform_given_rolling_shutter (common_device.cuh:656-659): the camera of ONE pixel of a frame whose camera moves from
+// camera0 to camera1 -- pixel_t = rs.x + rs.y u + rs.z v + rs.w motionblur_time, camera_slerp(camera0, camera1, pixel_t)
+// (:651-654: rotation slerp, position mix). tcnn's slerp(mat3, mat3, t) (vec.h, not in the reference mount) is the GLM-derived
+// trio quat_cast -> slerp -> normalize -> mat3_cast, restated here. Out of line: only moving frames come here.
+__device__ __attribute__((noinline)) void camera_at_pixel(const float* m0, const float* m1, const float* rs, float u, float v, float motionblur_time, float* out12) {
+	const float t = rs[0] + rs[1] * u + rs[2] * v + rs[3] * motionblur_time;
+	auto quat_cast = [](const float* m, float* q /* w x y z */) { // m[3 c + r]
+		const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+		const float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
+		int biggest = 0;
+		float fb = fw;
+		if (fx > fb) { fb = fx; biggest = 1; }
+		if (fy > fb) { fb = fy; biggest = 2; }
+		if (fz > fb) { fb = fz; biggest = 3; }
+		const float bv = __builtin_sqrtf(fb + 1.0f) * 0.5f, mult = 0.25f / bv;
+		if (biggest == 0) { q[0] = bv; q[1] = (m12 - m21) * mult; q[2] = (m20 - m02) * mult; q[3] = (m01 - m10) * mult; }
+		else if (biggest == 1) { q[0] = (m12 - m21) * mult; q[1] = bv; q[2] = (m01 + m10) * mult; q[3] = (m20 + m02) * mult; }
+		else if (biggest == 2) { q[0] = (m20 - m02) * mult; q[1] = (m01 + m10) * mult; q[2] = bv; q[3] = (m12 + m21) * mult; }
+		else { q[0] = (m01 - m10) * mult; q[1] = (m20 + m02) * mult; q[2] = (m12 + m21) * mult; q[3] = bv; }
+	};
+	float qa[4], qb[4], q[4];
+	quat_cast(m0, qa);
+	quat_cast(m1, qb);
+	float cos_theta = ((qa[0] * qb[0] + qa[1] * qb[1]) + qa[2] * qb[2]) + qa[3] * qb[3];
+	if (cos_theta < 0.0f) { // the short way round
+		for (int i = 0; i < 4; ++i) qb[i] = -qb[i];
+		cos_theta = -cos_theta;
+	}
+	if (cos_theta > 1.0f - 1.1920929e-07f) {
+		for (int i = 0; i < 4; ++i) q[i] = qa[i] + (qb[i] - qa[i]) * t;
+	} else {
+		const float angle = acosf(cos_theta);
+		const float sa = sinf((1.0f - t) * angle), sb = sinf(t * angle), s = sinf(angle);
+		for (int i = 0; i < 4; ++i) q[i] = (sa * qa[i] + sb * qb[i]) / s;
+	}
+	const float len = __builtin_sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+	const float w = q[0] / len, x = q[1] / len, y = q[2] / len, z = q[3] / len;
+	const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+	out12[0] = 1.0f - 2.0f * (yy + zz); out12[1] = 2.0f * (xy + wz); out12[2] = 2.0f * (xz - wy);
+	out12[3] = 2.0f * (xy - wz); out12[4] = 1.0f - 2.0f * (xx + zz); out12[5] = 2.0f * (yz + wx);
+	out12[6] = 2.0f * (xz + wy); out12[7] = 2.0f * (yz - wx); out12[8] = 1.0f - 2.0f * (xx + yy);
+	for (int i = 0; i < 3; ++i) out12[9 + i] = m0[9 + i] * (1.0f - t) + m1[9 + i] * t; // mix(a, b, t) = a (1 - t) + b t
+}
+
+// read_envmap (envmap.cuh:24-50): bilinear lat-long lookup of the environment map behind the NeRF, direction ->
+// dir_to_spherical_unorm({d.z, -d.x, d.y}) (random_val.cuh:62-72); x wraps, y clamps. Out of line: acosf / atan2f must not
+// carry their registers into the persistent kernel, which only comes here when an environment map is set.
+__device__ __attribute__((noinline)) void read_envmap(const float4* __restrict__ envmap, int res_x, int res_y, const float* dir3, float* out4) {
+	const float PI = 3.14159265358979323846f;
+	const float dx = dir3[2], dy = -dir3[0], dz = dir3[1];
+	const float cos_theta = fminf(fmaxf(dz, -1.0f), 1.0f);
+	const float theta = acosf(cos_theta);
+	const float phi = atan2f(dy, dx);
+	const float cyl_x = theta / PI, cyl_y = phi / (2.0f * PI) + 0.5f;
+	const float fx = cyl_y * (float)(res_x - 1), fy = cyl_x * (float)(res_y - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	auto read_val = [&](int px, int py) {
+		if (px < 0) px += res_x;
+		else if (px >= res_x) px -= res_x;
+		py = py > res_y - 1 ? res_y - 1 : py;
+		py = py < 0 ? 0 : py;
+		return envmap[px + (size_t)py * res_x];
+	};
+	const float4 v00 = read_val(tx, ty), v10 = read_val(tx + 1, ty), v01 = read_val(tx, ty + 1), v11 = read_val(tx + 1, ty + 1);
+	const float w00 = (1 - wx) * (1 - wy), w10 = wx * (1 - wy), w01 = (1 - wx) * wy, w11 = wx * wy;
+	out4[0] = ((w00 * v00.x + w10 * v10.x) + w01 * v01.x) + w11 * v11.x;
+	out4[1] = ((w00 * v00.y + w10 * v10.y) + w01 * v01.y) + w11 * v11.y;
+	out4[2] = ((w00 * v00.z + w10 * v10.z) + w01 * v01.z) + w11 * v11.z;
+	out4[3] = ((w00 * v00.w + w10 * v10.w) + w01 * v01.w) + w11 * v11.w;
+}
+
+// PLAIN: a static pinhole camera without depth of field (what a benchmark / screenshot frame is): the instantiation carries none of
+// the lens, aperture and moving-camera code, whose out-of-line calls and per-lane arrays cost the persistent kernel registers
+template <bool PLAIN = false>
 NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, uint32_t y, RayState& r) {
 	r.idx = x + (uint32_t)C.width * y;
 	r.out = r.idx;
 	float u = ((float)x + C.pixel_offset[0]) / (float)C.width;
 	float v = ((float)y + C.pixel_offset[1]) / (float)C.height;
 	f3 dir;
-	lens_direction(C, u, v, dir);
-	dir = m3_mulv(C.m, dir);
-	f3 origin = mk3(C.m[9], C.m[10], C.m[11]);
-	if (C.aperture_size != 0.0f) {
-		float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z}, cm[6];
-		for (int i = 0; i < 6; ++i) cm[i] = C.m[i];
-		// px = ivec2(uv * resolution)
-		apply_aperture(cm, C.aperture_size, C.focus_z, C.spp, (uint32_t)(int)(u * (float)C.width) * 19349663u + (uint32_t)(int)(v * (float)C.height) * 96925573u, o3, d3);
-		origin = mk3(o3[0], o3[1], o3[2]);
-		dir = mk3(d3[0], d3[1], d3[2]);
+	if (PLAIN) dir = mk3((u - C.screen_center[0]) * (float)C.width / C.focal[0], (v - C.screen_center[1]) * (float)C.height / C.focal[1], 1.0f);
+	else lens_direction(C, u, v, dir);
+	f3 origin;
+	if (PLAIN || !C.moving) { // (the static frame reads the camera from the kernel arguments: no per-lane copy of the matrix)
+		dir = m3_mulv(C.m, dir);
+		origin = mk3(C.m[9], C.m[10], C.m[11]);
+		if (!PLAIN && C.aperture_size != 0.0f) {
+			float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z}, cm[6];
+			for (int i = 0; i < 6; ++i) cm[i] = C.m[i];
+			// px = ivec2(uv * resolution)
+			apply_aperture(cm, C.aperture_size, C.focus_z, C.spp, (uint32_t)(int)(u * (float)C.width) * 19349663u + (uint32_t)(int)(v * (float)C.height) * 96925573u, o3, d3);
+			origin = mk3(o3[0], o3[1], o3[2]);
+			dir = mk3(d3[0], d3[1], d3[2]);
+		}
+	} else { // the camera of this pixel (rolling shutter / motion blur): init_rays_with_payload_kernel_nerf, src/testbed_nerf.cu:1468
+		float cam[12], m0[12], m1[12], rs[4];
+		for (int i = 0; i < 12; ++i) { m0[i] = C.m[i]; m1[i] = C.m1[i]; }
+		for (int i = 0; i < 4; ++i) rs[i] = C.rolling_shutter[i];
+		camera_at_pixel(m0, m1, rs, u, v, ld_random_val_dim0(C.spp, r.idx * 72239731u), cam);
+		dir = m3_mulv(cam, dir);
+		origin = mk3(cam[9], cam[10], cam[11]);
+		if (C.aperture_size != 0.0f) {
+			float o3[3] = {origin.x, origin.y, origin.z}, d3[3] = {dir.x, dir.y, dir.z};
+			apply_aperture(cam, C.aperture_size, C.focus_z, C.spp, (uint32_t)(int)(u * (float)C.width) * 19349663u + (uint32_t)(int)(v * (float)C.height) * 96925573u, o3, d3);
+			origin = mk3(o3[0], o3[1], o3[2]);
+			dir = mk3(d3[0], d3[1], d3[2]);
+		}
 	}
 	origin = add3(origin, scale3(dir, C.near_distance));
 	r.o = origin;
@@ -436,9 +540,9 @@ NGP_DEV void init_ray(const ModelParams& M, const CameraParams& C, uint32_t x, u
 	r.alive = false;
 	if (dir.x == 0.0f && dir.y == 0.0f && dir.z == 0.0f) return;
 	dir = normalize3(dir);
+	r.d = dir; // (a ray that misses the render box still has a direction: the environment map behind it is looked up along it)
 	float t = fmaxf(aabb_ray_entry(M.raabb_min, M.raabb_max, m3_mulv(M.r2l, origin), m3_mulv(M.r2l, dir)), 0.0f) + 1e-6f;
 	if (!raabb_contains(M, add3(origin, scale3(dir, t)))) return;
-	r.d = dir;
 	r.t = t;
 	r.alive = true;
 }

@@ -64,8 +64,8 @@ NGP_DEV float4 tonemap_pixel(const FrameParams& F, f3 bg_linear, float r, float 
 	return tmp;
 }
 
-template <bool PROBE>
-NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc, uint32_t n_steps) {
+template <bool PROBE, bool PLAIN = false>
+NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc, uint32_t n_steps, f3 dir) {
 	if (!(acc.a > 0.001f)) return false;
 	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
@@ -82,9 +82,16 @@ NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear,
 		P.ray_rgba[idx] = make_float4(r, g, b, a);
 		return true;
 	}
-	if (F.direct) { // the frame buffer would hold zeros: tmp + 0 * (1 - a) == tmp
+	if (F.direct) { // the frame buffer would hold zeros (tmp + 0 * (1 - a) == tmp) or the environment map's value for this ray
+		const bool deep = a > 0.2f;
+		if (!PLAIN && F.envmap) {
+			float d3[3] = {dir.x, dir.y, dir.z}, e[4];
+			read_envmap(F.envmap, F.env_w, F.env_h, d3, e);
+			const float k = 1.0f - a;
+			r = r + e[0] * k; g = g + e[1] * k; b = b + e[2] * k; a = a + e[3] * k;
+		}
 		F.frame_buffer[idx] = tonemap_pixel(F, bg_linear, r, g, b, a);
-		if (a > 0.2f) F.depth_buffer[idx] = acc.depth;
+		if (deep) F.depth_buffer[idx] = acc.depth;
 		return true;
 	}
 	float4 fb = F.frame_buffer[idx];
@@ -182,7 +189,8 @@ NGP_DEV unsigned long long stamp() {
 // src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
 // exponential-stepping branches; the arithmetic that remains is the same expression for expression.
 // OUTSIDE: the render box may reach beyond the occupancy grid (geometry mode, a hand-set render box)
-template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1>
+// PLAIN: static pinhole camera, no depth of field, no environment map (FrameParams::plain, decided by the host)
+template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
@@ -201,14 +209,15 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const int c = lane & 15;
 	if (lane == 0 && (threadIdx.x >> 6) == 0) atomicMax(&F.results[4], ~realtime()); // start stamp (one per workgroup): max of the complements = the earliest
 	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
-	const f3 cam_fwd = mk3(C.m[6], C.m[7], C.m[8]);
+	const float* cam_last = (!PLAIN && C.moving) ? C.m1 : C.m; // depth is measured along camera_matrix1 (src/testbed_nerf.cu:2412)
+	const f3 cam_fwd = mk3(cam_last[6], cam_last[7], cam_last[8]);
 	// direct output: the background's trip through the tonemap is the same for every pixel
 	// (the background colour is sRGB: linearised unless the frame is averaged in sRGB, src/render_buffer.cu:537-541)
 	const f3 bg_linear = (PROBE || !F.direct) ? mk3(0.f, 0.f, 0.f)
 	                     : F.color_space == 1 ? mk3(F.background[0], F.background[1], F.background[2])
 	                                          : mk3(srgb_to_linear(F.background[0]), srgb_to_linear(F.background[1]), srgb_to_linear(F.background[2]));
 	const float4 empty_pixel = (!PROBE && F.direct) ? tonemap_pixel(F, bg_linear, 0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-	const f3 cam_pos = mk3(C.m[9], C.m[10], C.m[11]);
+	const f3 cam_pos = mk3(cam_last[9], cam_last[10], cam_last[11]);
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
 	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
 
@@ -263,7 +272,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
 			bool hit = false;
 			if (finished) {
-				hit = shade_ray<PROBE>(F, P, bg_linear, ray.out, acc, step - 1u); // step counts from 1 like the reference's march loop
+				hit = shade_ray<PROBE, PLAIN>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d); // step counts from 1 like the reference's march loop
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -295,13 +304,29 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
 					uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
 					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
-						init_ray(M, C, x, y, ray);
+						init_ray<PLAIN>(M, C, x, y, ray);
 						if (F.packed) ray.out = tile_local * 64u + slot;
-						if (F.direct) { // CudaRenderBufferView::clear + the untouched pixel's trip through accumulate / tonemap
-							F.frame_buffer[ray.out] = empty_pixel;
-							F.depth_buffer[ray.out] = MAX_DEPTH;
-						} else if (F.depth_buffer[ray.out] < 0.01f) { // src/testbed_nerf.cu:1490-1493
-							F.depth_buffer[ray.out] = MAX_DEPTH;
+						if (PLAIN || !F.envmap) {
+							if (F.direct) { // CudaRenderBufferView::clear + the untouched pixel's trip through accumulate / tonemap
+								F.frame_buffer[ray.out] = empty_pixel;
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							} else if (F.depth_buffer[ray.out] < 0.01f) { // src/testbed_nerf.cu:1490-1493
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							}
+						} else { // frame_buffer[idx] = read_envmap(envmap, ray.d) for every valid ray (src/testbed_nerf.cu:1526-1528)
+							const bool valid = ray.d.x != 0.0f || ray.d.y != 0.0f || ray.d.z != 0.0f;
+							float env[4] = {0.f, 0.f, 0.f, 0.f};
+							if (valid) {
+								float d3[3] = {ray.d.x, ray.d.y, ray.d.z};
+								read_envmap(F.envmap, F.env_w, F.env_h, d3, env);
+							}
+							if (F.direct) {
+								F.frame_buffer[ray.out] = valid ? tonemap_pixel(F, bg_linear, env[0], env[1], env[2], env[3]) : empty_pixel;
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							} else {
+								if (valid) F.frame_buffer[ray.out] = make_float4(env[0], env[1], env[2], env[3]);
+								if (F.depth_buffer[ray.out] < 0.01f) F.depth_buffer[ray.out] = MAX_DEPTH;
+							}
 						}
 						if (ray.alive) {
 							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
@@ -651,6 +676,15 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused(const ModelParams 
 __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, false, true>(M, C, F, P);
+}
+// the same for a static pinhole camera without depth of field or environment map -- the frame a benchmark or a screenshot renders
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, true, 1, true, 1, true>(M, C, F, P);
+}
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, 5, false, 1, true>(M, C, F, P);
 }
 // scenes of up to 5 cascades (aabb_scale <= 16: fox, garden) rendered inside their occupancy grid: 20 KB of occupancy summaries instead of 32
 // leave room for a third workgroup per CU
@@ -1031,8 +1065,10 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 		return;
 	}
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
-	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5);
-	int per_cu = F.prof ? per_cu_prof : unit ? per_cu_unit : c5 ? per_cu_c5 : per_cu_generic;
+	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5),
+	                 per_cu_unit_plain = resident_blocks_per_cu(render_nerf_fused_unit_plain), per_cu_c5_plain = resident_blocks_per_cu(render_nerf_fused_c5_plain);
+	const bool plain = C.lens_mode == 0 && C.aperture_size == 0.0f && !C.moving && !F.envmap;
+	int per_cu = F.prof ? per_cu_prof : unit ? (plain ? per_cu_unit_plain : per_cu_unit) : c5 ? (plain ? per_cu_c5_plain : per_cu_c5) : per_cu_generic;
 	// a rank of a sharded frame leaves a third of every CU to the collective's kernels and to the next frame's launch
 	// (measured on one GPU with two frames in flight: 2 per CU is as fast as 3 from N = 2 on, tools/shard_probe.py)
 	if (F.shard_count > 1 && per_cu > 2) per_cu = 2;
@@ -1043,7 +1079,9 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
 	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (c5 && plain) hipLaunchKernelGGL(render_nerf_fused_c5_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (c5) hipLaunchKernelGGL(render_nerf_fused_c5, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else hipLaunchKernelGGL(render_nerf_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 }

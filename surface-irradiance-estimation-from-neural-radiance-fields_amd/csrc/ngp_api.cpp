@@ -620,6 +620,26 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		return t == "fullyfusedmlp" || t == "megakernelmlp" || t == "cutlassmlp";
 	};
 	if (!fully_fused(net) || !fully_fused(rgb)) throw std::runtime_error("unsupported network otype");
+	{ // what the kernels hard-wire beyond the shapes: ReLU hidden layers without an output activation, and a direction encoding of
+	  // SphericalHarmonics degree 4 (bare, or first in a Composite whose remainder is Identity: configs/nerf/base.json). A snapshot
+	  // with another choice has the same parameter count and would render silently wrong.
+		auto lower = [](std::string t) { for (auto& ch : t) ch = (char)tolower(ch); return t; };
+		for (const mj::Value* n : {&net, &rgb}) {
+			if (lower(n->value("activation", "ReLU")) != "relu") throw std::runtime_error("unsupported network activation '" + n->value("activation", "ReLU") + "' (ReLU is implemented)");
+			if (lower(n->value("output_activation", "None")) != "none") throw std::runtime_error("unsupported network output_activation '" + n->value("output_activation", "None") + "' (None is implemented)");
+		}
+		if (root.contains("dir_encoding")) {
+			const mj::Value& de = root.at("dir_encoding");
+			auto is_sh4 = [&](const mj::Value& e) { return lower(e.value("otype", "")) == "sphericalharmonics" && (int)e.value("degree", 4.0) == 4; };
+			bool ok = is_sh4(de);
+			if (!ok && lower(de.value("otype", "")) == "composite" && de.contains("nested") && de.at("nested").is_array() && de.at("nested").size() >= 1) {
+				const mj::Value& nested = de.at("nested");
+				ok = is_sh4(nested.at(0)) && (!nested.at(0).contains("n_dims_to_encode") || nested.at(0).at("n_dims_to_encode").integer() == 3);
+				for (size_t i = 1; ok && i < nested.size(); ++i) ok = lower(nested.at(i).value("otype", "")) == "identity";
+			}
+			if (!ok) throw std::runtime_error("unsupported dir_encoding (SphericalHarmonics of degree 4, bare or first in a Composite with Identity for the extra dimensions, is implemented)");
+		}
+	}
 	d.n_neurons = (uint32_t)net.at("n_neurons").integer();
 	if ((uint32_t)rgb.at("n_neurons").integer() != d.n_neurons) throw std::runtime_error("density and rgb networks must have the same width");
 	d.n_hidden_density = (uint32_t)net.at("n_hidden_layers").integer();
@@ -986,12 +1006,18 @@ CameraParams make_camera_params(const ngp_camera& cam, uint32_t spp_index) {
 	C.screen_center[1] = cam.screen_center[1];
 	C.spp = spp_index;
 	C.near_distance = cam.near_distance;
-	if (cam.lens_mode == NGP_LENS_FTHETA || cam.lens_mode < 0 || cam.lens_mode > NGP_LENS_EQUIRECTANGULAR) throw std::runtime_error("lens mode not supported (Perspective, OpenCV, OpenCVFisheye, LatLong, Equirectangular are)");
+	if (cam.lens_mode < 0 || cam.lens_mode > NGP_LENS_EQUIRECTANGULAR) throw std::runtime_error("unknown lens mode (Perspective, OpenCV, FTheta, LatLong, OpenCVFisheye, Equirectangular)");
 	C.lens_mode = cam.lens_mode;
 	C.aperture_size = cam.focus_z < 0.f ? 0.f : cam.aperture_size; // plane_z < 0 switches the aperture off (src/testbed_nerf.cu:1462-1464)
 	C.focus_z = cam.focus_z;
 	if (C.aperture_size != 0.f && !(C.focus_z > 0.f)) throw std::runtime_error("depth of field needs a positive focus distance");
 	memcpy(C.lens_params, cam.lens_params, sizeof(C.lens_params));
+	// camera_matrix1 + rolling shutter: a frame is "moving" only when camera1 differs from camera0 or the per-pixel time is not the
+	// whole-frame constant the quaternion round trip would leave unchanged anyway
+	C.moving = cam.has_matrix1 && memcmp(cam.matrix, cam.matrix1, sizeof(cam.matrix)) != 0 ? 1 : 0;
+	memcpy(C.m1, cam.has_matrix1 ? cam.matrix1 : cam.matrix, sizeof(C.m1));
+	memcpy(C.rolling_shutter, cam.rolling_shutter, sizeof(C.rolling_shutter));
+	if (!cam.has_matrix1) { C.rolling_shutter[0] = C.rolling_shutter[1] = C.rolling_shutter[2] = 0.f; C.rolling_shutter[3] = 1.f; }
 	ld_random_pixel_offset(cam.snap_to_pixel_centers ? 0u : spp_index, C.pixel_offset);
 	return C;
 }
@@ -1037,6 +1063,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	}
 	const bool geometry = opts.testbed_mode == NGP_MODE_GEOMETRY;
 	const bool have_meshes = geometry && !ctx->meshes.empty();
+	if (have_meshes && cam.has_matrix1 && memcmp(cam.matrix, cam.matrix1, sizeof(cam.matrix)) != 0) throw std::runtime_error("a moving camera (matrix1 / rolling shutter) renders NeRF mode");
 	F.depth_test = geometry ? 1 : 0; // shade_kernel_nerf_geometry
 	ModelParams M = ctx->M;
 	if (have_meshes) { // load_scene sets m_render_aabb to the inflated mesh bb (testbed_geometry_training.cu:3185-3189)
@@ -1057,6 +1084,12 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.depth_scale = opts.depth_scale != 0.f ? opts.depth_scale : 1.0f / 0.33f;
 	memcpy(F.background, opts.background, sizeof(F.background));
 	F.exposure_scale = powf(2.0f, opts.exposure);
+	if (ctx->d_bg_envmap) {
+		if (geometry) throw std::runtime_error("an environment map applies to NeRF mode (in the reference the Geometry-mode NeRF pass would paint it over the meshes, src/testbed_geometry_training.cu:1993-1995): clear it with ngp_set_envmap(ctx, 0, 0, NULL)");
+		F.envmap = ctx->d_bg_envmap;
+		F.env_w = ctx->bg_env_w;
+		F.env_h = ctx->bg_env_h;
+	}
 	{ // a render box inside the outermost cascade's cube never puts a ray outside the occupancy grid (kernel selection)
 		const float h = 0.5f * (float)(1u << M.max_cascade);
 		bool inside = M.r2l_identity != 0;
@@ -1225,6 +1258,7 @@ void ngp_destroy(ngp_ctx* ctx) {
 	if (ctx->d_meshrefs) (void)hipFree(ctx->d_meshrefs);
 	if (ctx->d_envmap) (void)hipFree(ctx->d_envmap);
 	if (ctx->d_irradiance) (void)hipFree(ctx->d_irradiance);
+	if (ctx->d_bg_envmap) (void)hipFree(ctx->d_bg_envmap);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->d_depth) (void)hipFree(ctx->d_depth);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -1689,6 +1723,26 @@ int ngp_set_render_aabb(ngp_ctx* ctx, const float* min3, const float* max3, cons
 		memcpy(ctx->M.raabb_max, max3, 12);
 		memcpy(ctx->M.r2l, r2l, 36);
 		ctx->M.r2l_identity = memcmp(r2l, ident, 36) == 0 ? 1u : 0u;
+	});
+}
+
+int ngp_set_envmap(ngp_ctx* ctx, int32_t width, int32_t height, const float* rgba) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only)");
+		NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight read the map
+		if (ctx->d_bg_envmap) (void)hipFree(ctx->d_bg_envmap);
+		ctx->d_bg_envmap = nullptr;
+		ctx->bg_env_w = ctx->bg_env_h = 0;
+		if (!rgba || width <= 0 || height <= 0) return;
+		if ((int64_t)width * height > (1ll << 28)) throw std::runtime_error("environment map too large");
+		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_bg_envmap, (size_t)width * height * sizeof(float4)));
+		NGP_HIP_CHECK(hipMemcpy(ctx->d_bg_envmap, rgba, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice));
+		ctx->bg_env_w = width;
+		ctx->bg_env_h = height;
+		for (ngp_ctx* p : ctx->peers) { // the replicas of a multi-device context see the same background
+			if (ngp_set_envmap(p, width, height, rgba) != 0) throw std::runtime_error(p->error);
+		}
+		NGP_HIP_CHECK(hipSetDevice(ctx->device));
 	});
 }
 

@@ -207,6 +207,10 @@ struct ngp_ctx {
 	uint32_t env_n_theta = 0, env_n_phi = 0;
 	ngp::ProbeParams env_probe{}; // what was traced: mode, shell position(s), grid
 
+	// ---- environment map behind the NeRF (m_envmap.inference_view(), testbed.h:1297-1316)
+	float4* d_bg_envmap = nullptr;
+	int32_t bg_env_w = 0, bg_env_h = 0;
+
 	// ---- frame
 	size_t n_pixels_alloc = 0;
 	float4* d_frame = nullptr;

@@ -85,6 +85,11 @@ struct CameraParams {
 	int32_t lens_mode; // ELensMode: 0 Perspective, 1 OpenCV, 3 LatLong, 4 OpenCVFisheye, 5 Equirectangular
 	float lens_params[7];
 	float aperture_size, focus_z; // depth of field: 0 = pinhole
+	// a frame whose camera moves (camera_matrix0 -> camera_matrix1, Testbed::render_frame): every pixel gets the camera of its time
+	// rolling_shutter.x + .y u + .z v + .w ld_random_val(spp, idx * 72239731); m is camera0. moving = 0: m alone (camera0 == camera1)
+	float m1[12];
+	float rolling_shutter[4];
+	int32_t moving;
 };
 
 struct FrameParams {
@@ -113,6 +118,8 @@ struct FrameParams {
 	int32_t direct, to_srgb, color_space;
 	float background[4];
 	float exposure_scale;
+	const float4* envmap;     // m_envmap.inference_view(): lat-long radiance behind the NeRF (read_envmap), nullptr = none
+	int32_t env_w, env_h;
 	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums
 };
 

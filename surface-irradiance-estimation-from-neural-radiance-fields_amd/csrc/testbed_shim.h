@@ -359,23 +359,28 @@ public:
 	void render_to_cpu(float* out, int width, int height, int spp, bool linear, float start_time = -1.f, float end_time = -1.f, float fps = 30.f, float shutter_fraction = 1.0f, float* depth_out = nullptr) {
 		(void)fps;
 		if (start_time >= 0.f) {
-			// Testbed::render_to_cpu along the camera path (src/python_api.cu:124-202): sample i of the frame is taken at the
-			// middle of its slice of the shutter interval. The reference also interpolates the camera per pixel inside a
-			// sample (camera0 -> camera1); here a sample has one camera, so motion blur is resolved by the spp samples only.
+			// Testbed::render_to_cpu along the camera path (src/python_api.cu:124-202): EVERY sample of the frame is rendered between
+			// the camera at the start of the shutter interval (camera_matrix0) and the camera at its end (camera_matrix1 =
+			// camera_log_lerp(start, end, shutter_fraction)) with rolling_shutter (0, 0, 0, 1), i.e. each pixel of each sample takes
+			// a low-discrepancy time in the interval -- motion blur. Here camera1 is the path itself evaluated at
+			// start + shutter_fraction (end - start) rather than the matrix-logarithm blend of the two end points (tcnn's
+			// mat_log / mat_exp are not in the reference mount); for a shutter fraction of 1 the two coincide.
 			if (m_camera_smoothing) throw std::runtime_error("camera_smoothing is not supported by the MI355X renderer");
 			if (end_time < 0.f) end_time = start_time;
-			std::vector<float> acc((size_t)width * height * 4, 0.f), one((size_t)width * height * 4);
-			for (int i = 0; i < spp; ++i) {
-				const float start_alpha = (float)i / (float)spp * shutter_fraction, end_alpha = ((float)i + 1.0f) / (float)spp * shutter_fraction;
-				set_camera_from_time(start_time + (end_time - start_time) * (start_alpha + end_alpha) / 2.0f);
-				render_to_cpu(one.data(), width, height, 1, true, -1.f, -1.f, fps, shutter_fraction, nullptr);
-				for (size_t k = 0; k < acc.size(); ++k) acc[k] += one[k];
+			set_camera_from_time(start_time + (end_time - start_time) * shutter_fraction);
+			const std::array<float, 12> end_cam = m_camera;
+			set_camera_from_time(start_time);
+			m_camera_end = end_cam;
+			m_has_camera_end = true;
+			try {
+				render_to_cpu(out, width, height, spp, linear, -1.f, -1.f, fps, shutter_fraction, depth_out);
+			} catch (...) {
+				m_has_camera_end = false;
+				throw;
 			}
-			for (size_t k = 0; k < acc.size(); ++k) {
-				float v = acc[k] / (float)spp;
-				if (!linear && (k & 3) != 3) v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 0.41666f) - 0.055f; // linear_to_srgb, common_device.cuh:58-64
-				out[k] = v;
-			}
+			m_has_camera_end = false;
+			// (the reference leaves m_camera at the middle of the last sample's slice, python_api.cu:169-171)
+			set_camera_from_time(start_time + (end_time - start_time) * (((float)spp - 0.5f) / (float)spp * shutter_fraction));
 			return;
 		}
 		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth || m_render_mode == ERenderMode::Cost;
@@ -401,6 +406,11 @@ public:
 		cam.near_distance = m_render_near_distance;
 		cam.aperture_size = m_aperture_size; // src/testbed_nerf.cu:2342, 2380
 		cam.focus_z = m_slice_plane_z + m_scale;
+		if (m_has_camera_end) { // camera_matrix1 + m_rolling_shutter of render_frame
+			cam.has_matrix1 = 1;
+			memcpy(cam.matrix1, m_camera_end.data(), sizeof(cam.matrix1));
+			memcpy(cam.rolling_shutter, m_rolling_shutter.data(), sizeof(cam.rolling_shutter));
+		}
 		if (nerf.render_with_lens_distortion) { // m_nerf.render_lens, src/testbed_nerf.cu render_nerf
 			cam.lens_mode = m_render_lens_mode;
 			memcpy(cam.lens_params, m_render_lens_params.data(), sizeof(cam.lens_params));
@@ -458,6 +468,9 @@ public:
 		m_envmap_ready = false;
 	}
 	bool m_envmap_ready = false, m_envmap_grid_ready = false;
+	std::array<float, 12> m_camera_end{};                       // camera_matrix1 of the frame being rendered along a path
+	bool m_has_camera_end = false;
+	std::array<float, 4> m_rolling_shutter{0.f, 0.f, 0.f, 1.f}; // what Testbed::render_to_cpu passes (src/python_api.cu:183)
 
 	struct BRDFParams { // common.h:167-177
 		float metallic = 0.f, subsurface = 0.f, specular = 1.f, roughness = 0.5f, sheen = 0.f, clearcoat = 0.f, clearcoat_gloss = 0.f;

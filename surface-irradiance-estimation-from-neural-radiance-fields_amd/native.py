@@ -46,6 +46,7 @@ class Camera(C.Structure):
         ("matrix", C.c_float * 12), ("width", C.c_int32), ("height", C.c_int32), ("focal_length", C.c_float * 2),
         ("screen_center", C.c_float * 2), ("spp_index", C.c_uint32), ("snap_to_pixel_centers", C.c_int32), ("near_distance", C.c_float),
         ("lens_mode", C.c_int32), ("lens_params", C.c_float * 7), ("aperture_size", C.c_float), ("focus_z", C.c_float),
+        ("has_matrix1", C.c_int32), ("matrix1", C.c_float * 12), ("rolling_shutter", C.c_float * 4),
     ]
 
 
@@ -149,6 +150,7 @@ def load_library():
     L.ngp_update_density_grid.argtypes = [vp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
     L.ngp_get_density_grid.argtypes = [vp, vp, C.c_uint64]
     L.ngp_set_cone_angle_constant.argtypes = [vp, C.c_float]
+    L.ngp_set_envmap.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.ngp_set_render_aabb.argtypes = [vp, vp, vp, vp]
     L.ngp_get_snapshot_camera.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ngp_get_session_state.argtypes = [vp, C.POINTER(SessionState)]
@@ -238,7 +240,8 @@ def decode_image(data):
     return out
 
 
-def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0):
+def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5), spp_index=0, snap=True, near=0.0, lens_mode=0, lens_params=(), aperture_size=0.0, focus_z=1.0,
+                matrix1_3x4=None, rolling_shutter=(0.0, 0.0, 0.0, 1.0)):
     cam = Camera()
     mat = np.asarray(matrix_3x4, np.float32)
     assert mat.shape == (3, 4)
@@ -255,6 +258,14 @@ def make_camera(matrix_3x4, width, height, focal_length, screen_center=(0.5, 0.5
     for i, q in enumerate(lens_params):
         cam.lens_params[i] = q
     cam.aperture_size, cam.focus_z = aperture_size, focus_z
+    if matrix1_3x4 is not None:  # the camera at the end of the frame's interval (camera_matrix1) + rolling shutter
+        m1 = np.asarray(matrix1_3x4, np.float32)
+        cam.has_matrix1 = 1
+        for c in range(4):
+            for r in range(3):
+                cam.matrix1[c * 3 + r] = m1[r, c]
+        for i in range(4):
+            cam.rolling_shutter[i] = rolling_shutter[i]
     return cam
 
 
@@ -552,6 +563,14 @@ class Context:
         lo = np.asarray(lo, np.float32); hi = np.asarray(hi, np.float32)
         r = None if to_local is None else np.ascontiguousarray(np.asarray(to_local, np.float32).T.reshape(-1))  # column-major
         self._check(self.L.ngp_set_render_aabb(self.h, _p(lo), _p(hi), _p(r) if r is not None else None))
+
+    def set_envmap(self, rgba=None):
+        """(H, W, 4) lat-long radiance behind the NeRF (m_envmap); None removes it"""
+        if rgba is None:
+            self._check(self.L.ngp_set_envmap(self.h, 0, 0, None))
+            return
+        env = np.ascontiguousarray(rgba, np.float32)
+        self._check(self.L.ngp_set_envmap(self.h, env.shape[1], env.shape[0], _p(env)))
 
     def set_cone_angle_constant(self, value):
         self._check(self.L.ngp_set_cone_angle_constant(self.h, value))

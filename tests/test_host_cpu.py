@@ -233,6 +233,17 @@ def test_snapshot_dense_and_unsupported_encodings(tmp_path, native):
         bad = dict(root, encoding=dict(root["encoding"], **enc))
         with pytest.raises(RuntimeError, match="unsupported (encoding|grid type)"):
             ctx2.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
+    # choices that leave the parameter count unchanged must not load silently: direction encoding, activations
+    assert root["dir_encoding"]["nested"][0]["degree"] == 4
+    for key, val, msg in (("dir_encoding", {"otype": "SphericalHarmonics", "degree": 3}, "unsupported dir_encoding"),
+                          ("dir_encoding", {"otype": "Frequency", "n_frequencies": 4}, "unsupported dir_encoding"),
+                          ("dir_encoding", {"otype": "Composite", "nested": [{"otype": "SphericalHarmonics", "degree": 4, "n_dims_to_encode": 3}, {"otype": "OneBlob"}]}, "unsupported dir_encoding"),
+                          ("network", dict(root["network"], activation="Sine"), "unsupported network activation"),
+                          ("rgb_network", dict(root["rgb_network"], output_activation="Sigmoid"), "unsupported network output_activation")):
+        with pytest.raises(RuntimeError, match=msg):
+            ctx2.load_snapshot_bytes(msgpack.packb(dict(root, **{key: val}), use_bin_type=True))
+    for ok in ({"otype": "SphericalHarmonics", "degree": 4}, {"otype": "Composite", "nested": [{"otype": "SphericalHarmonics", "degree": 4}]}):
+        ctx2.load_snapshot_bytes(msgpack.packb(dict(root, dir_encoding=ok), use_bin_type=True))
     ctx2.close()
     ctx.close()
 

@@ -541,15 +541,18 @@ def test_cone_angle_override(native, oracle, scene_mod, scene_big):
     ctx.close()
 
 
-@pytest.mark.parametrize("lens", ["opencv", "fisheye", "latlong", "equirectangular"])
+@pytest.mark.parametrize("lens", ["opencv", "fisheye", "latlong", "equirectangular", "ftheta"])
 def test_lens_models(lens, gpu_ctx, oracle, native, scene_mod, scene_unit):
-    """uv_to_ray's lenses (common_device.cuh:441-462): OpenCV / OpenCV-fisheye undistortion (Newton), lat-long, equirectangular."""
+    """uv_to_ray's lenses (common_device.cuh:441-462): OpenCV / OpenCV-fisheye undistortion (Newton), lat-long, equirectangular,
+    F-theta (angle = polynomial of the pixel radius; pixels beyond 90 degrees have no ray)."""
     w, h = 112, 64
     gpu_ctx.set_model(scene_unit)
     gpu_ctx.clear_meshes()
     kw = {"opencv": dict(lens_mode=native.LENS_OPENCV, lens_params=(0.0578421, -0.0805099, -0.000980296, 0.00015575)),
           "fisheye": dict(lens_mode=native.LENS_OPENCV_FISHEYE, lens_params=(0.05, -0.01, 0.003, -0.0005)),
-          "latlong": dict(lens_mode=native.LENS_LATLONG), "equirectangular": dict(lens_mode=native.LENS_EQUIRECTANGULAR)}[lens]
+          "latlong": dict(lens_mode=native.LENS_LATLONG), "equirectangular": dict(lens_mode=native.LENS_EQUIRECTANGULAR),
+          # r(pixels) -> angle: 0.8 rad at the intrinsics' half width (res 1000 x 600), slightly non-linear
+          "ftheta": dict(lens_mode=native.LENS_FTHETA, lens_params=(0.0, 1.5e-3, 2.0e-7, -1.0e-10, 0.0, 1000.0, 600.0))}[lens]
     mat = scene_mod.orbit_camera(20.0, 20.0, 2.2 if lens in ("opencv", "fisheye") else 0.9)
     focal = scene_mod.focal_from_fov_x(w, 1.2)
     img = gpu_ctx.render(native.make_camera(mat, w, h, focal, **kw))
@@ -561,8 +564,16 @@ def test_lens_models(lens, gpu_ctx, oracle, native, scene_mod, scene_unit):
     assert ost["n_rays_hit"] > 500
     assert_image_close(img, ref, 45.0, tol=2e-2)
     assert np.abs(img - plain).max() > 0.05  # the lens changes the picture
-    with pytest.raises(RuntimeError, match="lens mode not supported"):
-        gpu_ctx.render(native.make_camera(mat, w, h, focal, lens_mode=native.LENS_FTHETA))
+    with pytest.raises(RuntimeError, match="unknown lens mode"):
+        gpu_ctx.render(native.make_camera(mat, w, h, focal, lens_mode=7))
+    if lens == "ftheta":  # a polynomial that passes 90 degrees inside the image: those pixels have no ray and stay background
+        wide = dict(lens_mode=native.LENS_FTHETA, lens_params=(0.0, 4.0e-3, 0.0, 0.0, 0.0, 1000.0, 600.0))
+        img_w = gpu_ctx.render(native.make_camera(mat, w, h, focal, **wide), native.make_opts(background=(0, 0, 0, 0)))
+        m = oracle.make_model(scene_unit)
+        fb, _, _ = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal, **wide))
+        oracle.release(m)
+        assert_image_close(img_w, fb.reshape(h, w, 4), 45.0, tol=2e-2)
+        assert (img_w[:, :8, 3] == 0).all() and (img_w[h // 2, w // 2 - 4:w // 2 + 4, 3] > 0).any()
 
 
 @pytest.mark.parametrize("rotated", [False, True])
@@ -636,3 +647,83 @@ def test_depth_of_field(gpu_ctx, oracle, native, scene_mod, scene_unit):
     assert np.abs(img - sharp).max() > 0.05
     one = gpu_ctx.render(native.make_camera(mat, w, h, focal, aperture_size=0.03, focus_z=-1.0))  # plane_z < 0 switches the aperture off
     assert np.array_equal(one, gpu_ctx.render(native.make_camera(mat, w, h, focal)))
+
+
+@pytest.mark.parametrize("spp", [1, 3])
+def test_environment_map_background(spp, native, oracle, scene_mod, scene_unit):
+    """m_envmap behind the NeRF: every valid ray starts from read_envmap(dir) (envmap.cuh:24-50, src/testbed_nerf.cu:1526-1528) --
+    through the direct-output path (1 spp) and the general one (several samples per pixel)."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    rng = np.random.default_rng(12)
+    eh, ew = 16, 32
+    env = np.zeros((eh, ew, 4), np.float32)
+    env[..., :3] = rng.uniform(0, 1, (eh, ew, 3))
+    env[..., 3] = rng.uniform(0.5, 1.0, (eh, ew))
+    env[..., :3] *= env[..., 3:4]  # premultiplied, like every radiance buffer of the renderer
+    w, h = 144, 80
+    mat = scene_mod.orbit_camera(250.0, 10.0, 2.6)  # close: the picture has object, grazing rays and plain background
+    focal = scene_mod.focal_from_fov_x(w, 1.1)
+    kw = dict(background=(0.1, 0.2, 0.3, 1.0), exposure=0.25, to_srgb=(spp == 1))
+    plain = ctx.render(native.make_camera(mat, w, h, focal, snap=(spp == 1)), native.make_opts(spp=spp, **kw))
+    ctx.set_envmap(env)
+    img = ctx.render(native.make_camera(mat, w, h, focal, snap=(spp == 1)), native.make_opts(spp=spp, **kw))
+    m = oracle.make_model(scene_unit)
+    acc = np.zeros((w * h, 4), np.float32)
+    for s in range(spp):
+        fb, _, ost = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal, spp_index=s, snap=(spp == 1)), oracle.make_opts(envmap=env))
+        acc = oracle.accumulate(fb.reshape(-1, 4), acc, s)
+    oracle.release(m)
+    ref = oracle.tonemap(acc, kw["background"], kw["exposure"], kw["to_srgb"]).reshape(h, w, 4)
+    assert ost["n_rays_hit"] > 1000 and ost["n_rays_hit"] < 0.9 * w * h
+    assert_image_close(img, ref, 48.0, tol=2e-2)
+    assert np.abs(img - plain).max() > 0.1  # the map shows
+    # where no ray is composited the pixel is the map alone: agree to rounding (atan2 / acos of the device vs libm)
+    miss = np.abs(fb.reshape(h, w, 4) - 0).sum(-1) > 0
+    assert np.abs(img - ref)[miss].max() < 0.3
+    ctx.set_envmap(None)
+    assert np.array_equal(ctx.render(native.make_camera(mat, w, h, focal, snap=(spp == 1)), native.make_opts(spp=spp, **kw)), plain)
+    ctx.set_envmap(env)
+    ctx.add_mesh(pkg("meshio").icosphere(1))
+    with pytest.raises(RuntimeError, match="environment map applies to NeRF mode"):
+        ctx.render(native.make_camera(mat, w, h, focal), native.make_opts(testbed_mode=native.MODE_GEOMETRY))
+    ctx.close()
+
+
+@pytest.mark.parametrize("shutter", [(0.0, 0.0, 0.0, 1.0), (0.1, 0.3, 0.5, 0.2)])
+def test_moving_camera_and_rolling_shutter(shutter, native, oracle, scene_mod, scene_unit):
+    """camera_matrix0 -> camera_matrix1 with a rolling shutter (get_xform_given_rolling_shutter, common_device.cuh:651-659;
+    src/testbed_nerf.cu:1468): every pixel is rendered by the camera of its own time; depth is measured along camera_matrix1."""
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    w, h = 128, 72
+    m0, m1 = scene_mod.orbit_camera(40.0, 25.0, 3.6), scene_mod.orbit_camera(58.0, 32.0, 3.9)  # turns and moves within the frame
+    focal = scene_mod.focal_from_fov_x(w, 0.8)
+    kw = dict(rolling_shutter=shutter)
+    m = oracle.make_model(scene_unit)
+    for spp in (0, 5):
+        cam = native.make_camera(m0, w, h, focal, spp_index=spp, snap=False, matrix1_3x4=m1, **kw)
+        ocam = oracle.make_camera(m0, w, h, focal, spp_index=spp, snap=False, matrix1_4x3=m1, **kw)
+        got = ctx.init_rays(cam)
+        ref = oracle.init_rays(m, ocam)
+        assert np.array_equal(got["alive"], ref["alive"])
+        alive = ref["alive"] == 1
+        # quaternion slerp: sinf / acosf of the device against libm differ by an ulp
+        assert np.abs(got["origin"] - ref["origin"]).max() < 2e-6 and np.abs(got["dir"][alive] - ref["dir"][alive]).max() < 2e-6
+        img, depth = ctx.render(cam, native.make_opts(), want_depth=True)
+        fb, db, ost = oracle.render_nerf(m, ocam)
+        ref_img = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+        assert ost["n_rays_hit"] > 1500
+        assert_image_close(img, ref_img, 45.0, tol=2e-2)
+        both = (depth < 16000) & (db < 16000)
+        assert np.median(np.abs(depth[both] - db[both])) < 1e-4
+    still = ctx.render(native.make_camera(m0, w, h, focal, spp_index=5, snap=False))
+    assert np.abs(img - still).max() > 0.05
+    # camera1 == camera0 is the static frame, bit for bit (no quaternion round trip)
+    same = ctx.render(native.make_camera(m0, w, h, focal, spp_index=5, snap=False, matrix1_3x4=m0, **kw))
+    assert np.array_equal(same, still)
+    oracle.release(m)
+    ctx.add_mesh(pkg("meshio").icosphere(1))
+    with pytest.raises(RuntimeError, match="moving camera"):
+        ctx.render(native.make_camera(m0, w, h, focal, matrix1_3x4=m1), native.make_opts(testbed_mode=native.MODE_GEOMETRY))
+    ctx.close()
