@@ -1071,7 +1071,8 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	int per_cu = F.prof ? per_cu_prof : unit ? (plain ? per_cu_unit_plain : per_cu_unit) : c5 ? (plain ? per_cu_c5_plain : per_cu_c5) : per_cu_generic;
 	// a rank of a sharded frame leaves a third of every CU to the collective's kernels and to the next frame's launch
 	// (measured on one GPU with two frames in flight: 2 per CU is as fast as 3 from N = 2 on, tools/shard_probe.py)
-	if (F.shard_count > 1 && per_cu > 2) per_cu = 2;
+	static const int shard_per_cu = []() { const char* e = getenv("NGP_SHARD_BLOCKS_PER_CU"); int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }(); // experiments: tools/shard_probe.py
+	if (F.shard_count > 1 && per_cu > shard_per_cu) per_cu = shard_per_cu;
 	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
 	int n_blocks = n_cus * per_cu;
 	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least

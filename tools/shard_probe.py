@@ -15,9 +15,9 @@ cams = [native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(
 INFLIGHT = int(os.environ.get("NGP_BENCH_INFLIGHT", "1"))
 streams = [torch.cuda.Stream() for _ in range(INFLIGHT)]
 bufs = [(torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"), torch.zeros((h, w), dtype=torch.float32, device="cuda")) for _ in streams]
-for n in (1, 2, 4, 8):
+for n in [int(a) for a in os.environ.get("NGP_SHARD_NS", "1,2,4,8").split(",")]:
     worst = 0.0
-    for r in range(n):
+    for r in range(n if os.environ.get("NGP_SHARD_ALL_RANKS", "1") == "1" else 1):
         opts = native.make_opts(shard_index=r, shard_count=n, packed_output=n > 1)
         def go(i):
             rgba, depth = bufs[i % INFLIGHT]
