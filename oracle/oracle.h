@@ -53,9 +53,19 @@ typedef struct orc_nerf_model {
 	 * kernel (the tcnn that has tcnn::vec3 / mat4x3, which the reference's sources use throughout); ORC_GRID_ACC_LEGACY =
 	 * `result[f] += (T)(weight * (float)val[f])`, the kernel before the tvec refactor. */
 	uint32_t grid_accumulate;
+	/* configs/nerf/frequency.json (the original NeRF's architecture): tcnn Frequency encodings in place of the hash grid and
+	 * of the spherical harmonics -- out[j] = sin(2^((j / 2) % n_freq) * pi * x[j / (2 n_freq)] + (j % 2) * pi / 2), no
+	 * parameters -- feeding CutlassMLPs (256 wide, 7 + 1 hidden layers in that config). pos_encoding / dir_encoding: 0 = grid / SH
+	 * degree 4 (base.json), 1 = Frequency with that many frequencies. mlp_alignment: 16 for FullyFusedMLP, 8 for CutlassMLP --
+	 * NerfNetwork pads encoding widths, the rgb network's input and output to it (nerf_network.h:81-100). 0 = 16. */
+	uint32_t pos_encoding, pos_n_frequencies;
+	uint32_t dir_encoding, dir_n_frequencies;
+	uint32_t mlp_alignment;
 	/* derived, filled by orc_nerf_prepare */
 	void* prepared;
 } orc_nerf_model;
+/* tcnn FrequencyEncoding of n x n_dims inputs: out n x (n_dims * 2 * n_frequencies) fp16 */
+void orc_frequency_encode(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out);
 
 typedef struct orc_camera {
 	float matrix[12]; /* camera-to-world 4x3, column-major: x axis, y axis, z axis (fwd), position */

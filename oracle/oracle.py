@@ -50,6 +50,9 @@ class NerfModel(C.Structure):
         ("cone_angle_constant", C.c_float),
         ("density_grid_bitfield", C.c_void_p),
         ("grid_accumulate", C.c_uint32),
+        ("pos_encoding", C.c_uint32), ("pos_n_frequencies", C.c_uint32),
+        ("dir_encoding", C.c_uint32), ("dir_n_frequencies", C.c_uint32),
+        ("mlp_alignment", C.c_uint32),
         ("prepared", C.c_void_p),
     ]
 
@@ -187,11 +190,20 @@ class Oracle:
         """scene: dict produced by the package's synthetic/snapshot loaders (plain numpy + scalars)."""
         m = NerfModel()
         enc = scene["encoding"]
-        m.n_levels = enc["n_levels"]
-        m.n_features_per_level = enc["n_features_per_level"]
-        m.log2_hashmap_size = enc["log2_hashmap_size"]
-        m.base_resolution = enc["base_resolution"]
-        m.per_level_scale = enc["per_level_scale"]
+        if enc.get("otype", "HashGrid") == "Frequency":  # configs/nerf/frequency.json: no grid at all
+            m.pos_encoding, m.pos_n_frequencies = 1, enc["n_frequencies"]
+            m.n_levels = m.n_features_per_level = m.log2_hashmap_size = m.base_resolution = 0
+            m.per_level_scale = 1.0
+        else:
+            m.n_levels = enc["n_levels"]
+            m.n_features_per_level = enc["n_features_per_level"]
+            m.log2_hashmap_size = enc["log2_hashmap_size"]
+            m.base_resolution = enc["base_resolution"]
+            m.per_level_scale = enc["per_level_scale"]
+        de = scene.get("dir_encoding", {})
+        if de.get("otype") == "Frequency":
+            m.dir_encoding, m.dir_n_frequencies = 1, de["n_frequencies"]
+        m.mlp_alignment = 8 if scene["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
         m.n_neurons = scene["network"]["n_neurons"]
         m.n_hidden_density = scene["network"]["n_hidden_layers"]
         m.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]

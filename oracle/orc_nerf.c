@@ -146,6 +146,9 @@ typedef struct {
 	uint64_t n_density_w, n_rgb_w;
 	const uint16_t* grid;
 	aabb_t aabb, render_aabb;
+	uint32_t dir_dims;   /* width of the direction encoding (16 for SH degree 4, 6 n_freq for Frequency), padded to the alignment */
+	uint32_t rgb_in;     /* next_multiple(density out + dir_dims, alignment), nerf_network.h:97 */
+	uint32_t rgb_out;    /* next_multiple(3, alignment): 16 FullyFusedMLP, 8 CutlassMLP */
 } prepared_t;
 
 static uint32_t next_multiple_u32(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
@@ -176,25 +179,40 @@ static uint64_t mlp_n_params(uint32_t in, uint32_t width, uint32_t n_hidden, uin
 	return (uint64_t)width * in + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)out_padded * width;
 }
 
+static uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+static void network_shapes(const orc_nerf_model* m, uint32_t* enc_dims, uint32_t* dir_dims, uint32_t* rgb_in, uint32_t* rgb_out) {
+	const uint32_t al = m->mlp_alignment ? m->mlp_alignment : 16u;
+	*enc_dims = m->pos_encoding == 1 ? align_up(3u * 2u * m->pos_n_frequencies, al) : m->n_levels * m->n_features_per_level;
+	*dir_dims = m->dir_encoding == 1 ? align_up(3u * 2u * m->dir_n_frequencies, al) : 16u;
+	*rgb_in = align_up(m->density_out_dims + *dir_dims, al);
+	*rgb_out = align_up(3u, al);
+}
+
 uint64_t orc_n_params(const orc_nerf_model* m) {
 	uint32_t offsets[ORC_MAX_LEVELS + 1], res[ORC_MAX_LEVELS];
 	float scales[ORC_MAX_LEVELS];
-	if (orc_grid_layout(m, offsets, res, scales)) return 0;
-	uint32_t enc = m->n_levels * m->n_features_per_level;
+	uint32_t enc, dir, rgb_in, rgb_out;
+	network_shapes(m, &enc, &dir, &rgb_in, &rgb_out);
+	uint64_t ng = 0;
+	if (m->pos_encoding != 1) {
+		if (orc_grid_layout(m, offsets, res, scales)) return 0;
+		ng = (uint64_t)offsets[m->n_levels] * m->n_features_per_level;
+	}
 	uint64_t nd = mlp_n_params(enc, m->n_neurons, m->n_hidden_density, m->density_out_dims);
-	uint64_t nr = mlp_n_params(m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u);
-	return nd + nr + (uint64_t)offsets[m->n_levels] * m->n_features_per_level;
+	uint64_t nr = mlp_n_params(rgb_in, m->n_neurons, m->n_hidden_rgb, rgb_out);
+	return nd + nr + ng;
 }
 
 int orc_nerf_prepare(orc_nerf_model* m) {
 	if (m->n_hidden_density < 1 || m->n_hidden_rgb < 1) return -2;
+	if (m->n_neurons > 256) return -4;
 	prepared_t* p = (prepared_t*)calloc(1, sizeof(prepared_t));
 	if (!p) return -1;
-	if (orc_grid_layout(m, p->offsets, p->resolutions, p->scales)) { free(p); return -1; }
-	p->enc_dims = m->n_levels * m->n_features_per_level;
+	if (m->pos_encoding != 1 && orc_grid_layout(m, p->offsets, p->resolutions, p->scales)) { free(p); return -1; }
+	network_shapes(m, &p->enc_dims, &p->dir_dims, &p->rgb_in, &p->rgb_out);
 	p->n_density_w = mlp_n_params(p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims);
-	p->n_rgb_w = mlp_n_params(m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u);
-	uint64_t need = p->n_density_w + p->n_rgb_w + (uint64_t)p->offsets[m->n_levels] * m->n_features_per_level;
+	p->n_rgb_w = mlp_n_params(p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out);
+	uint64_t need = p->n_density_w + p->n_rgb_w + (m->pos_encoding == 1 ? 0 : (uint64_t)p->offsets[m->n_levels] * m->n_features_per_level);
 	if (m->n_params != need) { free(p); return -3; }
 	p->density_w = (float*)malloc(sizeof(float) * p->n_density_w);
 	p->rgb_w = (float*)malloc(sizeof(float) * p->n_rgb_w);
@@ -348,21 +366,42 @@ static void mlp_forward(const float* w, uint32_t n_in, uint32_t width, uint32_t 
 	mlp_layer(w, n_out, width, cur, 0, out_f, out_h);
 }
 
+/* tcnn FrequencyEncoding (encodings/frequency.h): out[j] = sin(scalbn(x[j / (2 n_freq)], (j / 2) % n_freq) * pi
+ * + (j % 2) * pi / 2), cast to half; padded outputs are 1 (tcnn pads encodings with ones) */
+static void frequency_encode_one(uint32_t n_dims, uint32_t n_freq, uint32_t padded, const float* x, uint16_t* out) {
+	const float PI = 3.14159265358979323846f;
+	const uint32_t n = n_dims * 2u * n_freq;
+	for (uint32_t j = 0; j < n; ++j) {
+		const uint32_t log2_frequency = (j / 2u) % n_freq, feature = j / (n_freq * 2u);
+		const float phase_shift = (float)(j % 2u) * (PI / 2.0f);
+		const float v = scalbnf(x[feature], (int)log2_frequency);
+		out[j] = orc_float_to_half(sinf(v * PI + phase_shift));
+	}
+	for (uint32_t j = n; j < padded; ++j) out[j] = orc_float_to_half(1.0f);
+}
+void orc_frequency_encode(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out) {
+	const uint32_t w = n_dims * 2u * n_frequencies;
+	for (uint32_t i = 0; i < n; ++i) frequency_encode_one(n_dims, n_frequencies, w, x + (size_t)n_dims * i, out + (size_t)w * i);
+}
+
 /* nerf_network.h:105-139: pos enc -> density MLP -> [density out | dir enc] -> rgb MLP; row 3 <- density logit. */
 static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const float* pos01, const float* dir01, uint16_t* out4) {
-	uint16_t enc_h[ORC_MAX_LEVELS * 8];
-	float enc[ORC_MAX_LEVELS * 8];
-	grid_encode_one(m, p, pos01, enc_h);
+	uint16_t enc_h[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
+	float enc[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
+	if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h);
+	else grid_encode_one(m, p, pos01, enc_h);
 	for (uint32_t i = 0; i < p->enc_dims; ++i) enc[i] = orc_half_to_float(enc_h[i]);
-	float rgb_in[64];
+	float rgb_in[128];
 	uint16_t dens_h[32];
 	mlp_forward(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, rgb_in, dens_h);
-	uint16_t sh[16];
-	sh4_one(dir01, sh);
-	for (int i = 0; i < 16; ++i) rgb_in[m->density_out_dims + i] = orc_half_to_float(sh[i]);
+	uint16_t dir_h[64];
+	if (m->dir_encoding == 1) frequency_encode_one(3, m->dir_n_frequencies, p->dir_dims, dir01, dir_h);
+	else sh4_one(dir01, dir_h);
+	for (uint32_t i = 0; i < p->dir_dims; ++i) rgb_in[m->density_out_dims + i] = orc_half_to_float(dir_h[i]);
+	for (uint32_t i = m->density_out_dims + p->dir_dims; i < p->rgb_in; ++i) rgb_in[i] = 1.0f; /* alignment padding of the rgb network's input */
 	float rgb_out[16];
 	uint16_t rgb_h[16];
-	mlp_forward(p->rgb_w, m->density_out_dims + 16u, m->n_neurons, m->n_hidden_rgb, 16u, rgb_in, rgb_out, rgb_h);
+	mlp_forward(p->rgb_w, p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out, rgb_in, rgb_out, rgb_h);
 	out4[0] = rgb_h[0];
 	out4[1] = rgb_h[1];
 	out4[2] = rgb_h[2];

@@ -23,6 +23,31 @@ def base_network_config():
     }
 
 
+def frequency_network_config(n_neurons=256, n_hidden_density=7, n_hidden_rgb=1):
+    """configs/nerf/frequency.json merged over base.json: the original NeRF's architecture -- Frequency encodings (16 / 4
+    frequencies), CutlassMLPs 256 wide with 7 + 1 hidden layers."""
+    return {
+        "encoding": {"otype": "Frequency", "n_frequencies": 16},
+        "network": {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": n_neurons, "n_hidden_layers": n_hidden_density},
+        "dir_encoding": {"otype": "Frequency", "n_frequencies": 4},
+        "rgb_network": {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": n_neurons, "n_hidden_layers": n_hidden_rgb},
+    }
+
+
+def network_shapes(cfg):
+    """(position encoding width, direction encoding width, rgb network input width, rgb network output width) as NerfNetwork derives
+    them (nerf_network.h:81-100): encodings, the rgb input and the rgb output are padded to the MLP's alignment -- 16 for
+    FullyFusedMLP, 8 for CutlassMLP."""
+    al = 8 if cfg["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+    up = lambda v: (v + al - 1) // al * al
+    enc = cfg["encoding"]
+    enc_dims = up(3 * 2 * enc["n_frequencies"]) if enc.get("otype") == "Frequency" else enc["n_levels"] * enc["n_features_per_level"]
+    de = cfg.get("dir_encoding", {})
+    dir_dims = up(3 * 2 * de["n_frequencies"]) if de.get("otype") == "Frequency" else 16
+    dens_out = cfg["network"].get("n_output_dims", 16)
+    return enc_dims, dir_dims, up(dens_out + dir_dims), up(3)
+
+
 def per_level_scale(aabb_scale, n_levels, base_resolution, rule="fork", desired_resolution=2048.0):
     """src/testbed.cu:3951-3966. The fork overwrites the value with one derived from
     m_geometry.nerf...aabb_scale, which is 1 in Nerf mode ('fork' rule); upstream uses the dataset's."""
@@ -56,10 +81,12 @@ def mlp_n_params(n_in, width, n_hidden, n_out_padded):
 
 def n_params(cfg):
     enc = cfg["encoding"]
-    enc_dims = enc["n_levels"] * enc["n_features_per_level"]
+    enc_dims, dir_dims, rgb_in, rgb_out = network_shapes(cfg)
     dens_out = cfg["network"].get("n_output_dims", 16)
     nd = mlp_n_params(enc_dims, cfg["network"]["n_neurons"], cfg["network"]["n_hidden_layers"], dens_out)
-    nr = mlp_n_params(dens_out + 16, cfg["rgb_network"]["n_neurons"], cfg["rgb_network"]["n_hidden_layers"], 16)
+    nr = mlp_n_params(rgb_in, cfg["rgb_network"]["n_neurons"], cfg["rgb_network"]["n_hidden_layers"], rgb_out)
+    if enc.get("otype") == "Frequency":
+        return nd, nr, 0
     offsets, _, _ = grid_layout(enc)
     return nd, nr, offsets[-1] * enc["n_features_per_level"]
 

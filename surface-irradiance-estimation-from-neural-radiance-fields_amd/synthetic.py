@@ -105,13 +105,15 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
     cfg = cfg or S.base_network_config()
     cfg = {k: dict(v) if isinstance(v, dict) else v for k, v in cfg.items()}
     enc = cfg["encoding"]
-    enc["log2_hashmap_size"] = log2_hashmap_size
-    if "per_level_scale" not in enc:
-        enc["per_level_scale"] = S.per_level_scale(aabb_scale, enc["n_levels"], enc["base_resolution"], pls_rule)
+    frequency = enc.get("otype") == "Frequency"
+    if not frequency:
+        enc["log2_hashmap_size"] = log2_hashmap_size
+        if "per_level_scale" not in enc:
+            enc["per_level_scale"] = S.per_level_scale(aabb_scale, enc["n_levels"], enc["base_resolution"], pls_rule)
     nd, nr, ng = S.n_params(cfg)
     rng = np.random.default_rng(seed)
     width = cfg["network"]["n_neurons"]
-    enc_dims = enc["n_levels"] * enc["n_features_per_level"]
+    enc_dims, dir_dims, rgb_in_dims, rgb_out_dims = S.network_shapes(cfg)
     dens_out = cfg["network"].get("n_output_dims", 16)
 
     def xavier(n_out, n_in):
@@ -126,7 +128,7 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
         return layers
 
     dens_layers = mlp(enc_dims, cfg["network"]["n_hidden_layers"], dens_out)
-    rgb_layers = mlp(dens_out + 16, cfg["rgb_network"]["n_hidden_layers"], 16)
+    rgb_layers = mlp(rgb_in_dims, cfg["rgb_network"]["n_hidden_layers"], rgb_out_dims)
     # zero-sum colour rows (ReLU activations have a positive mean) and a wider spread, so that the image
     # shows spatial and directional colour variation instead of one flat tint
     rgb_layers[-1][:3] -= rgb_layers[-1][:3].mean(axis=1, keepdims=True)
@@ -137,7 +139,15 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
     dens_layers[-1][0] = np.abs(dens_layers[-1][0])
     pts = rng.uniform(0.15, 0.85, size=(20000, 3)).astype(np.float32)
     pts = pts[_shapes_occupancy(pts, 1)][:4096]
-    h = _grid_encode_np(grid.astype(np.float16).astype(np.float32), cfg, pts)
+    if frequency:  # tcnn FrequencyEncoding: sin(2^k pi x + (j % 2) pi / 2), input-major, then frequency, then sin / cos
+        nf = enc["n_frequencies"]
+        k = np.arange(nf, dtype=np.float32)
+        arg = pts[:, :, None] * np.exp2(k)[None, None, :] * np.float32(np.pi)
+        h = np.stack([np.sin(arg), np.sin(arg + np.float32(np.pi / 2))], -1).reshape(pts.shape[0], -1).astype(np.float32)
+        if h.shape[1] < enc_dims:
+            h = np.concatenate([h, np.ones((pts.shape[0], enc_dims - h.shape[1]), np.float32)], 1)
+    else:
+        h = _grid_encode_np(grid.astype(np.float16).astype(np.float32), cfg, pts)
     for W in dens_layers[:-1]:
         h = np.maximum(h @ W.T, 0)
     logit = h @ dens_layers[-1][0]
