@@ -76,6 +76,17 @@ typedef struct ngp_model_desc {
 	uint32_t aabb_scale;                          /* dataset.aabb_scale -> max_cascade, src/testbed_nerf.cu:2729-2732 */
 	float cone_angle_constant;                    /* src/testbed_nerf.cu:2736 */
 	int32_t linear_colors;                        /* m_nerf.training.linear_colors */
+	/* The second architecture the renderer implements: configs/nerf/frequency.json, the original NeRF's network (tcnn Frequency
+	 * encodings, CutlassMLPs 128 or 256 wide with any number of hidden layers). All zero = the grid architecture above.
+	 *   pos_encoding  0: the grid encoding described by the fields above; 1: Frequency with pos_n_frequencies (the grid fields are
+	 *                 ignored, params_fp16 holds the two MLPs only)
+	 *   dir_encoding  0: SphericalHarmonics degree 4; 1: Frequency with dir_n_frequencies
+	 *   mlp_alignment 16: FullyFusedMLP, 8: CutlassMLP (0 = 16) -- what encodings, the rgb network's input and its output are padded
+	 *                 to (nerf_network.h:81-100)
+	 * Inference only: ngp_train_* refuse such a model. */
+	uint32_t pos_encoding, pos_n_frequencies;
+	uint32_t dir_encoding, dir_n_frequencies;
+	uint32_t mlp_alignment;
 } ngp_model_desc;
 
 /* Arguments of Testbed::render_frame (testbed.h:561-575) that the NeRF path consumes. */

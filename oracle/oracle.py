@@ -253,6 +253,15 @@ class Oracle:
         self.lib.orc_grid_encode(C.byref(m), n, _ptr(pos01), _ptr(out))
         return out.view(np.float16)
 
+    def frequency_encode(self, x, n_frequencies):
+        """tcnn FrequencyEncoding of n x d inputs: n x (d * 2 * n_frequencies) halves (unpadded)"""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros((x.shape[0], x.shape[1] * 2 * n_frequencies), np.uint16)
+        self.lib.orc_frequency_encode.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        self.lib.orc_frequency_encode.restype = None
+        self.lib.orc_frequency_encode(x.shape[0], x.shape[1], n_frequencies, _ptr(x), _ptr(out))
+        return out.view(np.float16)
+
     def sh4(self, dir01):
         dir01 = np.ascontiguousarray(dir01, np.float32)
         out = np.zeros((dir01.shape[0], 16), np.uint16)

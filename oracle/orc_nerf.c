@@ -367,7 +367,9 @@ static void mlp_forward(const float* w, uint32_t n_in, uint32_t width, uint32_t 
 }
 
 /* tcnn FrequencyEncoding (encodings/frequency.h): out[j] = sin(scalbn(x[j / (2 n_freq)], (j / 2) % n_freq) * pi
- * + (j % 2) * pi / 2), cast to half; padded outputs are 1 (tcnn pads encodings with ones) */
+ * + (j % 2) * pi / 2), cast to half; padded outputs are 1 (tcnn pads encodings with ones). The argument is one fma (what nvcc makes
+ * of the expression); the sine is libm's -- tcnn calls the hardware approximation __sinf, whose error at these arguments (up to
+ * 2^15 pi) is not specified closely enough to restate: PARITY UNPINNED like the rest of tcnn's arithmetic. */
 static void frequency_encode_one(uint32_t n_dims, uint32_t n_freq, uint32_t padded, const float* x, uint16_t* out) {
 	const float PI = 3.14159265358979323846f;
 	const uint32_t n = n_dims * 2u * n_freq;
@@ -375,7 +377,7 @@ static void frequency_encode_one(uint32_t n_dims, uint32_t n_freq, uint32_t padd
 		const uint32_t log2_frequency = (j / 2u) % n_freq, feature = j / (n_freq * 2u);
 		const float phase_shift = (float)(j % 2u) * (PI / 2.0f);
 		const float v = scalbnf(x[feature], (int)log2_frequency);
-		out[j] = orc_float_to_half(sinf(v * PI + phase_shift));
+		out[j] = orc_float_to_half(sinf(fmaf(v, PI, phase_shift))); /* x * PI + phase_shift as nvcc contracts it (-fmad is its default) */
 	}
 	for (uint32_t j = n; j < padded; ++j) out[j] = orc_float_to_half(1.0f);
 }

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libngp_hip.so")
-SOURCES = ["nerf_kernels.hip", "mesh_kernels.hip", "train_kernels.hip", "ngp_api.cpp", "ngp_mesh.cpp", "ngp_train.cpp", "ngp_multi.cpp"]
+SOURCES = ["nerf_kernels.hip", "wide_kernels.hip", "mesh_kernels.hip", "train_kernels.hip", "ngp_api.cpp", "ngp_mesh.cpp", "ngp_train.cpp", "ngp_multi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 

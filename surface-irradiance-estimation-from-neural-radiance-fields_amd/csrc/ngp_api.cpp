@@ -266,6 +266,39 @@ void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t
 	}
 }
 
+// MFMA A fragments of one layer of the wide architecture (ngp_kernels.h WideModel): [m tile][k block][lane] x 8 fp16, zeros beyond the matrix
+WideLayer emit_wide_fragments(std::vector<uint16_t>& frags, const uint16_t* W, uint32_t n_out, uint32_t n_in) {
+	WideLayer L{};
+	L.frag_offset = (uint32_t)(frags.size() / 8);
+	L.n_kblocks = (uint16_t)((n_in + 15) / 16);
+	L.n_mtiles = (uint16_t)((n_out + 31) / 32);
+	frags.resize(frags.size() + (size_t)L.n_mtiles * L.n_kblocks * 64 * 8, 0);
+	uint16_t* out = frags.data() + (size_t)L.frag_offset * 8;
+	for (uint32_t m = 0; m < L.n_mtiles; ++m)
+		for (uint32_t kb = 0; kb < L.n_kblocks; ++kb)
+			for (uint32_t l = 0; l < 64; ++l)
+				for (uint32_t j = 0; j < 8; ++j) {
+					const uint32_t row = 32 * m + (l & 31), col = 16 * kb + 8 * (l >> 5) + j;
+					if (row < n_out && col < n_in) out[(((size_t)m * L.n_kblocks + kb) * 64 + l) * 8 + j] = W[(size_t)row * n_in + col];
+				}
+	return L;
+}
+
+// widths of the wide architecture as NerfNetwork derives them (nerf_network.h:81-100)
+struct WideShapes {
+	uint32_t alignment, enc_dims, dir_dims, rgb_in, rgb_out;
+};
+WideShapes wide_shapes(const ngp_model_desc& d) {
+	WideShapes w{};
+	w.alignment = d.mlp_alignment ? d.mlp_alignment : 16u;
+	auto up = [&](uint32_t v) { return (v + w.alignment - 1) / w.alignment * w.alignment; };
+	w.enc_dims = up(6u * d.pos_n_frequencies);
+	w.dir_dims = d.dir_encoding == 1 ? up(6u * d.dir_n_frequencies) : 16u;
+	w.rgb_in = up(d.density_out_dims + w.dir_dims);
+	w.rgb_out = up(3u);
+	return w;
+}
+
 void free_model(ngp_ctx* ctx) {
 	ngp::free_training(ctx);
 	if (ctx->d_params) (void)hipFree(ctx->d_params);
@@ -290,22 +323,33 @@ void free_model(ngp_ctx* ctx) {
 }
 
 void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
+	const bool wide = d.pos_encoding == 1;
+	if (d.pos_encoding > 1 || d.dir_encoding > 1 || (d.mlp_alignment != 0 && d.mlp_alignment != 8 && d.mlp_alignment != 16)) throw std::runtime_error("invalid model descriptor (encoding kinds / mlp_alignment)");
+	if (!wide && d.dir_encoding != 0) throw std::runtime_error("unsupported network architecture: a Frequency direction encoding is implemented together with a Frequency position encoding (configs/nerf/frequency.json)");
+	if (wide) {
+		if ((d.n_neurons != 128 && d.n_neurons != 256) || d.n_hidden_density < 1 || d.n_hidden_rgb < 1 || d.n_hidden_density + d.n_hidden_rgb + 2 > (uint32_t)WIDE_MAX_LAYERS ||
+		    d.density_out_dims != 16 || d.pos_n_frequencies < 1 || d.pos_n_frequencies > 40 || (d.dir_encoding == 1 && (d.dir_n_frequencies < 1 || d.dir_n_frequencies > 5))) {
+			throw std::runtime_error("unsupported network architecture: with a Frequency position encoding (configs/nerf/frequency.json) the HIP path implements MLPs of 128 or 256 "
+			                         "neurons with 1 or more hidden layers, a 16-wide density output, up to 40 position and 5 direction frequencies");
+		}
+	} else
 	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density != 1 ||
 	    d.n_hidden_rgb < 1 || d.n_hidden_rgb > 1 + (uint32_t)MAX_RGB_MID || d.density_out_dims != 16) {
 		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json "
 		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64 wide with 1 to 3 hidden layers)");
 	}
-	if ((d.log2_hashmap_size > 28 && d.log2_hashmap_size != 31) || d.base_resolution == 0 || !(d.per_level_scale > 0.f)) throw std::runtime_error("invalid hash grid configuration");
+	if (!wide && ((d.log2_hashmap_size > 28 && d.log2_hashmap_size != 31) || d.base_resolution == 0 || !(d.per_level_scale > 0.f))) throw std::runtime_error("invalid hash grid configuration");
 	if (d.aabb_scale == 0 || (d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error("NeRF dataset's `aabb_scale` must be a power of two"); // testbed_nerf.cu:2707
 	if (d.aabb_scale > (1u << (NERF_CASCADES - 1))) throw std::runtime_error("NeRF dataset must have `aabb_scale <= 128`"); // :2711-2718
 
 	ModelParams M{};
 	uint32_t total_entries = 0;
-	build_levels(d, M.levels, &total_entries);
-	const uint32_t enc_dims = d.n_levels * d.n_features_per_level;
+	if (!wide) build_levels(d, M.levels, &total_entries);
+	const WideShapes ws = wide_shapes(d);
+	const uint32_t enc_dims = wide ? ws.enc_dims : d.n_levels * d.n_features_per_level;
 	const uint64_t nd = mlp_n_params(enc_dims, d.n_neurons, d.n_hidden_density, d.density_out_dims);
-	const uint64_t nr = mlp_n_params(d.density_out_dims + 16u, d.n_neurons, d.n_hidden_rgb, 16u);
-	const uint64_t ng = (uint64_t)total_entries * d.n_features_per_level;
+	const uint64_t nr = wide ? mlp_n_params(ws.rgb_in, d.n_neurons, d.n_hidden_rgb, ws.rgb_out) : mlp_n_params(d.density_out_dims + 16u, d.n_neurons, d.n_hidden_rgb, 16u);
+	const uint64_t ng = wide ? 0 : (uint64_t)total_entries * d.n_features_per_level;
 	if (d.n_params != nd + nr + ng || !d.params_fp16) {
 		throw std::runtime_error("parameter count mismatch: snapshot has " + std::to_string(d.n_params) + ", network needs " + std::to_string(nd + nr + ng));
 	}
@@ -335,6 +379,36 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	}
 	if (ctx->device < 0) return; // host-only context: the model is parsed and validated, nothing can be rendered
 
+	if (wide) {
+		// every layer's weights as MFMA A fragments (wide_kernels.hip)
+		std::vector<uint16_t> frags;
+		WideModel& WM = M.wide;
+		WM.width = d.n_neurons;
+		WM.pos_freqs = d.pos_n_frequencies;
+		WM.dir_freqs = d.dir_encoding == 1 ? d.dir_n_frequencies : 0u;
+		WM.enc_dims = ws.enc_dims;
+		WM.dir_dims = ws.dir_dims;
+		WM.rgb_in = ws.rgb_in;
+		WM.n_hidden_density = d.n_hidden_density;
+		WM.n_hidden_rgb = d.n_hidden_rgb;
+		const uint16_t* W = ctx->params.data();
+		uint32_t l = 0;
+		auto emit_mlp = [&](uint32_t n_in, uint32_t n_hidden, uint32_t n_out) {
+			WM.layers[l++] = emit_wide_fragments(frags, W, d.n_neurons, n_in);
+			W += (size_t)d.n_neurons * n_in;
+			for (uint32_t k = 1; k < n_hidden; ++k) {
+				WM.layers[l++] = emit_wide_fragments(frags, W, d.n_neurons, d.n_neurons);
+				W += (size_t)d.n_neurons * d.n_neurons;
+			}
+			WM.layers[l++] = emit_wide_fragments(frags, W, n_out, d.n_neurons);
+			W += (size_t)n_out * d.n_neurons;
+		};
+		emit_mlp(ws.enc_dims, d.n_hidden_density, d.density_out_dims);
+		emit_mlp(ws.rgb_in, d.n_hidden_rgb, ws.rgb_out);
+		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
+		NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		WM.frags = ctx->d_wfrags;
+	} else {
 	// grid table
 	NGP_HIP_CHECK(hipMalloc(&ctx->d_params, ng * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_params, ctx->params.data() + nd + nr, ng * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -360,6 +434,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	M.rgb_mid = (uint32_t)rgb_mid;
 	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	}
 	// occupancy: fp16 grid -> fp32 -> bitfield + mips on the device (K8/K9)
 	const size_t bitfield_bytes = (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES;
 	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_bitfield, bitfield_bytes));
@@ -382,7 +457,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	M.grid = (const uint2*)ctx->d_params;
 	M.xgrid = (const char*)ctx->d_xgrid;
 	M.coarse = ctx->d_coarse;
-	M.wfrags = ctx->d_wfrags;
+	M.wfrags = wide ? nullptr : ctx->d_wfrags;
 	M.bitfield = ctx->d_bitfield;
 	for (int i = 0; i < 3; ++i) {
 		M.aabb_min[i] = d.aabb_min[i];
@@ -593,8 +668,11 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		for (auto& ch : gt) ch = (char)tolower(ch);
 		if (gt == "dense") dense_grid = true;
 		else if (gt != "hash") throw std::runtime_error("unsupported grid type '" + gt + "' (Hash and Dense are implemented)");
+	} else if (otype == "frequency") { // configs/nerf/frequency.json
+		d.pos_encoding = 1;
+		d.pos_n_frequencies = (uint32_t)enc.value("n_frequencies", 12.0);
 	} else if (otype != "hashgrid") {
-		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid and DenseGrid are implemented)");
+		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid, DenseGrid and Frequency are implemented)");
 	}
 	d.n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2.0);
 	d.n_levels = enc.contains("n_features") && enc.at("n_features").num() > 0 ? (uint32_t)enc.at("n_features").num() / d.n_features_per_level
@@ -610,7 +688,10 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 	d.aabb_scale = (uint32_t)ds.aabb_scale;
 
 	d.per_level_scale = (float)enc.value("per_level_scale", 0.0);
-	if (!(d.per_level_scale > 0.0f) && d.n_levels > 1) {
+	if (d.pos_encoding == 1) {
+		d.n_levels = d.n_features_per_level = d.log2_hashmap_size = d.base_resolution = 0;
+		d.per_level_scale = 0.0f;
+	} else if (!(d.per_level_scale > 0.0f) && d.n_levels > 1) {
 		// The fork derives it from m_geometry.nerf...aabb_scale, which is 1 in Nerf mode (testbed.cu:3959-3966).
 		d.per_level_scale = std::exp(std::log(2048.0f * 1.0f / (float)d.base_resolution) / (float)(d.n_levels - 1));
 	}
@@ -620,6 +701,16 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		return t == "fullyfusedmlp" || t == "megakernelmlp" || t == "cutlassmlp";
 	};
 	if (!fully_fused(net) || !fully_fused(rgb)) throw std::runtime_error("unsupported network otype");
+	{ // encodings and the rgb network's input / output are padded to the networks' alignment: 16 for FullyFusedMLP, 8 for CutlassMLP
+		// (nerf_network.h:81-100; the rgb network's own for its output). The implemented architectures use one kind for both networks.
+		auto is_cutlass = [](const mj::Value& n) {
+			std::string t = n.value("otype", "FullyFusedMLP");
+			for (auto& ch : t) ch = (char)tolower(ch);
+			return t == "cutlassmlp";
+		};
+		if (is_cutlass(net) != is_cutlass(rgb) && d.pos_encoding == 1) throw std::runtime_error("unsupported network otype: density and rgb networks of different kinds");
+		d.mlp_alignment = (d.pos_encoding == 1 && is_cutlass(net)) ? 8u : 16u;
+	}
 	{ // what the kernels hard-wire beyond the shapes: ReLU hidden layers without an output activation, and a direction encoding of
 	  // SphericalHarmonics degree 4 (bare, or first in a Composite whose remainder is Identity: configs/nerf/base.json). A snapshot
 	  // with another choice has the same parameter count and would render silently wrong.
@@ -631,13 +722,20 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		if (root.contains("dir_encoding")) {
 			const mj::Value& de = root.at("dir_encoding");
 			auto is_sh4 = [&](const mj::Value& e) { return lower(e.value("otype", "")) == "sphericalharmonics" && (int)e.value("degree", 4.0) == 4; };
-			bool ok = is_sh4(de);
+			auto is_freq = [&](const mj::Value& e) { return d.pos_encoding == 1 && lower(e.value("otype", "")) == "frequency"; };
+			const mj::Value* first = &de;
+			bool ok = is_sh4(de) || is_freq(de);
 			if (!ok && lower(de.value("otype", "")) == "composite" && de.contains("nested") && de.at("nested").is_array() && de.at("nested").size() >= 1) {
 				const mj::Value& nested = de.at("nested");
-				ok = is_sh4(nested.at(0)) && (!nested.at(0).contains("n_dims_to_encode") || nested.at(0).at("n_dims_to_encode").integer() == 3);
+				first = &nested.at(0);
+				ok = (is_sh4(*first) || is_freq(*first)) && (!first->contains("n_dims_to_encode") || first->at("n_dims_to_encode").integer() == 3);
 				for (size_t i = 1; ok && i < nested.size(); ++i) ok = lower(nested.at(i).value("otype", "")) == "identity";
 			}
-			if (!ok) throw std::runtime_error("unsupported dir_encoding (SphericalHarmonics of degree 4, bare or first in a Composite with Identity for the extra dimensions, is implemented)");
+			if (!ok) throw std::runtime_error("unsupported dir_encoding (SphericalHarmonics of degree 4 -- or Frequency beside a Frequency position encoding --, bare or first in a Composite with Identity for the extra dimensions, is implemented)");
+			if (is_freq(*first)) {
+				d.dir_encoding = 1;
+				d.dir_n_frequencies = (uint32_t)first->value("n_frequencies", 12.0);
+			}
 		}
 	}
 	d.n_neurons = (uint32_t)net.at("n_neurons").integer();
@@ -1311,6 +1409,32 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 		ngp::refresh_density_grid_host(ctx);
 		const ngp_model_desc& d = ctx->desc;
 		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
+		if (!root.contains("encoding") && d.pos_encoding == 1) { // configs/nerf/frequency.json
+			mj::Value e = mj::Value::make_object();
+			e["otype"] = mj::Value::make_string("Frequency");
+			e["n_frequencies"] = mj::Value::make_uint(d.pos_n_frequencies);
+			root["encoding"] = e;
+			auto mlp = [&](uint32_t hidden) {
+				mj::Value n = mj::Value::make_object();
+				n["otype"] = mj::Value::make_string(d.mlp_alignment == 8 ? "CutlassMLP" : "FullyFusedMLP");
+				n["activation"] = mj::Value::make_string("ReLU");
+				n["output_activation"] = mj::Value::make_string("None");
+				n["n_neurons"] = mj::Value::make_uint(d.n_neurons);
+				n["n_hidden_layers"] = mj::Value::make_uint(hidden);
+				return n;
+			};
+			root["network"] = mlp(d.n_hidden_density);
+			root["rgb_network"] = mlp(d.n_hidden_rgb);
+			mj::Value de = mj::Value::make_object();
+			if (d.dir_encoding == 1) {
+				de["otype"] = mj::Value::make_string("Frequency");
+				de["n_frequencies"] = mj::Value::make_uint(d.dir_n_frequencies);
+			} else {
+				de["otype"] = mj::Value::make_string("SphericalHarmonics");
+				de["degree"] = mj::Value::make_uint(4);
+			}
+			root["dir_encoding"] = de;
+		}
 		if (!root.contains("encoding")) {
 			mj::Value e = mj::Value::make_object();
 			e["otype"] = mj::Value::make_string(d.log2_hashmap_size == 31 ? "DenseGrid" : "HashGrid");
@@ -1344,7 +1468,7 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 			de["nested"] = nested;
 			root["dir_encoding"] = de;
 		}
-		root["encoding"]["per_level_scale"] = mj::Value::make_float(d.per_level_scale);
+		if (d.pos_encoding == 0) root["encoding"]["per_level_scale"] = mj::Value::make_float(d.per_level_scale);
 		mj::Value snap = mj::Value::make_object();
 		snap["n_params"] = mj::Value::make_uint(ctx->params.size());
 		snap["params_type"] = mj::Value::make_string("__half");
@@ -1663,11 +1787,13 @@ int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_
 		float* d_pos = nullptr;
 		uint16_t* d_out = nullptr;
 		NGP_HIP_CHECK(hipMalloc((void**)&d_pos, (size_t)n * 3 * sizeof(float)));
-		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 32 * sizeof(uint16_t)));
+		const size_t width = ctx->M.wide.width ? ctx->M.wide.enc_dims : 32; // the position encoding's (padded) width
+		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * width * sizeof(uint16_t)));
 		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-		launch_grid_encode(ctx->M, n, d_pos, d_out, ctx->stream);
+		if (ctx->M.wide.width) launch_frequency_encode(ctx->M, n, d_pos, d_out, ctx->stream);
+		else launch_grid_encode(ctx->M, n, d_pos, d_out, ctx->stream);
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * 32 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * width * sizeof(uint16_t), hipMemcpyDeviceToHost));
 		(void)hipFree(d_pos);
 		(void)hipFree(d_out);
 		NGP_HIP_CHECK(hipGetLastError());
@@ -1688,7 +1814,8 @@ int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const fl
 		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 4 * sizeof(uint16_t)));
 		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
 		NGP_HIP_CHECK(hipMemcpy(d_dir, dir01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-		launch_network_inference(ctx->M, n, d_pos, d_dir, d_out, ctx->stream);
+		if (ctx->M.wide.width) launch_network_inference_wide(ctx->M, n, d_pos, d_dir, d_out, ctx->n_cus, ctx->stream);
+		else launch_network_inference(ctx->M, n, d_pos, d_dir, d_out, ctx->stream);
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost));
 		(void)hipFree(d_pos);
@@ -1760,6 +1887,7 @@ int ngp_update_density_grid(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint3
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (ctx->M.wide.width) throw std::runtime_error("the occupancy grid update is built for the configs/nerf/base.json network; a Frequency-encoding model keeps the grid of its snapshot");
 		ngp::sync_inference_model(ctx);
 		ngp::update_density_grid_device(ctx, decay, n_uniform, n_nonuniform, n_iterations);
 		ngp::refresh_density_grid_host(ctx);

@@ -53,6 +53,27 @@ struct NerfPayload { // nerf_device.cuh:144-152
 };
 static_assert(sizeof(NerfPayload) == 40, "NerfPayload layout");
 
+// The "wide" architecture (configs/nerf/frequency.json, the original NeRF's: Frequency encodings, CutlassMLPs 128 or 256 wide with
+// any number of hidden layers) runs in wide_kernels.hip on v_mfma_f32_32x32x16_f16 tiles. Every layer's weights are stored as MFMA
+// A fragments: fragment (m, kb) of a layer = rows 32m..32m+31 (output neurons), columns 16kb..16kb+15 (inputs) of its row-major
+// [out][in] matrix, 64 lanes x 8 fp16 with lane (r = lane & 31, h = lane >> 5) holding W[32m + r][16kb + 8h + j]; rows and columns
+// beyond the matrix are zeros. Layer l's fragments start at uint4 index frag_offset and are ordered [m][kb][lane].
+constexpr int WIDE_MAX_LAYERS = 24;
+struct WideLayer {
+	uint32_t frag_offset;
+	uint16_t n_kblocks; // 16-wide blocks of the (zero-padded) input
+	uint16_t n_mtiles;  // 32-row tiles of the (zero-padded) output
+};
+struct WideModel {
+	const uint4* frags;
+	uint32_t width;                        // n_neurons: 128 or 256; 0 = the model is not of this architecture
+	uint32_t pos_freqs, dir_freqs;         // n_frequencies of the position / direction encodings; dir_freqs 0 = SphericalHarmonics degree 4
+	uint32_t enc_dims, dir_dims, rgb_in;   // padded widths (nerf_network.h:81-100): position encoding, direction encoding, rgb network input
+	uint32_t n_hidden_density, n_hidden_rgb;
+	// density: layers [0, n_hidden_density] (the last one is the 16-wide output layer); rgb: the n_hidden_rgb + 1 layers behind them
+	WideLayer layers[WIDE_MAX_LAYERS];
+};
+
 struct ModelParams {
 	const uint2* grid;       // fp16 x4 per entry, tcnn order (level-major, entry-major)
 	const char* xgrid;       // the same entries in the xor layout: one index formula for dense and hashed levels
@@ -71,6 +92,7 @@ struct ModelParams {
 	uint32_t diag_pow2;    // every component of aabb_diag is a power of two: x / diag == x * (1/diag) bit for bit
 	float aabb_inv_diag[3];
 	uint32_t grid_bytes, xgrid_bytes; // sizes of the two tables (buffer-load descriptors: out-of-range gathers read zeros)
+	WideModel wide;                   // wide.width != 0: grid / xgrid / wfrags / levels are unused, wide_kernels.hip renders
 };
 constexpr uint32_t COARSE_WORDS_PER_MIP = 32 * 32 * 32 / 32;
 

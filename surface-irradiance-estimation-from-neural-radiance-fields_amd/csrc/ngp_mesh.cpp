@@ -364,7 +364,7 @@ void compute_probes(ngp_ctx* ctx, ngp::ProbeParams P, float min_transmittance) {
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 	if (!ctx->model_loaded) throw std::runtime_error("No network available.");
 	ngp::sync_inference_model(ctx);
-	if (ctx->M.rgb_mid != 1) throw std::runtime_error("irradiance probes are built for the configs/nerf/base.json rgb head (2 hidden layers)");
+	if (ctx->M.rgb_mid != 1 && !ctx->M.wide.width) throw std::runtime_error("irradiance probes are built for the configs/nerf/base.json rgb head (2 hidden layers)");
 	ensure_sync_buffers(ctx);
 	for (int i = 0; i < 3; ++i) P.center[i] = 0.5f * (ctx->M.raabb_max[i] + ctx->M.raabb_min[i]); // render_aabb.center()
 	const uint32_t no = P.mode == NGP_PROBE_MULTI_CENTER ? P.n_origin : 1u;

@@ -66,6 +66,7 @@ ModelParams training_model(const ngp_ctx* ctx) {
 // Trainer construction: parameters from the current model (ctx->params), optimizer state zeroed
 TrainState& ensure_training(ngp_ctx* ctx) {
 	require_device_model(ctx);
+	if (ctx->M.wide.width) throw std::runtime_error("training is built for the configs/nerf/base.json network; a Frequency-encoding model (configs/nerf/frequency.json) is inference only");
 	if (ctx->train && ctx->train->d_weights) return *ctx->train;
 	if (!ctx->train) ctx->train = new TrainState();
 	if (ctx->train->opts.struct_size == 0) default_opts(ctx->train->opts);

@@ -1,0 +1,534 @@
+// The NeRF inference path for the "wide" architecture on MI355X (gfx950): configs/nerf/frequency.json -- the original NeRF's
+// network inside the reference's renderer: Frequency encodings of position (16 frequencies -> 96 inputs) and direction (4 -> 24),
+// a density MLP of 7 hidden layers x 256 neurons and an rgb MLP of 1 x 256 (tcnn CutlassMLP; the reference's loop is the same
+// src/testbed_nerf.cu:2056-2138 chain, with every layer a cutlass GEMM launch).
+//
+// One persistent kernel per sample-per-pixel, like the base.json kernel (nerf_kernels.hip), but organised around the GEMMs that
+// now dominate (0.87 MFLOP per sample, 42x base.json's): a workgroup of 4 waves owns 256 ray slots, one per thread; every round
+// each live slot marches to its next sample, the workgroup runs the network on the 256 samples with the activations resident in
+// LDS, and each thread composites its own sample. Rays never leave registers; the only HBM traffic is occupancy bits, the weight
+// fragments (868 KB, L2-resident, read once per workgroup round) and one frame-buffer write per pixel.
+//
+//   activations  X[256 samples][264] fp16 in LDS (132 KB, rows padded by 8 halves so that the 16-byte operand reads of 16
+//                consecutive samples cover all 64 banks once); a layer is computed in place: all waves read, barrier, all write
+//   GEMM         v_mfma_f32_32x32x16_f16, weights on the A side (M = neurons), samples on the B side (N). A wave owns
+//                width / 4 neurons (2 M-tiles for 256) and takes the 256 samples as two halves of 4 tiles: 8 accumulator tiles =
+//                128 fp32 registers at a time, every B read feeds two MFMAs (LDS at half its rate when the MFMA pipe is full).
+//                One wave per SIMD (the 132 KB of LDS allow one workgroup per CU anyway) with gfx950's 512 registers
+//   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2
+//   B operand    ds_read_b128 of X[sample][16 kb + 8 h ..]; each B read feeds two MFMAs
+//   output tile  lane (n, h) holds neurons 8q + 4h + r of sample n: four 8-byte LDS writes per tile put them back in row n
+//   a half of the block (128 samples) in which no slot holds a sample (the tail of a frame) is skipped, reads and MFMAs alike
+//
+// Sample sets are the reference's exactly: the march is the one-voxel-at-a-time loop of nerf_device.cuh:461-494 on the occupancy
+// bitfield in global memory (L2), no block jumps.
+#include "render_common.h"
+
+namespace ngp {
+
+constexpr int WBLOCK = 256;
+constexpr int XS = 264;        // halves per activation row
+constexpr int DIR_STRIDE = 32; // halves per direction-encoding row
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct WideShared {
+	half_t x[WBLOCK * XS];
+	half_t dir[WBLOCK * DIR_STRIDE]; // per ray slot: the encoded direction, constant along the ray
+	uint2 out[WBLOCK];               // rgb + density logit of the slot's sample
+	uint32_t tile_mask[4];           // per wave: which of its two 32-sample tiles hold a sample this round
+};
+
+NGP_DEV floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// tcnn FrequencyEncoding (encodings/frequency.h): feature j of input x is
+//   sin(fma(scalbn(x[j / (2 F)], (j / 2) % F), pi, (j % 2) pi / 2))
+// rounded to fp16; inputs beyond 3 * 2 F up to `padded` are ones. Writes `padded` halves to out (4-byte aligned), then zeros up to
+// k_end (the MFMA K block the row is read in: the weights' columns there are zeros, which does not make 0 x stale-NaN a zero).
+NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y, float z, half_t* out, uint32_t k_end = 0) {
+	const float PI = 3.14159265358979323846f;
+	const float in[3] = {x, y, z};
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		for (uint32_t f = 0; f < n_freq; ++f) {
+			const float v = __builtin_ldexpf(in[d], (int)f);
+			half2_t sc;
+			sc[0] = (half_t)sinf(__builtin_fmaf(v, PI, 0.0f));
+			sc[1] = (half_t)sinf(__builtin_fmaf(v, PI, PI / 2.0f));
+			*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
+		}
+	}
+	const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
+	for (uint32_t j = 6u * n_freq; j < padded; j += 2u) *(half2_t*)(out + j) = ones;
+	const half2_t zeros = {(half_t)0.0f, (half_t)0.0f};
+	for (uint32_t j = padded; j < k_end; j += 2u) *(half2_t*)(out + j) = zeros;
+}
+
+NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
+	union { half_t h[4]; uint2 u; } p;
+	p.h[0] = (half_t)a; p.h[1] = (half_t)b; p.h[2] = (half_t)c; p.h[3] = (half_t)d;
+	if (relu) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) p.h[i] = p.h[i] > (half_t)0 ? p.h[i] : (half_t)0; // max(round(x), 0) == round(max(x, 0))
+	}
+	return p.u;
+}
+
+// One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 n_kb)). The 256 samples are taken as two halves of four
+// 32-sample tiles (128 accumulator registers each; the weights' A fragments are read once per half); `active` bit g = half g
+// (samples 128g .. 128g+127) holds at least one sample and is computed.
+template <int MT>
+NGP_DEV void wide_hidden_layer(half_t* X, const uint4* __restrict__ frags, int n_kb, int wave, int lane, uint32_t active) {
+	const int n = lane & 31, h = lane >> 5;
+	const uint4* wf = frags + (size_t)(wave * MT) * n_kb * 64 + lane;
+	union AF { uint4 u; half8 v; };
+	uint2 packed[2][MT][4][4]; // the layer's outputs as fp16, kept until every wave has read its inputs
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		if (!((active >> g) & 1u)) continue;
+		floatx16 acc[MT][4];
+		const half_t* col = X + (128 * g + n) * XS + 8 * h;
+		{ // first K block: the accumulators start from the products (C = 0 is an inline constant)
+			const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			AF a[MT];
+#pragma unroll
+			for (int m = 0; m < MT; ++m) a[m].u = wf[(size_t)m * n_kb * 64];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const half8 b = *(const half8*)(col + 32 * t * XS);
+#pragma unroll
+				for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(a[m].v, b, zero);
+			}
+		}
+		for (int kb = 1; kb < n_kb; ++kb) {
+			AF a[MT];
+#pragma unroll
+			for (int m = 0; m < MT; ++m) a[m].u = wf[((size_t)m * n_kb + kb) * 64];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const half8 b = *(const half8*)(col + 32 * t * XS + 16 * kb);
+#pragma unroll
+				for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(a[m].v, b, acc[m][t]);
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < MT; ++m)
+#pragma unroll
+			for (int t = 0; t < 4; ++t)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) packed[g][m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
+	}
+	__syncthreads(); // every wave has read the layer's input
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		if (!((active >> g) & 1u)) continue;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			half_t* row = X + (128 * g + 32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
+#pragma unroll
+			for (int m = 0; m < MT; ++m)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[g][m][t][q];
+		}
+	}
+	__syncthreads();
+}
+
+// An output layer (at most 32 neurons, no activation): wave w computes its own two sample tiles 2w, 2w+1 (both in half w >> 1).
+NGP_DEV void wide_out_layer(const half_t* X, const uint4* __restrict__ frags, int n_kb, int wave, int lane, floatx16 (&acc)[2]) {
+	const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+	for (int t = 0; t < 2; ++t)
+#pragma unroll
+		for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+	union { uint4 u; half8 v; } a;
+	for (int kb = 0; kb < n_kb; ++kb) {
+		a.u = frags[(size_t)kb * 64 + lane];
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			const half8 b = *(const half8*)(X + (32 * (2 * wave + t) + n) * XS + 16 * kb + 8 * h);
+			acc[t] = mfma32(a.v, b, acc[t]);
+		}
+	}
+}
+
+struct WideOut {
+	half_t r, g, b, sigma;
+};
+
+// NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 256 sample rows. On entry row `tid` of
+// S.x holds the position encoding of thread tid's sample and S.dir its direction encoding (both visible: the caller has passed a
+// barrier); on exit every thread has its own sample's outputs and X may be overwritten.
+template <int MT>
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, uint32_t active) {
+	const int wave = tid >> 6, lane = tid & 63;
+	const int n = lane & 31, h = lane >> 5;
+	uint32_t l = 0;
+	for (; l < W.n_hidden_density; ++l) wide_hidden_layer<MT>(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, active);
+	const bool mine = (active >> (wave >> 1)) & 1u; // this wave's 64 samples belong to an active half
+	floatx16 acc[2];
+	if (mine) {
+		wide_out_layer(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, acc);
+		// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tiles: no other wave reads them now)
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			half_t* row = S.x + (32 * (2 * wave + t) + n) * XS + 4 * h;
+#pragma unroll
+			for (int q = 0; q < 2; ++q) *(uint2*)(row + 8 * q) = pack4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3], false);
+		}
+	}
+	++l;
+	__syncthreads();
+	WideOut o;
+	o.sigma = S.x[tid * XS];
+	{ // [density out | direction encoding | ones up to the network's input alignment | zeros up to the MFMA K block]
+		half_t* row = S.x + tid * XS;
+		const uint32_t k_end = 16u * W.layers[l].n_kblocks;
+		for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + tid * DIR_STRIDE + c);
+		for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
+			const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
+			const half8 fill = {v, v, v, v, v, v, v, v};
+			*(half8*)(row + c) = fill;
+		}
+	}
+	__syncthreads();
+	for (uint32_t k = 0; k < W.n_hidden_rgb; ++k, ++l) wide_hidden_layer<MT>(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, active);
+	if (mine) {
+		wide_out_layer(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, acc);
+		if (h == 0) {
+#pragma unroll
+			for (int t = 0; t < 2; ++t) S.out[32 * (2 * wave + t) + n] = pack4(acc[t][0], acc[t][1], acc[t][2], 0.f, false);
+		}
+	}
+	__syncthreads();
+	union { uint2 u; half_t hh[4]; } r;
+	r.u = S.out[tid];
+	o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
+	return o;
+}
+
+NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int tid, f3 d) {
+	const float dx = (d.x + 1.0f) * 0.5f, dy = (d.y + 1.0f) * 0.5f, dz = (d.z + 1.0f) * 0.5f;
+	half_t* out = S.dir + tid * DIR_STRIDE;
+	if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dx, dy, dz, out);
+	else sh4_all(dx, dy, dz, out);
+}
+
+// which halves of the block (128 samples = two waves' slots) hold a sample: a workgroup-uniform 2-bit mask (contains a barrier)
+NGP_DEV uint32_t active_halves(WideShared& S, int tid, bool run) {
+	const unsigned long long m = __ballot(run);
+	if ((tid & 63) == 0) S.tile_mask[tid >> 6] = m != 0ull ? 1u : 0u;
+	__syncthreads();
+	const uint32_t mask = (S.tile_mask[0] | S.tile_mask[1]) | ((S.tile_mask[2] | S.tile_mask[3]) << 1);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)mask);
+}
+
+template <bool PROBE, int MT>
+NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
+	__shared__ WideShared S;
+	const WideModel& W = M.wide;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const uint32_t max_cascade = M.max_cascade;
+	const float cone_angle = M.cone_angle;
+	if (tid == 0) atomicMax(&F.results[4], ~realtime());
+	const float* cam_last = C.moving ? C.m1 : C.m;
+	const f3 cam_fwd = mk3(cam_last[6], cam_last[7], cam_last[8]);
+	const f3 cam_pos = mk3(cam_last[9], cam_last[10], cam_last[11]);
+	const f3 bg_linear = (PROBE || !F.direct) ? mk3(0.f, 0.f, 0.f)
+	                     : F.color_space == 1 ? mk3(F.background[0], F.background[1], F.background[2])
+	                                          : mk3(srgb_to_linear(F.background[0]), srgb_to_linear(F.background[1]), srgb_to_linear(F.background[2]));
+	const float4 empty_pixel = (!PROBE && F.direct) ? tonemap_pixel(F, bg_linear, 0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
+	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
+
+	RayState ray;
+	ray.alive = false;
+	ray.o = ray.d = mk3(0.f, 0.f, 0.f);
+	ray.t = 0.f;
+	ray.idx = ray.out = 0;
+	f3 idir = mk3(0.f, 0.f, 0.f);
+	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	uint32_t step = 1, skip_i = 1;
+	bool ready = false, counted = false, finished = false, exhausted = false;
+	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
+	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
+	int stall = 0;
+
+	for (;;) {
+		// ---- retire finished rays (K7) and refill free slots from the strip queue (K1 + the jitter of K2), per wave
+		const unsigned long long dead_mask = __ballot(!ray.alive);
+		const int n_dead = __popcll(dead_mask);
+		if (__any(finished)) {
+			bool hit = false;
+			if (finished) {
+				hit = shade_ray<PROBE, false>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d);
+				finished = false;
+			}
+			n_hit += (uint32_t)__popcll(__ballot(hit));
+		}
+		if (!exhausted && n_dead >= 16) {
+			const uint32_t want = (uint32_t)n_dead >> 4, n_strips = F.n_local_tiles * 4u;
+			uint32_t first = 0;
+			if (lane == 0) first = atomicAdd(F.queue, want);
+			first = __builtin_amdgcn_readfirstlane(first);
+			if (first >= n_strips) {
+				exhausted = true;
+			} else {
+				const uint32_t got = n_strips - first < want ? n_strips - first : want;
+				const uint32_t r = lanes_below(dead_mask);
+				const uint32_t strip = first + (r >> 4);
+				const bool take = !ray.alive && r < got * 16u;
+				const uint32_t tile_local = strip >> 2, slot = (strip & 3u) * 16u + (r & 15u);
+				const uint32_t tile = F.shard_index + F.shard_count * tile_local;
+				bool fresh = false;
+				if (PROBE) {
+					const uint32_t q = tile * 64u + slot;
+					if (take && q < P.n_rays) {
+						init_probe_ray(P, q, ray);
+						fresh = true;
+					}
+				} else if (take) {
+					const uint32_t x = (tile % F.tiles_x) * 8u + (slot & 7u);
+					const uint32_t y = (tile / F.tiles_x) * 8u + (slot >> 3);
+					if (x < (uint32_t)C.width && y < (uint32_t)C.height) {
+						init_ray<false>(M, C, x, y, ray);
+						if (F.packed) ray.out = tile_local * 64u + slot;
+						if (!F.envmap) {
+							if (F.direct) {
+								F.frame_buffer[ray.out] = empty_pixel;
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							} else if (F.depth_buffer[ray.out] < 0.01f) {
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							}
+						} else {
+							const bool valid = ray.d.x != 0.0f || ray.d.y != 0.0f || ray.d.z != 0.0f;
+							float env[4] = {0.f, 0.f, 0.f, 0.f};
+							if (valid) {
+								float d3[3] = {ray.d.x, ray.d.y, ray.d.z};
+								read_envmap(F.envmap, F.env_w, F.env_h, d3, env);
+							}
+							if (F.direct) {
+								F.frame_buffer[ray.out] = valid ? tonemap_pixel(F, bg_linear, env[0], env[1], env[2], env[3]) : empty_pixel;
+								F.depth_buffer[ray.out] = MAX_DEPTH;
+							} else {
+								if (valid) F.frame_buffer[ray.out] = make_float4(env[0], env[1], env[2], env[3]);
+								if (F.depth_buffer[ray.out] < 0.01f) F.depth_buffer[ray.out] = MAX_DEPTH;
+							}
+						}
+						if (ray.alive) {
+							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u));
+							fresh = true;
+						}
+					}
+				}
+				if (fresh) {
+					encode_direction(W, S, tid, ray.d); // (the slot's own row: nobody else touches it)
+					idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+					acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+					step = 1;
+					skip_i = 1;
+					ready = false;
+					counted = PROBE;
+				}
+				if (PROBE) n_alive_init += (uint32_t)__popcll(__ballot(fresh));
+			}
+		}
+
+		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494): every marching slot walks to its next
+		// sample (or out of the box), at most 64 voxels per round so that one long empty stretch does not hold up the workgroup
+		bool newly_counted = false;
+		if (ray.alive && !ready) {
+			for (int k = 0; k < 64; ++k) {
+				const f3 pos = add3(ray.o, scale3(ray.d, ray.t));
+				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
+				if (PROBE && skip_i >= 200) out = true;
+				if (out) {
+					ray.alive = false;
+					finished = true;
+					break;
+				}
+				uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
+				mip = mip > max_cascade ? max_cascade : mip;
+				if (density_grid_occupied_at(pos, M.bitfield, mip)) {
+					const float dt = calc_dt(ray.t, cone_angle);
+					f3 w = sub3(pos, amin);
+					if (M.diag_pow2) w = mul3(w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
+					else w = div3(w, adiag);
+					wx = w.x; wy = w.y; wz = w.z;
+					wdt = warp_dt(dt);
+					ray.t = ray.t + dt;
+					ready = true;
+					skip_i = 1;
+					newly_counted = !counted;
+					counted = true;
+					break;
+				}
+				while (mip < max_cascade && !density_grid_occupied_at(pos, M.bitfield, mip + 1)) ++mip;
+				const float grid_half = 0.5f * (float)(1u << max_cascade);
+				const bool outside = !PROBE && mip == max_cascade &&
+				                     fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f)) > grid_half;
+				const float to_grid = outside ? grid_cube_entry(pos, idir, grid_half) : 0.0f;
+				if (outside && to_grid < 0.0f) {
+					ray.alive = false;
+					finished = true;
+					break;
+				} else if (outside && to_grid > 0.0f) {
+					ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
+				} else {
+					ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip);
+				}
+				++skip_i;
+			}
+		}
+		n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
+
+		// ---- workgroup decision: run the network once most slots hold a sample or nothing else can fill them
+		const int n_ready = __syncthreads_count(ready);
+		const int n_progress = __syncthreads_count((ray.alive && !ready) || finished || (!ray.alive && !exhausted));
+		if (n_ready == 0) {
+			if (n_progress == 0) break;
+			continue;
+		}
+		if (n_ready < WBLOCK - 32 && n_progress > 0 && stall < 3) {
+			++stall;
+			continue;
+		}
+		stall = 0;
+
+		// ---- K5: position encoding into the slot's row, then the network on the whole block
+		const bool run = ready;
+		if (run) frequency_encode(W.pos_freqs, W.enc_dims, wx, wy, wz, S.x + tid * XS, 16u * W.layers[0].n_kblocks);
+		const uint32_t active = active_halves(S, tid, run); // (its barrier also publishes the rows)
+		const WideOut o = wide_network<MT>(W, S, tid, active);
+
+		// ---- K6: composite_kernel_nerf (:569-726)
+		if (run) {
+			ready = false;
+			const f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag));
+			const float sdepth = dot3(cam_fwd, sub3(pos, cam_pos));
+			const float T = 1.0f - acc.a;
+			const float dt = unwarp_dt(wdt);
+			const float alpha = 1.0f - fast_exp(-network_to_density((float)o.sigma, M.density_act) * dt);
+			const float weight = alpha * T;
+			float cr = network_to_rgb((float)o.r, M.rgb_act), cg = network_to_rgb((float)o.g, M.rgb_act), cb = network_to_rgb((float)o.b, M.rgb_act);
+			if (!PROBE && F.render_mode > 1) {
+				if (F.render_mode == 2) {
+					cr = cg = cb = alpha;
+				} else if (F.render_mode == 3) {
+					cr = (pos.x - 0.5f) / 2.0f + 0.5f; cg = (pos.y - 0.5f) / 2.0f + 0.5f; cb = (pos.z - 0.5f) / 2.0f + 0.5f;
+				} else if (F.render_mode == 4) {
+					cr = cg = cb = dot3(cam_fwd, sub3(pos, ray.o)) * F.depth_scale;
+				}
+			}
+			acc.r += cr * weight;
+			acc.g += cg * weight;
+			acc.b += cb * weight;
+			acc.a += weight;
+			if (weight > acc.max_weight) {
+				acc.max_weight = weight;
+				acc.depth = sdepth;
+			}
+			++step;
+			if (acc.a > (1.0f - F.min_transmittance)) {
+				acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
+				ray.alive = false;
+				finished = true;
+			} else if (step >= MARCH_ITER) {
+				ray.alive = false;
+			}
+		}
+		n_samples += (uint32_t)__popcll(__ballot(run));
+	}
+	finish_launch(F, lane, n_alive_init, n_hit, n_samples);
+}
+
+#define NGP_WIDE_KERNEL __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
+
+NGP_WIDE_KERNEL void render_nerf_wide256(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	wide_body<false, 2>(M, C, F, P);
+}
+NGP_WIDE_KERNEL void render_nerf_wide128(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	wide_body<false, 1>(M, C, F, P);
+}
+NGP_WIDE_KERNEL void trace_probe_wide256(const ModelParams M, const FrameParams F, const ProbeParams P) {
+	CameraParams C{};
+	wide_body<true, 2>(M, C, F, P);
+}
+NGP_WIDE_KERNEL void trace_probe_wide128(const ModelParams M, const FrameParams F, const ProbeParams P) {
+	CameraParams C{};
+	wide_body<true, 1>(M, C, F, P);
+}
+
+// NerfNetwork::inference on explicit inputs (ngp_network_inference): 256 samples per workgroup round
+template <int MT>
+NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
+	__shared__ WideShared S;
+	const WideModel& W = M.wide;
+	const int tid = threadIdx.x;
+	for (uint32_t base = blockIdx.x * WBLOCK; base < n; base += gridDim.x * WBLOCK) { // (workgroup-uniform trip count)
+		const uint32_t i = base + (uint32_t)tid;
+		const bool run = i < n;
+		if (run) {
+			frequency_encode(W.pos_freqs, W.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], S.x + tid * XS, 16u * W.layers[0].n_kblocks);
+			half_t* d = S.dir + tid * DIR_STRIDE;
+			if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
+			else sh4_all(dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
+		}
+		const uint32_t active = active_halves(S, tid, run);
+		const WideOut o = wide_network<MT>(W, S, tid, active);
+		if (run) {
+			union { half_t h[4]; uint2 u; } p;
+			p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
+			*(uint2*)(out + 4 * (size_t)i) = p.u;
+		}
+	}
+}
+NGP_WIDE_KERNEL void network_inference_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
+	wide_inference_body<2>(M, n, pos01, dir01, out);
+}
+NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
+	wide_inference_body<1>(M, n, pos01, dir01, out);
+}
+// the position encoding alone (ngp_grid_encode's counterpart for this architecture): n x enc_dims halves
+__global__ void frequency_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	frequency_encode(M.wide.pos_freqs, M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], (half_t*)out + (size_t)M.wide.enc_dims * i);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers: one workgroup per CU (the activations take 132 of the CU's 160 KB of LDS)
+static int wide_blocks(const FrameParams& F, int n_cus) {
+	int n_blocks = n_cus;
+	const int needed = (int)((F.n_local_tiles + 3) / 4);
+	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
+	return n_blocks;
+}
+void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
+	const int n_blocks = wide_blocks(F, n_cus);
+	FrameParams G = F;
+	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
+	if (M.wide.width == 256) hipLaunchKernelGGL(render_nerf_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
+	else hipLaunchKernelGGL(render_nerf_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
+}
+void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {
+	const int n_blocks = wide_blocks(F, n_cus);
+	FrameParams G = F;
+	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
+	if (M.wide.width == 256) hipLaunchKernelGGL(trace_probe_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, G, P);
+	else hipLaunchKernelGGL(trace_probe_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, G, P);
+}
+void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, int n_cus, hipStream_t stream) {
+	if (n == 0) return;
+	int n_blocks = (int)((n + WBLOCK - 1) / WBLOCK);
+	if (n_blocks > n_cus) n_blocks = n_cus;
+	if (M.wide.width == 256) hipLaunchKernelGGL(network_inference_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
+	else hipLaunchKernelGGL(network_inference_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
+}
+void launch_frequency_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(frequency_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, M, n, pos01, out);
+}
+
+} // namespace ngp

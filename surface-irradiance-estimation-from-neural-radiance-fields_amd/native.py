@@ -38,6 +38,8 @@ class ModelDesc(C.Structure):
         ("render_aabb_min", C.c_float * 3), ("render_aabb_max", C.c_float * 3),
         ("render_aabb_to_local", C.c_float * 9),
         ("aabb_scale", C.c_uint32), ("cone_angle_constant", C.c_float), ("linear_colors", C.c_int32),
+        ("pos_encoding", C.c_uint32), ("pos_n_frequencies", C.c_uint32), ("dir_encoding", C.c_uint32), ("dir_n_frequencies", C.c_uint32),
+        ("mlp_alignment", C.c_uint32),
     ]
 
 
@@ -333,9 +335,16 @@ class Context:
     def set_model(self, scene):
         d = ModelDesc()
         enc = scene["encoding"]
-        d.n_levels, d.n_features_per_level = enc["n_levels"], enc["n_features_per_level"]
-        d.log2_hashmap_size, d.base_resolution = enc["log2_hashmap_size"], enc["base_resolution"]
-        d.per_level_scale = enc["per_level_scale"]
+        if enc.get("otype") == "Frequency":  # configs/nerf/frequency.json
+            d.pos_encoding, d.pos_n_frequencies = 1, enc["n_frequencies"]
+            de = scene.get("dir_encoding", {})
+            if de.get("otype") == "Frequency":
+                d.dir_encoding, d.dir_n_frequencies = 1, de["n_frequencies"]
+            d.mlp_alignment = 8 if scene["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+        else:
+            d.n_levels, d.n_features_per_level = enc["n_levels"], enc["n_features_per_level"]
+            d.log2_hashmap_size, d.base_resolution = enc["log2_hashmap_size"], enc["base_resolution"]
+            d.per_level_scale = enc["per_level_scale"]
         d.n_neurons = scene["network"]["n_neurons"]
         d.n_hidden_density = scene["network"]["n_hidden_layers"]
         d.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]
@@ -542,7 +551,10 @@ class Context:
     # ---------------------------------------------------------------- stages
     def grid_encode(self, pos01):
         pos01 = np.ascontiguousarray(pos01, np.float32)
-        out = np.zeros((pos01.shape[0], 32), np.uint16)
+        d = self.get_model()  # a Frequency position encoding (pos_encoding 1) is as wide as its padded 3 * 2 * n_frequencies
+        al = d.mlp_alignment or 16
+        width = (6 * d.pos_n_frequencies + al - 1) // al * al if d.pos_encoding == 1 else 32
+        out = np.zeros((pos01.shape[0], width), np.uint16)
         self._check(self.L.ngp_grid_encode(self.h, pos01.shape[0], _p(pos01), _p(out)))
         return out.view(np.float16)
 

@@ -1,0 +1,155 @@
+"""GPU parity of the second architecture: configs/nerf/frequency.json -- Frequency encodings of position and
+direction, MLPs 256 (or 128) wide -- through the C ABI against the CPU oracle on the same seeded inputs.
+
+Bars: the encoding within one fp16 spacing (two correctly rounded sines of the same fp32 argument can differ in the last fp32
+bit, which flips an fp16 rounding in ~1e-4 of the features); network outputs within a few fp16 spacings of the logits (eight
+layers of fp16 activations, fp32 MFMA accumulation against the oracle's exact sums); images: identical ray statistics -- the
+march takes the reference's one-voxel steps, so the sample SETS are the oracle's -- and per-pixel |d| < 1e-2, PSNR >= 50 dB.
+"""
+import numpy as np
+import pytest
+
+from conftest import _with_bitfield, pkg, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(oracle, scene_mod, seed=3, aabb_scale=1, **kw):
+    cfg = scene_mod.frequency_network_config(**kw)
+    return _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=aabb_scale, seed=seed, cfg=cfg))
+
+
+@pytest.fixture(scope="module")
+def scene_freq(oracle, scene_mod):
+    return _scene(oracle, scene_mod)
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return pos, ((d + 1) * 0.5).astype(np.float32)
+
+
+def test_frequency_encoding(ctx, oracle, scene_freq):
+    ctx.set_model(scene_freq)
+    pos, _ = _rays(8192 + 5, 1)
+    pos[:4] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0.999999, 1e-7, 0.25]]
+    got = ctx.grid_encode(pos).astype(np.float32)
+    ref = oracle.frequency_encode(pos, 16).astype(np.float32)
+    assert got.shape == (pos.shape[0], 96) and ref.shape == got.shape
+    err = np.abs(got - ref)
+    assert err.max() <= 2.0 ** -10, err.max()  # one fp16 spacing below 1
+    assert (err == 0).mean() > 0.999
+    assert ctx.grid_encode(np.zeros((0, 3), np.float32)).shape == (0, 96)
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 20000])
+def test_network_outputs(n, ctx, oracle, scene_freq):
+    ctx.set_model(scene_freq)
+    m = oracle.make_model(scene_freq)
+    pos, dir01 = _rays(n, 11 + n)
+    got = ctx.network(pos, dir01).astype(np.float32)
+    ref = oracle.network(m, pos, dir01).astype(np.float32)
+    oracle.release(m)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)
+    assert err.max() <= 6e-2, f"max err {err.max()} at ref {ref.ravel()[err.argmax()]}"
+    if n >= 256:
+        assert (err <= 2 * ulp).mean() > 0.9
+
+
+@pytest.mark.parametrize("variant", ["w128_sh4_fullyfused", "w128_freq_cutlass_3_2", "w256_1_1"])
+def test_network_variants(variant, ctx, oracle, scene_mod):
+    """other shapes of the same family: 128 neurons, SphericalHarmonics directions with FullyFusedMLP alignment (16), other depths"""
+    if variant == "w128_sh4_fullyfused":
+        cfg = scene_mod.frequency_network_config(n_neurons=128, n_hidden_density=2, n_hidden_rgb=2)
+        cfg["dir_encoding"] = {"otype": "SphericalHarmonics", "degree": 4}
+        cfg["network"]["otype"] = cfg["rgb_network"]["otype"] = "FullyFusedMLP"
+        cfg["encoding"]["n_frequencies"] = 10  # 60 inputs -> padded to 64 with ones
+    elif variant == "w128_freq_cutlass_3_2":
+        cfg = scene_mod.frequency_network_config(n_neurons=128, n_hidden_density=3, n_hidden_rgb=2)
+        cfg["encoding"]["n_frequencies"] = 9   # 54 -> 56: the padding ones meet zero-padded weight columns up to the K block (64)
+        cfg["dir_encoding"]["n_frequencies"] = 3  # 18 -> 24
+    else:
+        cfg = scene_mod.frequency_network_config(n_neurons=256, n_hidden_density=1, n_hidden_rgb=1)
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=21, cfg=cfg))
+    ctx.set_model(sc)
+    m = oracle.make_model(sc)
+    pos, dir01 = _rays(3000, 5)
+    got = ctx.network(pos, dir01).astype(np.float32)
+    ref = oracle.network(m, pos, dir01).astype(np.float32)
+    oracle.release(m)
+    err = np.abs(got - ref)
+    assert np.isfinite(got).all() and err.max() <= 6e-2, err.max()
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+def test_render_matches_oracle(aabb_scale, ctx, oracle, native, scene_mod, scene_freq):
+    sc = scene_freq if aabb_scale == 1 else _scene(oracle, scene_mod, seed=8, aabb_scale=4)
+    ctx.set_model(sc)
+    m = oracle.make_model(sc)
+    w, h = (96, 54) if aabb_scale == 1 else (64, 36)
+    mat = scene_mod.orbit_camera(40.0, 25.0, 3.2 if aabb_scale == 1 else 5.0)
+    focal = scene_mod.focal_from_fov_x(w, 0.6911)
+    img, depth = ctx.render(native.make_camera(mat, w, h, focal), native.make_opts(), want_depth=True)
+    st = ctx.render_stats()
+    fb, db, ost = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal))
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    oracle.release(m)
+    # one-voxel marching: the samples are the oracle's unless a ray's termination flips on a network rounding
+    assert st["n_rays_alive_after_init"] == ost["n_rays_alive_after_init"]
+    assert abs(int(st["n_samples"]) - int(ost["n_samples"])) <= max(4, ost["n_samples"] // 2000)
+    assert abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 2
+    assert ost["n_samples"] > 10000 and img[..., 3].max() > 0.9
+    assert psnr(img[..., :3], ref[..., :3]) >= 50.0
+    d = np.abs(img - ref).max(-1)
+    tol = 1e-2 if aabb_scale == 1 else 3e-2  # (exponential stepping: logf / expf differ by ulps between libm and the device, as for base.json's big scenes)
+    assert (d < tol).mean() >= 0.999 and d.max() < 0.1, (float((d < tol).mean()), float(d.max()))
+    db = db.reshape(h, w)
+    both = (depth < 16000) & (db < 16000)
+    assert both.sum() > 100 and np.median(np.abs(depth[both] - db[both])) < 1e-3
+
+
+def test_snapshot_round_trip_and_modes(ctx, native, scene_mod, scene_freq, tmp_path):
+    ctx.set_model(scene_freq)
+    w, h = 64, 36
+    cam = native.make_camera(scene_mod.orbit_camera(10.0, 20.0, 3.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+    img0 = ctx.render(cam, native.make_opts(to_srgb=True))
+    path = str(tmp_path / "freq.ingp")
+    ctx.save_snapshot_file(path)
+    other = native.Context(0)
+    try:
+        other.load_snapshot_file(path)
+        d = other.get_model()
+        assert (d.pos_encoding, d.pos_n_frequencies, d.dir_encoding, d.dir_n_frequencies, d.mlp_alignment) == (1, 16, 1, 4, 8)
+        assert (d.n_neurons, d.n_hidden_density, d.n_hidden_rgb) == (256, 7, 1) and d.n_params == 421888 + 12288
+        img1 = other.render(cam, native.make_opts(to_srgb=True))
+        assert np.array_equal(img0, img1)
+        # the G-buffer modes and several samples per pixel go through the same kernel
+        for mode in (native.RENDER_AO, native.RENDER_POSITIONS, native.RENDER_DEPTH, native.RENDER_COST):
+            g = other.render(cam, native.make_opts(render_mode=mode))
+            assert np.isfinite(g).all() and g[..., 3].max() > 0.9
+        img4 = other.render(cam, native.make_opts(to_srgb=True, spp=4))
+        assert psnr(img4[..., :3], img0[..., :3]) > 25.0
+        with pytest.raises(RuntimeError, match="inference only"):
+            other.train(1)
+    finally:
+        other.close()
+
+
+def test_probe_envmap(ctx, native, scene_freq):
+    """the irradiance probes (K10: rays from the centre) run on this architecture too"""
+    ctx.set_model(scene_freq)
+    env = ctx.compute_envmap(n_theta=32, n_phi=16)
+    assert env.shape == (16, 32, 4)
+    assert np.isfinite(env).all() and env[..., 3].max() > 0.5

@@ -229,7 +229,7 @@ def test_snapshot_dense_and_unsupported_encodings(tmp_path, native):
     root["encoding"]["otype"], root["encoding"]["type"] = "Grid", "Dense"
     ctx2.load_snapshot_bytes(msgpack.packb(root, use_bin_type=True))
     assert ctx2.get_model().log2_hashmap_size == 31
-    for enc in ({"otype": "TiledGrid"}, {"otype": "Grid", "type": "Tiled"}, {"otype": "Frequency"}):
+    for enc in ({"otype": "TiledGrid"}, {"otype": "Grid", "type": "Tiled"}, {"otype": "OneBlob"}):
         bad = dict(root, encoding=dict(root["encoding"], **enc))
         with pytest.raises(RuntimeError, match="unsupported (encoding|grid type)"):
             ctx2.load_snapshot_bytes(msgpack.packb(bad, use_bin_type=True))
@@ -244,6 +244,43 @@ def test_snapshot_dense_and_unsupported_encodings(tmp_path, native):
             ctx2.load_snapshot_bytes(msgpack.packb(dict(root, **{key: val}), use_bin_type=True))
     for ok in ({"otype": "SphericalHarmonics", "degree": 4}, {"otype": "Composite", "nested": [{"otype": "SphericalHarmonics", "degree": 4}]}):
         ctx2.load_snapshot_bytes(msgpack.packb(dict(root, dir_encoding=ok), use_bin_type=True))
+    ctx2.close()
+    ctx.close()
+
+
+def test_frequency_architecture_snapshot(tmp_path, native, scene_mod):
+    """configs/nerf/frequency.json (SURVEY a-19): Frequency encodings + CutlassMLP 256 x 7 / 256 x 1. Shapes follow NerfNetwork's
+    padding to the MLP alignment (8 for CutlassMLP): 96 + 24 inputs, rgb input 40, rgb output 8."""
+    import msgpack
+
+    cfg = scene_mod.frequency_network_config()
+    assert scene_mod.network_shapes(cfg) == (96, 24, 40, 8)
+    assert scene_mod.n_params(cfg) == (96 * 256 + 6 * 256 * 256 + 16 * 256, 40 * 256 + 8 * 256, 0)
+    ff = scene_mod.frequency_network_config(n_neurons=128, n_hidden_density=2, n_hidden_rgb=2)
+    ff["network"]["otype"] = ff["rgb_network"]["otype"] = "FullyFusedMLP"
+    ff["encoding"]["n_frequencies"] = 10
+    assert scene_mod.network_shapes(ff) == (64, 32, 48, 16)  # alignment 16
+    sc = pkg("synthetic").make_scene(aabb_scale=2, seed=4, cfg=cfg)
+    ctx = native.Context(-1)
+    ctx.set_model(sc)
+    p = str(tmp_path / "freq.msgpack")
+    ctx.save_snapshot_file(p, compress=False)
+    root = msgpack.unpackb(open(p, "rb").read(), raw=False)
+    assert root["encoding"] == {"otype": "Frequency", "n_frequencies": 16} and root["dir_encoding"] == {"otype": "Frequency", "n_frequencies": 4}
+    assert root["network"]["otype"] == "CutlassMLP" and root["network"]["n_hidden_layers"] == 7 and root["rgb_network"]["n_neurons"] == 256
+    assert root["snapshot"]["n_params"] == 421888 + 12288
+    ctx2 = native.Context(-1)
+    ctx2.load_snapshot_file(p)
+    d = ctx2.get_model()
+    assert (d.pos_encoding, d.pos_n_frequencies, d.dir_encoding, d.dir_n_frequencies, d.mlp_alignment, d.aabb_scale) == (1, 16, 1, 4, 8, 2)
+    # the direction encoding inside a Composite (how base.json spells its own), and a parameter count that does not follow the shapes
+    comp = {"otype": "Composite", "nested": [{"otype": "Frequency", "n_frequencies": 4, "n_dims_to_encode": 3}, {"otype": "Identity"}]}
+    ctx2.load_snapshot_bytes(msgpack.packb(dict(root, dir_encoding=comp), use_bin_type=True))
+    assert ctx2.get_model().dir_n_frequencies == 4
+    with pytest.raises(RuntimeError, match="parameter count mismatch"):
+        ctx2.load_snapshot_bytes(msgpack.packb(dict(root, encoding={"otype": "Frequency", "n_frequencies": 12}), use_bin_type=True))
+    with pytest.raises(RuntimeError, match="unsupported network architecture"):
+        ctx2.load_snapshot_bytes(msgpack.packb(dict(root, network=dict(root["network"], n_neurons=64), rgb_network=dict(root["rgb_network"], n_neurons=64)), use_bin_type=True))
     ctx2.close()
     ctx.close()
 
