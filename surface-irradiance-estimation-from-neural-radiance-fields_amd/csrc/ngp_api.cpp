@@ -270,7 +270,7 @@ void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t
 WideLayer emit_wide_fragments(std::vector<uint16_t>& frags, const uint16_t* W, uint32_t n_out, uint32_t n_in) {
 	WideLayer L{};
 	L.frag_offset = (uint32_t)(frags.size() / 8);
-	L.n_kblocks = (uint16_t)((n_in + 15) / 16);
+	L.n_kblocks = (uint16_t)(n_in <= 128 ? 8 : 16); // the kernels are instantiated for K = 128 and 256 (zero columns beyond the matrix)
 	L.n_mtiles = (uint16_t)((n_out + 31) / 32);
 	frags.resize(frags.size() + (size_t)L.n_mtiles * L.n_kblocks * 64 * 8, 0);
 	uint16_t* out = frags.data() + (size_t)L.frag_offset * 8;

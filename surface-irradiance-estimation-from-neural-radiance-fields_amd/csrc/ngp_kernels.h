@@ -61,7 +61,7 @@ static_assert(sizeof(NerfPayload) == 40, "NerfPayload layout");
 constexpr int WIDE_MAX_LAYERS = 24;
 struct WideLayer {
 	uint32_t frag_offset;
-	uint16_t n_kblocks; // 16-wide blocks of the (zero-padded) input
+	uint16_t n_kblocks; // 16-wide blocks of the input, zero-padded to 8 or 16 blocks (K = 128 or 256: what wide_kernels.hip is instantiated for)
 	uint16_t n_mtiles;  // 32-row tiles of the (zero-padded) output
 };
 struct WideModel {

@@ -15,13 +15,15 @@
 //                width / 4 neurons (2 M-tiles for 256) and takes the 256 samples as two halves of 4 tiles: 8 accumulator tiles =
 //                128 fp32 registers at a time, every B read feeds two MFMAs (LDS at half its rate when the MFMA pipe is full).
 //                One wave per SIMD (the 132 KB of LDS allow one workgroup per CU anyway) with gfx950's 512 registers
-//   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2
+//   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2; a wave holds its
+//                fragments of a whole layer in registers (128 for 64 neurons x 256 inputs) and requests them one layer ahead
 //   B operand    ds_read_b128 of X[sample][16 kb + 8 h ..]; each B read feeds two MFMAs
 //   output tile  lane (n, h) holds neurons 8q + 4h + r of sample n: four 8-byte LDS writes per tile put them back in row n
 //   a half of the block (128 samples) in which no slot holds a sample (the tail of a frame) is skipped, reads and MFMAs alike
 //
-// Sample sets are the reference's exactly: the march is the one-voxel-at-a-time loop of nerf_device.cuh:461-494 on the occupancy
-// bitfield in global memory (L2), no block jumps.
+// The march is the loop of nerf_device.cuh:461-494 on the occupancy bitfield in global memory (L2), one 8-byte word = one 4^3 block
+// of cells per load, kept by the lane; like the base.json kernel it leaves empty 4^3 / 16^3 blocks in one step unless
+// FrameParams::tune[6] (ngp_set_schedule's block_jumps) is 0, which gives the reference's one-voxel steps and its exact sample sets.
 #include "render_common.h"
 
 namespace ngp {
@@ -35,8 +37,34 @@ struct WideShared {
 	half_t x[WBLOCK * XS];
 	half_t dir[WBLOCK * DIR_STRIDE]; // per ray slot: the encoded direction, constant along the ray
 	uint2 out[WBLOCK];               // rgb + density logit of the slot's sample
-	uint32_t tile_mask[4];           // per wave: which of its two 32-sample tiles hold a sample this round
+	uint32_t tile_mask[4];           // per wave: does it hold a sample this round
+	uint32_t coarse16[NERF_CASCADES * 16]; // per cascade: which 16^3-cell blocks of the occupancy grid hold anything (ModelParams::coarse, tail)
 };
+
+// The march's occupancy lookup (cf. empty_block_size_at, nerf_device.h): 0 = the cell is occupied, else the side (in cells of this
+// cascade) of the largest aligned empty block around pos that can be vouched for: 16 (summary bits in LDS), 4 (the 64 occupancy
+// bits of a 4x4x4 block are one aligned 8-byte word of the Morton-ordered bitfield: all zero = the block is empty) or 1. The
+// lane keeps the last word it read: a ray spends many consecutive lookups in one block, and every miss is an L2 round trip that
+// nothing hides at one wave per SIMD.
+NGP_DEV uint32_t empty_block_size_global(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse16, uint32_t mip, OccBlockCache& cache) {
+	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
+	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
+	int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
+	int iy = (int)(pos.y * (float)NERF_GRIDSIZE);
+	int iz = (int)(pos.z * (float)NERF_GRIDSIZE);
+	if (ix < 0 || ix >= (int)NERF_GRIDSIZE || iy < 0 || iy >= (int)NERF_GRIDSIZE || iz < 0 || iz >= (int)NERF_GRIDSIZE) return 1u;
+	const uint32_t idx = morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+	const uint32_t b16 = idx >> 12;
+	if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
+	const uint32_t b4 = idx >> 6, key = (mip << 26) | b4;
+	if (cache.key != key) {
+		cache.bits = *(const uint2*)(bitfield + (size_t)b4 * 8 + (size_t)(NERF_GRID_N_CELLS / 8) * mip);
+		cache.key = key;
+	}
+	if ((cache.bits.x | cache.bits.y) == 0u) return 4u;
+	const uint32_t word = (idx & 32u) ? cache.bits.y : cache.bits.x;
+	return ((word >> (idx & 31u)) & 1u) ? 0u : 1u;
+}
 
 NGP_DEV floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -59,94 +87,102 @@ NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y
 	}
 	const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
 	for (uint32_t j = 6u * n_freq; j < padded; j += 2u) *(half2_t*)(out + j) = ones;
-	const half2_t zeros = {(half_t)0.0f, (half_t)0.0f};
-	for (uint32_t j = padded; j < k_end; j += 2u) *(half2_t*)(out + j) = zeros;
+	const half8 zeros = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (uint32_t j = padded; j < k_end; j += 8u) *(half8*)(out + j) = zeros; // (padded is a multiple of 8 and the row 16-byte aligned)
 }
 
 NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
-	union { half_t h[4]; uint2 u; } p;
-	p.h[0] = (half_t)a; p.h[1] = (half_t)b; p.h[2] = (half_t)c; p.h[3] = (half_t)d;
-	if (relu) {
-#pragma unroll
-		for (int i = 0; i < 4; ++i) p.h[i] = p.h[i] > (half_t)0 ? p.h[i] : (half_t)0; // max(round(x), 0) == round(max(x, 0))
+	half2_t lo = {(half_t)a, (half_t)b}, hi = {(half_t)c, (half_t)d}; // v_cvt_pk_f16_f32
+	if (relu) { // max(round(x), 0) == round(max(x, 0)): v_pk_max_f16
+		const half2_t zero = {(half_t)0.0f, (half_t)0.0f};
+		lo = __builtin_elementwise_max(lo, zero);
+		hi = __builtin_elementwise_max(hi, zero);
 	}
-	return p.u;
+	return make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
-// One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 n_kb)). The 256 samples are taken as two halves of four
-// 32-sample tiles (128 accumulator registers each; the weights' A fragments are read once per half); `active` bit g = half g
-// (samples 128g .. 128g+127) holds at least one sample and is computed.
-template <int MT>
-NGP_DEV void wide_hidden_layer(half_t* X, const uint4* __restrict__ frags, int n_kb, int wave, int lane, uint32_t active) {
+// The weights a wave needs for one layer -- its MFMA A fragments, up to 32 of them (2 M-tiles x 16 K-blocks) -- are held in 128
+// registers for the whole layer and requested one layer ahead: the loads are issued right after the previous layer's last MFMA and
+// land while that layer's outputs are packed, exchanged and written back. The barriers inside the network wait for LDS traffic only
+// (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() would also drain the outstanding global loads, i.e. the prefetch.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 AReg[32];
+NGP_DEV void prefetch_frags(AReg& a, const uint4* __restrict__ base, int count) {
+	// (one uniform guard per fragment, in groups of 8: every element of `a` is accessed the same way on every path, which is what lets
+	// the array live in registers)
+#pragma unroll
+	for (int i = 0; i < 32; ++i)
+		if (i < ((count + 7) & ~7)) a[i] = *(const u32x4*)(base + (size_t)i * 64);
+}
+NGP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+NGP_DEV half8 as_half8(u32x4 u) { return __builtin_bit_cast(half8, u); }
+
+// One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)), the wave's fragments a[m * NKB + kb] already in
+// flight. The 256 samples are taken as two halves of four 32-sample tiles (128 accumulator registers); `active` bit g = half g
+// (samples 128g .. 128g+127) holds at least one sample and is computed. Half 0's outputs are written while half 1 is computed
+// (after a barrier: every wave has read half 0's rows by then), so only one half's packed outputs wait in registers.
+template <int MT, int NKB>
+NGP_DEV void wide_hidden_layer(half_t* X, AReg& a, int wave, int lane, uint32_t active, const uint4* __restrict__ next_base, int next_count) {
 	const int n = lane & 31, h = lane >> 5;
-	const uint4* wf = frags + (size_t)(wave * MT) * n_kb * 64 + lane;
-	union AF { uint4 u; half8 v; };
-	uint2 packed[2][MT][4][4]; // the layer's outputs as fp16, kept until every wave has read its inputs
+	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
-		if (!((active >> g) & 1u)) continue;
-		floatx16 acc[MT][4];
-		const half_t* col = X + (128 * g + n) * XS + 8 * h;
-		{ // first K block: the accumulators start from the products (C = 0 is an inline constant)
-			const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-			AF a[MT];
+		const bool on = (active >> g) & 1u;
+		uint2 packed[MT][4][4];
+		if (on) {
+			floatx16 acc[MT][4];
+			const half_t* col = X + (128 * g + n) * XS + 8 * h;
+			// the B operands of K block kb + 1 are read while the 4 MT MFMAs of block kb run (two register sets)
+			half8 b[2][4];
 #pragma unroll
-			for (int m = 0; m < MT; ++m) a[m].u = wf[(size_t)m * n_kb * 64];
+			for (int t = 0; t < 4; ++t) b[0][t] = *(const half8*)(col + 32 * t * XS);
 #pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const half8 b = *(const half8*)(col + 32 * t * XS);
+			for (int kb = 0; kb < NKB; ++kb) {
+				if (kb + 1 < NKB) {
 #pragma unroll
-				for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(a[m].v, b, zero);
+					for (int t = 0; t < 4; ++t) b[(kb + 1) & 1][t] = *(const half8*)(col + 32 * t * XS + 16 * (kb + 1));
+				}
+				__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use, one block late)
+#pragma unroll
+				for (int t = 0; t < 4; ++t)
+#pragma unroll
+					for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(a[m * NKB + kb]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
+				__builtin_amdgcn_sched_barrier(0);
 			}
-		}
-		for (int kb = 1; kb < n_kb; ++kb) {
-			AF a[MT];
-#pragma unroll
-			for (int m = 0; m < MT; ++m) a[m].u = wf[((size_t)m * n_kb + kb) * 64];
-#pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const half8 b = *(const half8*)(col + 32 * t * XS + 16 * kb);
-#pragma unroll
-				for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(a[m].v, b, acc[m][t]);
-			}
-		}
-#pragma unroll
-		for (int m = 0; m < MT; ++m)
-#pragma unroll
-			for (int t = 0; t < 4; ++t)
-#pragma unroll
-				for (int q = 0; q < 4; ++q) packed[g][m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
-	}
-	__syncthreads(); // every wave has read the layer's input
-#pragma unroll
-	for (int g = 0; g < 2; ++g) {
-		if (!((active >> g) & 1u)) continue;
-#pragma unroll
-		for (int t = 0; t < 4; ++t) {
-			half_t* row = X + (128 * g + 32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
 #pragma unroll
 			for (int m = 0; m < MT; ++m)
 #pragma unroll
-				for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[g][m][t][q];
+				for (int t = 0; t < 4; ++t)
+#pragma unroll
+					for (int q = 0; q < 4; ++q) packed[m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
+		}
+		if (g == 1) prefetch_frags(a, next_base, next_count); // the layer's own fragments have been used for the last time
+		lds_barrier(); // every wave has read this half's rows
+		if (on) {
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				half_t* row = X + (128 * g + 32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
+#pragma unroll
+				for (int m = 0; m < MT; ++m)
+#pragma unroll
+					for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[m][t][q];
+			}
 		}
 	}
-	__syncthreads();
+	lds_barrier();
 }
 
-// An output layer (at most 32 neurons, no activation): wave w computes its own two sample tiles 2w, 2w+1 (both in half w >> 1).
-NGP_DEV void wide_out_layer(const half_t* X, const uint4* __restrict__ frags, int n_kb, int wave, int lane, floatx16 (&acc)[2]) {
+// An output layer (at most 32 neurons, no activation): wave w computes its own two sample tiles 2w, 2w+1 (both in half w >> 1)
+template <int NKB>
+NGP_DEV void wide_out_layer(const half_t* X, AReg& a, int wave, int lane, floatx16 (&acc)[2]) {
 	const int n = lane & 31, h = lane >> 5;
+	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-	for (int t = 0; t < 2; ++t)
-#pragma unroll
-		for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-	union { uint4 u; half8 v; } a;
-	for (int kb = 0; kb < n_kb; ++kb) {
-		a.u = frags[(size_t)kb * 64 + lane];
+	for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {
 			const half8 b = *(const half8*)(X + (32 * (2 * wave + t) + n) * XS + 16 * kb + 8 * h);
-			acc[t] = mfma32(a.v, b, acc[t]);
+			acc[t] = mfma32(as_half8(a[kb]), b, kb == 0 ? zero : acc[t]);
 		}
 	}
 }
@@ -155,54 +191,80 @@ struct WideOut {
 	half_t r, g, b, sigma;
 };
 
-// NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 256 sample rows. On entry row `tid` of
-// S.x holds the position encoding of thread tid's sample and S.dir its direction encoding (both visible: the caller has passed a
-// barrier); on exit every thread has its own sample's outputs and X may be overwritten.
+// where the wave's fragments of layer l start (lane included), and how many there are
+NGP_DEV const uint4* layer_frags(const WideModel& W, uint32_t l, bool is_out, int mt, int wave, int lane, int* count) {
+	const int nkb = (int)W.layers[l].n_kblocks;
+	*count = is_out ? nkb : mt * nkb;
+	return W.frags + W.layers[l].frag_offset + (is_out ? 0 : (size_t)(wave * mt) * nkb * 64) + lane;
+}
 template <int MT>
-NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, uint32_t active) {
+NGP_DEV void wide_network_prefetch(const WideModel& W, AReg& a, int tid) {
+	int count;
+	const uint4* base = layer_frags(W, 0, false, MT, tid >> 6, tid & 63, &count);
+	prefetch_frags(a, base, count);
+}
+
+// NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 256 sample rows. On entry row `tid` of
+// S.x holds the position encoding of thread tid's sample (zeros beyond it up to the first layer's K) and S.dir its direction
+// encoding, both visible (the caller has passed a barrier), and the first layer's fragments have been requested
+// (wide_network_prefetch); on exit every thread has its own sample's outputs and X may be overwritten.
+template <int MT>
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, uint32_t active, AReg& a) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
-	uint32_t l = 0;
-	for (; l < W.n_hidden_density; ++l) wide_hidden_layer<MT>(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, active);
+	const uint32_t n_layers = W.n_hidden_density + W.n_hidden_rgb + 2u;
 	const bool mine = (active >> (wave >> 1)) & 1u; // this wave's 64 samples belong to an active half
-	floatx16 acc[2];
-	if (mine) {
-		wide_out_layer(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, acc);
-		// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tiles: no other wave reads them now)
-#pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			half_t* row = S.x + (32 * (2 * wave + t) + n) * XS + 4 * h;
-#pragma unroll
-			for (int q = 0; q < 2; ++q) *(uint2*)(row + 8 * q) = pack4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3], false);
-		}
-	}
-	++l;
-	__syncthreads();
 	WideOut o;
-	o.sigma = S.x[tid * XS];
-	{ // [density out | direction encoding | ones up to the network's input alignment | zeros up to the MFMA K block]
-		half_t* row = S.x + tid * XS;
-		const uint32_t k_end = 16u * W.layers[l].n_kblocks;
-		for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + tid * DIR_STRIDE + c);
-		for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
-			const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
-			const half8 fill = {v, v, v, v, v, v, v, v};
-			*(half8*)(row + c) = fill;
+	for (uint32_t l = 0; l < n_layers; ++l) {
+		const bool density_out = l == W.n_hidden_density, rgb_out = l + 1u == n_layers;
+		const uint4* next_base = nullptr;
+		int next_count = 0;
+		if (!rgb_out) next_base = layer_frags(W, l + 1u, l + 1u == W.n_hidden_density || l + 2u == n_layers, MT, wave, lane, &next_count);
+		const int nkb = (int)W.layers[l].n_kblocks;
+		if (!density_out && !rgb_out) {
+			if (nkb == 16) wide_hidden_layer<MT, 16>(S.x, a, wave, lane, active, next_base, next_count);
+			else wide_hidden_layer<MT, 8>(S.x, a, wave, lane, active, next_base, next_count);
+			continue;
 		}
-	}
-	__syncthreads();
-	for (uint32_t k = 0; k < W.n_hidden_rgb; ++k, ++l) wide_hidden_layer<MT>(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, active);
-	if (mine) {
-		wide_out_layer(S.x, W.frags + W.layers[l].frag_offset, (int)W.layers[l].n_kblocks, wave, lane, acc);
-		if (h == 0) {
+		floatx16 acc[2];
+		if (mine) {
+			if (nkb == 16) wide_out_layer<16>(S.x, a, wave, lane, acc);
+			else wide_out_layer<8>(S.x, a, wave, lane, acc);
+		}
+		prefetch_frags(a, next_base, next_count);
+		if (density_out) {
+			// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tiles: no other wave reads them now)
+			if (mine) {
 #pragma unroll
-			for (int t = 0; t < 2; ++t) S.out[32 * (2 * wave + t) + n] = pack4(acc[t][0], acc[t][1], acc[t][2], 0.f, false);
+				for (int t = 0; t < 2; ++t) {
+					half_t* row = S.x + (32 * (2 * wave + t) + n) * XS + 4 * h;
+#pragma unroll
+					for (int q = 0; q < 2; ++q) *(uint2*)(row + 8 * q) = pack4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3], false);
+				}
+			}
+			lds_barrier();
+			o.sigma = S.x[tid * XS];
+			// [density out | direction encoding | ones up to the network's input alignment | zeros up to the next layer's K]
+			half_t* row = S.x + tid * XS;
+			const uint32_t k_end = 16u * W.layers[l + 1u].n_kblocks;
+			for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + tid * DIR_STRIDE + c);
+			for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
+				const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
+				const half8 fill = {v, v, v, v, v, v, v, v};
+				*(half8*)(row + c) = fill;
+			}
+			lds_barrier();
+		} else {
+			if (mine && h == 0) {
+#pragma unroll
+				for (int t = 0; t < 2; ++t) S.out[32 * (2 * wave + t) + n] = pack4(acc[t][0], acc[t][1], acc[t][2], 0.f, false);
+			}
+			lds_barrier();
+			union { uint2 u; half_t hh[4]; } r;
+			r.u = S.out[tid];
+			o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
 		}
 	}
-	__syncthreads();
-	union { uint2 u; half_t hh[4]; } r;
-	r.u = S.out[tid];
-	o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
 	return o;
 }
 
@@ -230,6 +292,11 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	const uint32_t max_cascade = M.max_cascade;
 	const float cone_angle = M.cone_angle;
 	if (tid == 0) atomicMax(&F.results[4], ~realtime());
+	if (tid < (int)NERF_CASCADES * 16) S.coarse16[tid] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + tid];
+	__syncthreads();
+	OccBlockCache occ_cache;
+	occ_cache.key = 0xffffffffu;
+	occ_cache.bits = make_uint2(0u, 0u);
 	const float* cam_last = C.moving ? C.m1 : C.m;
 	const f3 cam_fwd = mk3(cam_last[6], cam_last[7], cam_last[8]);
 	const f3 cam_pos = mk3(cam_last[9], cam_last[10], cam_last[11]);
@@ -252,8 +319,12 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
 	int stall = 0;
+	// diagnostic (NGP_PROFILE_SECTIONS=1: FrameParams::prof): cycle sums per section, taken by one lane per workgroup
+	const bool prof = F.prof != nullptr && tid == 0;
+	unsigned long long pt[4] = {0, 0, 0, 0}, p_rounds = 0, p_net = 0, p_ready = 0, t0 = 0, t1 = 0;
 
 	for (;;) {
+		if (prof) { t0 = stamp(); ++p_rounds; }
 		// ---- retire finished rays (K7) and refill free slots from the strip queue (K1 + the jitter of K2), per wave
 		const unsigned long long dead_mask = __ballot(!ray.alive);
 		const int n_dead = __popcll(dead_mask);
@@ -333,11 +404,12 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 
+		if (prof) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; }
 		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494): every marching slot walks to its next
 		// sample (or out of the box), at most 64 voxels per round so that one long empty stretch does not hold up the workgroup
 		bool newly_counted = false;
 		if (ray.alive && !ready) {
-			for (int k = 0; k < 64; ++k) {
+			for (int k = 0; k < 32; ++k) {
 				const f3 pos = add3(ray.o, scale3(ray.d, ray.t));
 				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
 				if (PROBE && skip_i >= 200) out = true;
@@ -348,7 +420,8 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 				}
 				uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
 				mip = mip > max_cascade ? max_cascade : mip;
-				if (density_grid_occupied_at(pos, M.bitfield, mip)) {
+				uint32_t empty = empty_block_size_global(pos, M.bitfield, S.coarse16, mip, occ_cache);
+				if (empty == 0u) {
 					const float dt = calc_dt(ray.t, cone_angle);
 					f3 w = sub3(pos, amin);
 					if (M.diag_pow2) w = mul3(w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
@@ -362,9 +435,15 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 					counted = true;
 					break;
 				}
-				while (mip < max_cascade && !density_grid_occupied_at(pos, M.bitfield, mip + 1)) ++mip;
+				// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490)
+				while (mip < max_cascade) {
+					const uint32_t e = empty_block_size_global(pos, M.bitfield, S.coarse16, mip + 1, occ_cache);
+					if (e == 0u) break;
+					++mip;
+					empty = e;
+				}
 				const float grid_half = 0.5f * (float)(1u << max_cascade);
-				const bool outside = !PROBE && mip == max_cascade &&
+				const bool outside = !PROBE && empty == 1u && mip == max_cascade &&
 				                     fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f)) > grid_half;
 				const float to_grid = outside ? grid_cube_entry(pos, idir, grid_half) : 0.0f;
 				if (outside && to_grid < 0.0f) {
@@ -374,7 +453,8 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 				} else if (outside && to_grid > 0.0f) {
 					ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
 				} else {
-					ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip);
+					// block jumps (FrameParams::tune[6], on by default like the base.json kernel): leave an empty 4^3 / 16^3 block in one step
+					ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
 				}
 				++skip_i;
 			}
@@ -384,6 +464,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		// ---- workgroup decision: run the network once most slots hold a sample or nothing else can fill them
 		const int n_ready = __syncthreads_count(ready);
 		const int n_progress = __syncthreads_count((ray.alive && !ready) || finished || (!ray.alive && !exhausted));
+		if (prof) { t1 = stamp(); pt[1] += t1 - t0; t0 = t1; }
 		if (n_ready == 0) {
 			if (n_progress == 0) break;
 			continue;
@@ -396,9 +477,13 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 
 		// ---- K5: position encoding into the slot's row, then the network on the whole block
 		const bool run = ready;
+		AReg afrag;
+		wide_network_prefetch<MT>(W, afrag, tid); // the first layer's weights travel while the sines are computed
 		if (run) frequency_encode(W.pos_freqs, W.enc_dims, wx, wy, wz, S.x + tid * XS, 16u * W.layers[0].n_kblocks);
 		const uint32_t active = active_halves(S, tid, run); // (its barrier also publishes the rows)
-		const WideOut o = wide_network<MT>(W, S, tid, active);
+		if (prof) { t1 = stamp(); pt[3] += t1 - t0; t0 = t1; ++p_net; p_ready += (unsigned long long)n_ready; }
+		const WideOut o = wide_network<MT>(W, S, tid, active, afrag);
+		if (prof) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; }
 
 		// ---- K6: composite_kernel_nerf (:569-726)
 		if (run) {
@@ -437,6 +522,14 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 		n_samples += (uint32_t)__popcll(__ballot(run));
+		if (prof) { t1 = stamp(); pt[3] += t1 - t0; }
+	}
+	if (prof) { // [refill, march + decision, network, encode + composite] cycles, rounds, network rounds (twice: the host divides by both), samples
+		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], pt[k]);
+		atomicAdd(&F.prof[4], p_rounds);
+		atomicAdd(&F.prof[5], p_net);
+		atomicAdd(&F.prof[6], p_net);
+		atomicAdd(&F.prof[7], p_ready);
 	}
 	finish_launch(F, lane, n_alive_init, n_hit, n_samples);
 }
@@ -469,6 +562,8 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 	for (uint32_t base = blockIdx.x * WBLOCK; base < n; base += gridDim.x * WBLOCK) { // (workgroup-uniform trip count)
 		const uint32_t i = base + (uint32_t)tid;
 		const bool run = i < n;
+		AReg afrag;
+		wide_network_prefetch<MT>(W, afrag, tid);
 		if (run) {
 			frequency_encode(W.pos_freqs, W.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], S.x + tid * XS, 16u * W.layers[0].n_kblocks);
 			half_t* d = S.dir + tid * DIR_STRIDE;
@@ -476,7 +571,7 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 			else sh4_all(dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
 		}
 		const uint32_t active = active_halves(S, tid, run);
-		const WideOut o = wide_network<MT>(W, S, tid, active);
+		const WideOut o = wide_network<MT>(W, S, tid, active, afrag);
 		if (run) {
 			union { half_t h[4]; uint2 u; } p;
 			p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
