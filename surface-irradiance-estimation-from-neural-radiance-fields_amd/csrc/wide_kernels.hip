@@ -4,22 +4,23 @@
 // src/testbed_nerf.cu:2056-2138 chain, with every layer a cutlass GEMM launch).
 //
 // One persistent kernel per sample-per-pixel, like the base.json kernel (nerf_kernels.hip), but organised around the GEMMs that
-// now dominate (0.87 MFLOP per sample, 42x base.json's): a workgroup of 4 waves owns 256 ray slots, one per thread; every round
-// each live slot marches to its next sample, the workgroup runs the network on the 256 samples with the activations resident in
-// LDS, and each thread composites its own sample. Rays never leave registers; the only HBM traffic is occupancy bits, the weight
-// fragments (868 KB, L2-resident, read once per workgroup round) and one frame-buffer write per pixel.
+// now dominate (0.87 MFLOP per sample, 42x base.json's). A workgroup of 4 waves owns 128 ray slots (threads 0..127): every round
+// each live slot marches to its next sample, the workgroup runs the network on the 128 samples with the activations resident in
+// LDS, and each slot composites its own sample. TWO workgroups share a CU (80 KB of LDS each, 2 waves per SIMD): while one
+// marches, evaluates sines or exchanges activations, the other one's MFMAs run -- the phases of one workgroup are serial, and
+// with one workgroup per CU the matrix pipe idled through all but the GEMM phase. Rays never leave registers; the only HBM
+// traffic is occupancy bits, the weight fragments (868 KB, L2-resident) and one frame-buffer write per pixel.
 //
-//   activations  X[256 samples][264] fp16 in LDS (132 KB, rows padded by 8 halves so that the 16-byte operand reads of 16
+//   activations  X[128 samples][264] fp16 in LDS (66 KB, rows padded by 8 halves so that the 16-byte operand reads of 16
 //                consecutive samples cover all 64 banks once); a layer is computed in place: all waves read, barrier, all write
 //   GEMM         v_mfma_f32_32x32x16_f16, weights on the A side (M = neurons), samples on the B side (N). A wave owns
-//                width / 4 neurons (2 M-tiles for 256) and takes the 256 samples as two halves of 4 tiles: 8 accumulator tiles =
-//                128 fp32 registers at a time, every B read feeds two MFMAs (LDS at half its rate when the MFMA pipe is full).
-//                One wave per SIMD (the 132 KB of LDS allow one workgroup per CU anyway) with gfx950's 512 registers
-//   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2; a wave holds its
-//                fragments of a whole layer in registers (128 for 64 neurons x 256 inputs) and requests them one layer ahead
-//   B operand    ds_read_b128 of X[sample][16 kb + 8 h ..]; each B read feeds two MFMAs
+//                width / 4 neurons (2 M-tiles for 256) and all four 32-sample tiles: 8 accumulator tiles = 128 fp32 registers,
+//                every B read feeds two MFMAs (LDS at half its rate when the MFMA pipe is full)
+//   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2, streamed through
+//                a ring of 4 K-blocks that runs 3 blocks (768 MFMA cycles) ahead of its use and on into the next layer
+//   B operand    ds_read_b128 of X[sample][16 kb + 8 h ..], read one K-block ahead into a second register set
 //   output tile  lane (n, h) holds neurons 8q + 4h + r of sample n: four 8-byte LDS writes per tile put them back in row n
-//   a half of the block (128 samples) in which no slot holds a sample (the tail of a frame) is skipped, reads and MFMAs alike
+//   encodings    the sines of a sample are split over two threads (tid and tid + 128): all four waves work through them
 //
 // The march is the loop of nerf_device.cuh:461-494 on the occupancy bitfield in global memory (L2), one 8-byte word = one 4^3 block
 // of cells per load, kept by the lane; like the base.json kernel it leaves empty 4^3 / 16^3 blocks in one step unless
@@ -28,18 +29,20 @@
 
 namespace ngp {
 
-constexpr int WBLOCK = 256;
+constexpr int WBLOCK = 256;    // threads of a workgroup
+constexpr int ROWS = 128;      // ray slots = samples per round
 constexpr int XS = 264;        // halves per activation row
 constexpr int DIR_STRIDE = 32; // halves per direction-encoding row
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct WideShared {
-	half_t x[WBLOCK * XS];
-	half_t dir[WBLOCK * DIR_STRIDE]; // per ray slot: the encoded direction, constant along the ray
-	uint2 out[WBLOCK];               // rgb + density logit of the slot's sample
-	uint32_t tile_mask[4];           // per wave: does it hold a sample this round
+	half_t x[ROWS * XS];
+	half_t dir[ROWS * DIR_STRIDE];         // per ray slot: the encoded direction, constant along the ray
+	float4 pos[ROWS];                      // the slot's sample position (w != 0: there is one) for the threads that encode it
+	uint2 out[ROWS];                       // rgb of the slot's sample
 	uint32_t coarse16[NERF_CASCADES * 16]; // per cascade: which 16^3-cell blocks of the occupancy grid hold anything (ModelParams::coarse, tail)
 };
+static_assert(2 * sizeof(WideShared) <= 160 * 1024, "two workgroups per CU");
 
 // The march's occupancy lookup (cf. empty_block_size_at, nerf_device.h): 0 = the cell is occupied, else the side (in cells of this
 // cascade) of the largest aligned empty block around pos that can be vouched for: 16 (summary bits in LDS), 4 (the 64 occupancy
@@ -70,14 +73,15 @@ NGP_DEV floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_
 
 // tcnn FrequencyEncoding (encodings/frequency.h): feature j of input x is
 //   sin(fma(scalbn(x[j / (2 F)], (j / 2) % F), pi, (j % 2) pi / 2))
-// rounded to fp16; inputs beyond 3 * 2 F up to `padded` are ones. Writes `padded` halves to out (4-byte aligned), then zeros up to
-// k_end (the MFMA K block the row is read in: the weights' columns there are zeros, which does not make 0 x stale-NaN a zero).
-NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y, float z, half_t* out, uint32_t k_end = 0) {
+// rounded to fp16; inputs beyond 3 * 2 F up to `padded` are ones. This call writes the features of frequencies [f_begin, f_end) of
+// the three inputs (4-byte aligned pairs); with `tail` also the ones up to `padded` and zeros from there to k_end (the MFMA K the row
+// is read in: the weights' columns there are zeros, which does not make 0 x stale-NaN a zero; 16-byte aligned).
+NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y, float z, half_t* out, uint32_t f_begin, uint32_t f_end, bool tail, uint32_t k_end = 0) {
 	const float PI = 3.14159265358979323846f;
 	const float in[3] = {x, y, z};
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
-		for (uint32_t f = 0; f < n_freq; ++f) {
+		for (uint32_t f = f_begin; f < f_end; ++f) {
 			const float v = __builtin_ldexpf(in[d], (int)f);
 			half2_t sc;
 			sc[0] = (half_t)sinf(__builtin_fmaf(v, PI, 0.0f));
@@ -85,10 +89,12 @@ NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y
 			*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
 		}
 	}
-	const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
-	for (uint32_t j = 6u * n_freq; j < padded; j += 2u) *(half2_t*)(out + j) = ones;
-	const half8 zeros = {0, 0, 0, 0, 0, 0, 0, 0};
-	for (uint32_t j = padded; j < k_end; j += 8u) *(half8*)(out + j) = zeros; // (padded is a multiple of 8 and the row 16-byte aligned)
+	if (tail) {
+		const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
+		for (uint32_t j = 6u * n_freq; j < padded; j += 2u) *(half2_t*)(out + j) = ones;
+		const half8 zeros = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (uint32_t j = padded; j < k_end; j += 8u) *(half8*)(out + j) = zeros; // (padded is a multiple of 8)
+	}
 }
 
 NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
@@ -101,187 +107,184 @@ NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
 	return make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
-// The weights a wave needs for one layer -- its MFMA A fragments, up to 32 of them (2 M-tiles x 16 K-blocks) -- are held in 128
-// registers for the whole layer and requested one layer ahead: the loads are issued right after the previous layer's last MFMA and
-// land while that layer's outputs are packed, exchanged and written back. The barriers inside the network wait for LDS traffic only
-// (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() would also drain the outstanding global loads, i.e. the prefetch.
+// The weights stream: a wave's MFMA A fragments of K-block kb sit in ring stage kb & 3, requested three K-blocks (24 MFMAs) before
+// their use; the ring runs on into the next layer (its first three blocks are requested while this layer's outputs are packed and
+// exchanged). The barriers inside the network wait for LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads()
+// would also drain the outstanding global loads, i.e. the stream.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 AReg[32];
-NGP_DEV void prefetch_frags(AReg& a, const uint4* __restrict__ base, int count) {
-	// (one uniform guard per fragment, in groups of 8: every element of `a` is accessed the same way on every path, which is what lets
-	// the array live in registers)
-#pragma unroll
-	for (int i = 0; i < 32; ++i)
-		if (i < ((count + 7) & ~7)) a[i] = *(const u32x4*)(base + (size_t)i * 64);
-}
 NGP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 NGP_DEV half8 as_half8(u32x4 u) { return __builtin_bit_cast(half8, u); }
 
-// One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)), the wave's fragments a[m * NKB + kb] already in
-// flight. The 256 samples are taken as two halves of four 32-sample tiles (128 accumulator registers); `active` bit g = half g
-// (samples 128g .. 128g+127) holds at least one sample and is computed. Half 0's outputs are written while half 1 is computed
-// (after a barrier: every wave has read half 0's rows by then), so only one half's packed outputs wait in registers.
+struct LayerFrags { // where this wave's fragments of a layer start (lane included), their K-blocks and M-tiles (0 tiles: no layer)
+	const uint4* base;
+	int nkb, mt;
+};
+template <int MT>
+NGP_DEV void ring_preload(u32x4 (&ar)[4][MT], LayerFrags L) {
+#pragma unroll
+	for (int st = 0; st < 3; ++st)
+#pragma unroll
+		for (int m = 0; m < MT; ++m)
+			if (m < L.mt) ar[st][m] = *(const u32x4*)(L.base + ((size_t)m * L.nkb + st) * 64);
+}
+
+// One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)); ring stages 0..2 hold (or await) K-blocks 0..2.
 template <int MT, int NKB>
-NGP_DEV void wide_hidden_layer(half_t* X, AReg& a, int wave, int lane, uint32_t active, const uint4* __restrict__ next_base, int next_count) {
+NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[4][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
 	const int n = lane & 31, h = lane >> 5;
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	floatx16 acc[MT][4];
+	const half_t* col = X + n * XS + 8 * h;
+	half8 b[2][4]; // the B operands of K block kb + 1 are read while the 4 MT MFMAs of block kb run
 #pragma unroll
-	for (int g = 0; g < 2; ++g) {
-		const bool on = (active >> g) & 1u;
-		uint2 packed[MT][4][4];
-		if (on) {
-			floatx16 acc[MT][4];
-			const half_t* col = X + (128 * g + n) * XS + 8 * h;
-			// the B operands of K block kb + 1 are read while the 4 MT MFMAs of block kb run (two register sets)
-			half8 b[2][4];
+	for (int t = 0; t < 4; ++t) b[0][t] = *(const half8*)(col + 32 * t * XS);
 #pragma unroll
-			for (int t = 0; t < 4; ++t) b[0][t] = *(const half8*)(col + 32 * t * XS);
+	for (int kb = 0; kb < NKB; ++kb) {
+		if (kb + 3 < NKB) {
 #pragma unroll
-			for (int kb = 0; kb < NKB; ++kb) {
-				if (kb + 1 < NKB) {
-#pragma unroll
-					for (int t = 0; t < 4; ++t) b[(kb + 1) & 1][t] = *(const half8*)(col + 32 * t * XS + 16 * (kb + 1));
-				}
-				__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use, one block late)
-#pragma unroll
-				for (int t = 0; t < 4; ++t)
-#pragma unroll
-					for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(a[m * NKB + kb]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
-				__builtin_amdgcn_sched_barrier(0);
-			}
-#pragma unroll
-			for (int m = 0; m < MT; ++m)
-#pragma unroll
-				for (int t = 0; t < 4; ++t)
-#pragma unroll
-					for (int q = 0; q < 4; ++q) packed[m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
+			for (int m = 0; m < MT; ++m) ar[(kb + 3) & 3][m] = *(const u32x4*)(wf + ((size_t)m * NKB + kb + 3) * 64);
 		}
-		if (g == 1) prefetch_frags(a, next_base, next_count); // the layer's own fragments have been used for the last time
-		lds_barrier(); // every wave has read this half's rows
-		if (on) {
+		if (kb + 1 < NKB) {
 #pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				half_t* row = X + (128 * g + 32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
-#pragma unroll
-				for (int m = 0; m < MT; ++m)
-#pragma unroll
-					for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[m][t][q];
-			}
+			for (int t = 0; t < 4; ++t) b[(kb + 1) & 1][t] = *(const half8*)(col + 32 * t * XS + 16 * (kb + 1));
 		}
+		__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use, one block late)
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+#pragma unroll
+			for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(ar[kb & 3][m]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	ring_preload<MT>(ar, next);
+	uint2 packed[MT][4][4];
+#pragma unroll
+	for (int m = 0; m < MT; ++m)
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) packed[m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
+	lds_barrier(); // every wave has read the layer's input
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		half_t* row = X + (32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
+#pragma unroll
+		for (int m = 0; m < MT; ++m)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[m][t][q];
 	}
 	lds_barrier();
 }
 
-// An output layer (at most 32 neurons, no activation): wave w computes its own two sample tiles 2w, 2w+1 (both in half w >> 1)
-template <int NKB>
-NGP_DEV void wide_out_layer(const half_t* X, AReg& a, int wave, int lane, floatx16 (&acc)[2]) {
+// An output layer (at most 32 neurons, no activation): wave w computes its own sample tile w; fragments in ar[.][0]
+template <int MT, int NKB>
+NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[4][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
 	const int n = lane & 31, h = lane >> 5;
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	floatx16 acc = zero;
+	const half_t* col = X + (32 * wave + n) * XS + 8 * h;
+	half8 b[2];
+	b[0] = *(const half8*)col;
 #pragma unroll
 	for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			const half8 b = *(const half8*)(X + (32 * (2 * wave + t) + n) * XS + 16 * kb + 8 * h);
-			acc[t] = mfma32(as_half8(a[kb]), b, kb == 0 ? zero : acc[t]);
-		}
+		if (kb + 3 < NKB) ar[(kb + 3) & 3][0] = *(const u32x4*)(wf + (size_t)(kb + 3) * 64);
+		if (kb + 1 < NKB) b[(kb + 1) & 1] = *(const half8*)(col + 16 * (kb + 1));
+		__builtin_amdgcn_sched_barrier(0);
+		acc = mfma32(as_half8(ar[kb & 3][0]), b[kb & 1], acc);
+		__builtin_amdgcn_sched_barrier(0);
 	}
+	ring_preload<MT>(ar, next);
+	return acc;
 }
 
 struct WideOut {
 	half_t r, g, b, sigma;
 };
 
-// where the wave's fragments of layer l start (lane included), and how many there are
-NGP_DEV const uint4* layer_frags(const WideModel& W, uint32_t l, bool is_out, int mt, int wave, int lane, int* count) {
-	const int nkb = (int)W.layers[l].n_kblocks;
-	*count = is_out ? nkb : mt * nkb;
-	return W.frags + W.layers[l].frag_offset + (is_out ? 0 : (size_t)(wave * mt) * nkb * 64) + lane;
+template <int MT>
+NGP_DEV LayerFrags layer_frags(const WideModel& W, uint32_t l, int wave, int lane) {
+	LayerFrags L;
+	const uint32_t n_layers = W.n_hidden_density + W.n_hidden_rgb + 2u;
+	if (l >= n_layers) {
+		L.base = nullptr; L.nkb = 0; L.mt = 0;
+		return L;
+	}
+	const bool is_out = l == W.n_hidden_density || l + 1u == n_layers;
+	L.nkb = (int)W.layers[l].n_kblocks;
+	L.mt = is_out ? 1 : MT;
+	L.base = W.frags + W.layers[l].frag_offset + (is_out ? 0 : (size_t)(wave * MT) * L.nkb * 64) + lane;
+	return L;
 }
 template <int MT>
-NGP_DEV void wide_network_prefetch(const WideModel& W, AReg& a, int tid) {
-	int count;
-	const uint4* base = layer_frags(W, 0, false, MT, tid >> 6, tid & 63, &count);
-	prefetch_frags(a, base, count);
+NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[4][MT], int tid) {
+	ring_preload<MT>(ar, layer_frags<MT>(W, 0, tid >> 6, tid & 63));
 }
 
-// NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 256 sample rows. On entry row `tid` of
-// S.x holds the position encoding of thread tid's sample (zeros beyond it up to the first layer's K) and S.dir its direction
+// NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 128 sample rows. On entry row r of
+// S.x holds the position encoding of slot r's sample (zeros beyond it up to the first layer's K) and S.dir its direction
 // encoding, both visible (the caller has passed a barrier), and the first layer's fragments have been requested
-// (wide_network_prefetch); on exit every thread has its own sample's outputs and X may be overwritten.
+// (wide_network_prefetch); on exit threads 0..127 have their slot's outputs and X may be overwritten.
 template <int MT>
-NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, uint32_t active, AReg& a) {
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[4][MT]) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
+	const int row_id = tid & (ROWS - 1), part = tid >> 7;
 	const uint32_t n_layers = W.n_hidden_density + W.n_hidden_rgb + 2u;
-	const bool mine = (active >> (wave >> 1)) & 1u; // this wave's 64 samples belong to an active half
 	WideOut o;
+	o.r = o.g = o.b = o.sigma = (half_t)0.0f;
 	for (uint32_t l = 0; l < n_layers; ++l) {
 		const bool density_out = l == W.n_hidden_density, rgb_out = l + 1u == n_layers;
-		const uint4* next_base = nullptr;
-		int next_count = 0;
-		if (!rgb_out) next_base = layer_frags(W, l + 1u, l + 1u == W.n_hidden_density || l + 2u == n_layers, MT, wave, lane, &next_count);
-		const int nkb = (int)W.layers[l].n_kblocks;
+		const LayerFrags cur = layer_frags<MT>(W, l, wave, lane), next = layer_frags<MT>(W, l + 1u, wave, lane);
 		if (!density_out && !rgb_out) {
-			if (nkb == 16) wide_hidden_layer<MT, 16>(S.x, a, wave, lane, active, next_base, next_count);
-			else wide_hidden_layer<MT, 8>(S.x, a, wave, lane, active, next_base, next_count);
+			if (cur.nkb == 16) wide_hidden_layer<MT, 16>(S.x, ar, cur.base, wave, lane, next);
+			else wide_hidden_layer<MT, 8>(S.x, ar, cur.base, wave, lane, next);
 			continue;
 		}
-		floatx16 acc[2];
-		if (mine) {
-			if (nkb == 16) wide_out_layer<16>(S.x, a, wave, lane, acc);
-			else wide_out_layer<8>(S.x, a, wave, lane, acc);
-		}
-		prefetch_frags(a, next_base, next_count);
+		const floatx16 acc = cur.nkb == 16 ? wide_out_layer<MT, 16>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, 8>(S.x, ar, cur.base, wave, lane, next);
 		if (density_out) {
-			// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tiles: no other wave reads them now)
-			if (mine) {
+			// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tile: no other wave reads them now)
+			half_t* orow = S.x + (32 * wave + n) * XS + 4 * h;
 #pragma unroll
-				for (int t = 0; t < 2; ++t) {
-					half_t* row = S.x + (32 * (2 * wave + t) + n) * XS + 4 * h;
-#pragma unroll
-					for (int q = 0; q < 2; ++q) *(uint2*)(row + 8 * q) = pack4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3], false);
+			for (int q = 0; q < 2; ++q) *(uint2*)(orow + 8 * q) = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], false);
+			lds_barrier();
+			// [density out | direction encoding | ones up to the network's input alignment | zeros up to the next layer's K]; two threads per row
+			half_t* row = S.x + row_id * XS;
+			if (part == 0) {
+				o.sigma = row[0];
+				for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + row_id * DIR_STRIDE + c);
+			} else {
+				const uint32_t k_end = 16u * W.layers[l + 1u].n_kblocks;
+				for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
+					const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
+					const half8 fill = {v, v, v, v, v, v, v, v};
+					*(half8*)(row + c) = fill;
 				}
 			}
 			lds_barrier();
-			o.sigma = S.x[tid * XS];
-			// [density out | direction encoding | ones up to the network's input alignment | zeros up to the next layer's K]
-			half_t* row = S.x + tid * XS;
-			const uint32_t k_end = 16u * W.layers[l + 1u].n_kblocks;
-			for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + tid * DIR_STRIDE + c);
-			for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
-				const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
-				const half8 fill = {v, v, v, v, v, v, v, v};
-				*(half8*)(row + c) = fill;
-			}
-			lds_barrier();
 		} else {
-			if (mine && h == 0) {
-#pragma unroll
-				for (int t = 0; t < 2; ++t) S.out[32 * (2 * wave + t) + n] = pack4(acc[t][0], acc[t][1], acc[t][2], 0.f, false);
-			}
+			if (h == 0) S.out[32 * wave + n] = pack4(acc[0], acc[1], acc[2], 0.f, false);
 			lds_barrier();
 			union { uint2 u; half_t hh[4]; } r;
-			r.u = S.out[tid];
+			r.u = S.out[row_id];
 			o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
 		}
 	}
 	return o;
 }
 
-NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int tid, f3 d) {
+NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int slot, f3 d) {
 	const float dx = (d.x + 1.0f) * 0.5f, dy = (d.y + 1.0f) * 0.5f, dz = (d.z + 1.0f) * 0.5f;
-	half_t* out = S.dir + tid * DIR_STRIDE;
-	if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dx, dy, dz, out);
+	half_t* out = S.dir + slot * DIR_STRIDE;
+	if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dx, dy, dz, out, 0u, W.dir_freqs, true);
 	else sh4_all(dx, dy, dz, out);
 }
 
-// which halves of the block (128 samples = two waves' slots) hold a sample: a workgroup-uniform 2-bit mask (contains a barrier)
-NGP_DEV uint32_t active_halves(WideShared& S, int tid, bool run) {
-	const unsigned long long m = __ballot(run);
-	if ((tid & 63) == 0) S.tile_mask[tid >> 6] = m != 0ull ? 1u : 0u;
-	__syncthreads();
-	const uint32_t mask = (S.tile_mask[0] | S.tile_mask[1]) | ((S.tile_mask[2] | S.tile_mask[3]) << 1);
-	return (uint32_t)__builtin_amdgcn_readfirstlane((int)mask);
+// the position encodings of the round's samples: row r by threads r (low frequencies) and r + 128 (high frequencies, padding)
+NGP_DEV void encode_positions(const WideModel& W, WideShared& S, int tid) {
+	const int row = tid & (ROWS - 1), part = tid >> 7;
+	const float4 p = S.pos[row];
+	if (p.w == 0.0f) return;
+	const uint32_t split = (W.pos_freqs + 1u) / 2u;
+	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, 16u * W.layers[0].n_kblocks);
 }
 
 template <bool PROBE, int MT>
@@ -315,7 +318,8 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	f3 idir = mk3(0.f, 0.f, 0.f);
 	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint32_t step = 1, skip_i = 1;
-	bool ready = false, counted = false, finished = false, exhausted = false;
+	// threads 128..255 (waves 2, 3) own no ray slot: they take part in the encodings and the GEMMs only
+	bool ready = false, counted = false, finished = false, exhausted = tid >= ROWS;
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
 	int stall = 0;
@@ -469,7 +473,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			if (n_progress == 0) break;
 			continue;
 		}
-		if (n_ready < WBLOCK - 32 && n_progress > 0 && stall < 3) {
+		if (n_ready < ROWS - 16 && n_progress > 0 && stall < 3) {
 			++stall;
 			continue;
 		}
@@ -477,12 +481,14 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 
 		// ---- K5: position encoding into the slot's row, then the network on the whole block
 		const bool run = ready;
-		AReg afrag;
-		wide_network_prefetch<MT>(W, afrag, tid); // the first layer's weights travel while the sines are computed
-		if (run) frequency_encode(W.pos_freqs, W.enc_dims, wx, wy, wz, S.x + tid * XS, 16u * W.layers[0].n_kblocks);
-		const uint32_t active = active_halves(S, tid, run); // (its barrier also publishes the rows)
+		if (tid < ROWS) S.pos[tid] = make_float4(wx, wy, wz, run ? 1.0f : 0.0f);
+		u32x4 ar[4][MT];
+		wide_network_prefetch<MT>(W, ar, tid); // the first layer's weights travel while the sines are computed
+		lds_barrier();
+		encode_positions(W, S, tid);
+		lds_barrier();
 		if (prof) { t1 = stamp(); pt[3] += t1 - t0; t0 = t1; ++p_net; p_ready += (unsigned long long)n_ready; }
-		const WideOut o = wide_network<MT>(W, S, tid, active, afrag);
+		const WideOut o = wide_network<MT>(W, S, tid, ar);
 		if (prof) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; }
 
 		// ---- K6: composite_kernel_nerf (:569-726)
@@ -534,7 +540,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	finish_launch(F, lane, n_alive_init, n_hit, n_samples);
 }
 
-#define NGP_WIDE_KERNEL __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define NGP_WIDE_KERNEL __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 NGP_WIDE_KERNEL void render_nerf_wide256(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
@@ -553,30 +559,34 @@ NGP_WIDE_KERNEL void trace_probe_wide128(const ModelParams M, const FrameParams 
 	wide_body<true, 1>(M, C, F, P);
 }
 
-// NerfNetwork::inference on explicit inputs (ngp_network_inference): 256 samples per workgroup round
+// NerfNetwork::inference on explicit inputs (ngp_network_inference): 128 samples per workgroup round
 template <int MT>
 NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
 	__shared__ WideShared S;
 	const WideModel& W = M.wide;
-	const int tid = threadIdx.x;
-	for (uint32_t base = blockIdx.x * WBLOCK; base < n; base += gridDim.x * WBLOCK) { // (workgroup-uniform trip count)
-		const uint32_t i = base + (uint32_t)tid;
+	const int tid = threadIdx.x, row = tid & (ROWS - 1), part = tid >> 7;
+	for (uint32_t base = blockIdx.x * ROWS; base < n; base += gridDim.x * ROWS) { // (workgroup-uniform trip count)
+		const uint32_t i = base + (uint32_t)row;
 		const bool run = i < n;
-		AReg afrag;
-		wide_network_prefetch<MT>(W, afrag, tid);
-		if (run) {
-			frequency_encode(W.pos_freqs, W.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], S.x + tid * XS, 16u * W.layers[0].n_kblocks);
-			half_t* d = S.dir + tid * DIR_STRIDE;
-			if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
+		u32x4 ar[4][MT];
+		wide_network_prefetch<MT>(W, ar, tid);
+		if (part == 0) {
+			S.pos[row] = run ? make_float4(pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+		} else if (run) {
+			half_t* d = S.dir + row * DIR_STRIDE;
+			if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d, 0u, W.dir_freqs, true);
 			else sh4_all(dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
 		}
-		const uint32_t active = active_halves(S, tid, run);
-		const WideOut o = wide_network<MT>(W, S, tid, active, afrag);
-		if (run) {
+		lds_barrier();
+		encode_positions(W, S, tid);
+		lds_barrier();
+		const WideOut o = wide_network<MT>(W, S, tid, ar);
+		if (run && part == 0) {
 			union { half_t h[4]; uint2 u; } p;
 			p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
 			*(uint2*)(out + 4 * (size_t)i) = p.u;
 		}
+		lds_barrier(); // (the next round's positions overwrite what this round's threads may still read)
 	}
 }
 NGP_WIDE_KERNEL void network_inference_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
@@ -589,26 +599,34 @@ NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, 
 __global__ void frequency_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	frequency_encode(M.wide.pos_freqs, M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], (half_t*)out + (size_t)M.wide.enc_dims * i);
+	frequency_encode(M.wide.pos_freqs, M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], (half_t*)out + (size_t)M.wide.enc_dims * i, 0u, M.wide.pos_freqs, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// launchers: one workgroup per CU (the activations take 132 of the CU's 160 KB of LDS)
-static int wide_blocks(const FrameParams& F, int n_cus) {
-	int n_blocks = n_cus;
-	const int needed = (int)((F.n_local_tiles + 3) / 4);
+// launchers: persistent grids of what is resident at once -- two workgroups per CU (80 KB of LDS, 256 registers per lane each)
+template <typename K>
+static int wide_blocks_per_cu(K kernel) {
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, WBLOCK, 0) != hipSuccess || n < 1) n = 1;
+	return n;
+}
+static int wide_blocks(const FrameParams& F, int n_cus, int per_cu) {
+	int n_blocks = n_cus * per_cu;
+	const int needed = (int)((F.n_local_tiles + 1) / 2); // 128 ray slots = two 8x8 tiles per workgroup
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	return n_blocks;
 }
 void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
-	const int n_blocks = wide_blocks(F, n_cus);
+	static const int per_cu256 = wide_blocks_per_cu(render_nerf_wide256), per_cu128 = wide_blocks_per_cu(render_nerf_wide128);
+	const int n_blocks = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256 : per_cu128);
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
 	if (M.wide.width == 256) hipLaunchKernelGGL(render_nerf_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
 	else hipLaunchKernelGGL(render_nerf_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
 }
 void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {
-	const int n_blocks = wide_blocks(F, n_cus);
+	static const int per_cu256 = wide_blocks_per_cu(trace_probe_wide256), per_cu128 = wide_blocks_per_cu(trace_probe_wide128);
+	const int n_blocks = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256 : per_cu128);
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
 	if (M.wide.width == 256) hipLaunchKernelGGL(trace_probe_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, G, P);
@@ -616,8 +634,8 @@ void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const P
 }
 void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, int n_cus, hipStream_t stream) {
 	if (n == 0) return;
-	int n_blocks = (int)((n + WBLOCK - 1) / WBLOCK);
-	if (n_blocks > n_cus) n_blocks = n_cus;
+	int n_blocks = (int)((n + ROWS - 1) / ROWS);
+	if (n_blocks > 2 * n_cus) n_blocks = 2 * n_cus;
 	if (M.wide.width == 256) hipLaunchKernelGGL(network_inference_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
 	else hipLaunchKernelGGL(network_inference_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
 }
