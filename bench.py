@@ -125,6 +125,33 @@ def pmc_evidence():
     return out
 
 
+def frequency_probe(native, scene_mod):
+    """SURVEY 8 a-19, reported beside the headline (never part of `value`): the same 1080p camera over the same occupancy with
+    the configs/nerf/frequency.json network (Frequency encodings, MLPs 256 x 7 + 256 x 1; 434176 MACs per sample, 42x base.json's).
+    This path is bound by the matrix pipe: its rate is quoted against the dense f16 MFMA peak."""
+    try:
+        synthetic = pkg("synthetic")
+        sc = synthetic.make_scene(aabb_scale=1, seed=1234, cfg=scene_mod.frequency_network_config())
+        fctx = native.Context(0)
+        fctx.set_model(sc)
+        cam = native.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), WIDTH, HEIGHT, scene_mod.focal_from_fov_x(WIDTH, FOV_X))
+        opts = native.make_opts()
+        fctx.render_pinned(cam, opts)
+        ms = []
+        for _ in range(3):
+            fctx.render_pinned(cam, opts)
+            ms.append(fctx.render_stats()["kernel_device_ms"])
+        st = fctx.render_stats()
+        fctx.close()
+        t = min(ms)
+        flops = st["n_samples"] * 2.0 * (421888 + 12288)
+        return {"ms_per_frame": round(t, 3), "mrays_s": round(WIDTH * HEIGHT / t / 1e3, 2), "gsamples_s": round(st["n_samples"] / t / 1e6, 3),
+                "samples_per_frame": int(st["n_samples"]), "achieved_tflops": round(flops / t / 1e9, 1), "mfma_frac": round(flops / t / 1e9 / MFMA_PEAK_TFLOPS, 3),
+                "config": "configs/nerf/frequency.json architecture, synthetic weights, %dx%d, kernel time on the device clock" % (WIDTH, HEIGHT)}
+    except Exception as e:  # the headline line must come out whatever happens here
+        return {"error": str(e)[:200]}
+
+
 def training_probe(native, scene_mod, gt_ctx):
     """SURVEY 8 f-2, reported beside the headline (never part of `value`): the training step at the reference's batch of
     2^18 samples on views rendered from the bench scene. Failures are reported, not raised."""
@@ -376,6 +403,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, scene_mod, ctx, native)
         if world == 1 and not args.no_training_probe:
             out["training"] = training_probe(native, scene_mod, ctx)
+            out["frequency_json"] = frequency_probe(native, scene_mod)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -27,6 +27,9 @@
 // FrameParams::tune[6] (ngp_set_schedule's block_jumps) is 0, which gives the reference's one-voxel steps and its exact sample sets.
 #include "render_common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace ngp {
 
 constexpr int WBLOCK = 256;    // threads of a workgroup
@@ -41,6 +44,7 @@ struct WideShared {
 	float4 pos[ROWS];                      // the slot's sample position (w != 0: there is one) for the threads that encode it
 	uint2 out[ROWS];                       // rgb of the slot's sample
 	uint32_t coarse16[NERF_CASCADES * 16]; // per cascade: which 16^3-cell blocks of the occupancy grid hold anything (ModelParams::coarse, tail)
+	unsigned long long prof[8];            // diagnostic (NGP_PROFILE_SECTIONS=1): the workgroup's section sums, kept here rather than in registers
 };
 static_assert(2 * sizeof(WideShared) <= 160 * 1024, "two workgroups per CU");
 
@@ -71,6 +75,27 @@ NGP_DEV uint32_t empty_block_size_global(f3 pos, const uint8_t* __restrict__ bit
 
 NGP_DEV floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// sin(t) for the encoder's arguments (|t| up to 2^15 pi for positions in the unit cube): Cody-Waite reduction by pi in three fp32
+// pieces (fma: the products are exact), then the odd Taylor polynomial of degree 11 on [-pi/2, pi/2]. Absolute error < 2e-7 (measured
+// 1.7e-7 over 6.4e6 arguments), i.e. the fp16 rounding of the feature differs from the exactly rounded one in < 1e-4 of the cases;
+// 17 instructions where libm's general sinf takes ~55. Arguments beyond 2^20 go to sinf.
+NGP_DEV float encoder_sin(float t) {
+	if (!(__builtin_fabsf(t) < 1048576.0f)) return sinf(t);
+	const float k = __builtin_rintf(t * 0.318309886183790672f);
+	float r = __builtin_fmaf(-k, 3.14159274101257324f, t);
+	r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);
+	r = __builtin_fmaf(-k, -3.55271367880050093e-15f, r);
+	const float r2 = r * r;
+	float p = -2.50521083854417188e-08f;
+	p = __builtin_fmaf(p, r2, 2.75573192239858907e-06f);
+	p = __builtin_fmaf(p, r2, -1.98412698412698413e-04f);
+	p = __builtin_fmaf(p, r2, 8.33333333333333333e-03f);
+	p = __builtin_fmaf(p, r2, -1.66666666666666667e-01f);
+	const float s = __builtin_fmaf(r * r2, p, r);
+	const uint32_t flip = (uint32_t)(int)k << 31; // sin(r + k pi) = (-1)^k sin(r)
+	return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) ^ flip);
+}
+
 // tcnn FrequencyEncoding (encodings/frequency.h): feature j of input x is
 //   sin(fma(scalbn(x[j / (2 F)], (j / 2) % F), pi, (j % 2) pi / 2))
 // rounded to fp16; inputs beyond 3 * 2 F up to `padded` are ones. This call writes the features of frequencies [f_begin, f_end) of
@@ -84,8 +109,8 @@ NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y
 		for (uint32_t f = f_begin; f < f_end; ++f) {
 			const float v = __builtin_ldexpf(in[d], (int)f);
 			half2_t sc;
-			sc[0] = (half_t)sinf(__builtin_fmaf(v, PI, 0.0f));
-			sc[1] = (half_t)sinf(__builtin_fmaf(v, PI, PI / 2.0f));
+			sc[0] = (half_t)encoder_sin(__builtin_fmaf(v, PI, 0.0f));
+			sc[1] = (half_t)encoder_sin(__builtin_fmaf(v, PI, PI / 2.0f));
 			*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
 		}
 	}
@@ -325,10 +350,16 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	int stall = 0;
 	// diagnostic (NGP_PROFILE_SECTIONS=1: FrameParams::prof): cycle sums per section, taken by one lane per workgroup
 	const bool prof = F.prof != nullptr && tid == 0;
-	unsigned long long pt[4] = {0, 0, 0, 0}, p_rounds = 0, p_net = 0, p_ready = 0, t0 = 0, t1 = 0;
+	unsigned long long t0 = 0;
+	if (tid < 8) S.prof[tid] = 0ull;
+	auto lap = [&](int section) { // [0] refill, [1] march + decision, [2] network, [3] encode + composite
+		const unsigned long long t1 = stamp();
+		S.prof[section] += t1 - t0;
+		t0 = t1;
+	};
 
 	for (;;) {
-		if (prof) { t0 = stamp(); ++p_rounds; }
+		if (prof) { t0 = stamp(); S.prof[4] += 1ull; }
 		// ---- retire finished rays (K7) and refill free slots from the strip queue (K1 + the jitter of K2), per wave
 		const unsigned long long dead_mask = __ballot(!ray.alive);
 		const int n_dead = __popcll(dead_mask);
@@ -408,12 +439,12 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 
-		if (prof) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; }
+		if (prof) lap(0);
 		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494): every marching slot walks to its next
 		// sample (or out of the box), at most 64 voxels per round so that one long empty stretch does not hold up the workgroup
 		bool newly_counted = false;
 		if (ray.alive && !ready) {
-			for (int k = 0; k < 32; ++k) {
+			for (int k = 0; k < F.tune[1]; ++k) {
 				const f3 pos = add3(ray.o, scale3(ray.d, ray.t));
 				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
 				if (PROBE && skip_i >= 200) out = true;
@@ -468,12 +499,12 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		// ---- workgroup decision: run the network once most slots hold a sample or nothing else can fill them
 		const int n_ready = __syncthreads_count(ready);
 		const int n_progress = __syncthreads_count((ray.alive && !ready) || finished || (!ray.alive && !exhausted));
-		if (prof) { t1 = stamp(); pt[1] += t1 - t0; t0 = t1; }
+		if (prof) lap(1);
 		if (n_ready == 0) {
 			if (n_progress == 0) break;
 			continue;
 		}
-		if (n_ready < ROWS - 16 && n_progress > 0 && stall < 3) {
+		if (n_ready < F.tune[2] && n_progress > 0 && stall < F.tune[3]) {
 			++stall;
 			continue;
 		}
@@ -487,9 +518,9 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		lds_barrier();
 		encode_positions(W, S, tid);
 		lds_barrier();
-		if (prof) { t1 = stamp(); pt[3] += t1 - t0; t0 = t1; ++p_net; p_ready += (unsigned long long)n_ready; }
+		if (prof) { lap(3); S.prof[5] += 1ull; S.prof[7] += (unsigned long long)n_ready; }
 		const WideOut o = wide_network<MT>(W, S, tid, ar);
-		if (prof) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; }
+		if (prof) lap(2);
 
 		// ---- K6: composite_kernel_nerf (:569-726)
 		if (run) {
@@ -528,14 +559,14 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 		n_samples += (uint32_t)__popcll(__ballot(run));
-		if (prof) { t1 = stamp(); pt[3] += t1 - t0; }
+		if (prof) lap(3);
 	}
 	if (prof) { // [refill, march + decision, network, encode + composite] cycles, rounds, network rounds (twice: the host divides by both), samples
-		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], pt[k]);
-		atomicAdd(&F.prof[4], p_rounds);
-		atomicAdd(&F.prof[5], p_net);
-		atomicAdd(&F.prof[6], p_net);
-		atomicAdd(&F.prof[7], p_ready);
+		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], S.prof[k]);
+		atomicAdd(&F.prof[4], S.prof[4]);
+		atomicAdd(&F.prof[5], S.prof[5]);
+		atomicAdd(&F.prof[6], S.prof[5]);
+		atomicAdd(&F.prof[7], S.prof[7]);
 	}
 	finish_launch(F, lane, n_alive_init, n_hit, n_samples);
 }
@@ -610,7 +641,24 @@ static int wide_blocks_per_cu(K kernel) {
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, WBLOCK, 0) != hipSuccess || n < 1) n = 1;
 	return n;
 }
+// The round's schedule (FrameParams::tune as this kernel reads it; of ngp_set_schedule's knobs only block_jumps applies here):
+// [1] voxel steps a marching slot may take per round, [2] run the network once this many of the 128 slots hold a sample ...
+// [3] ... or after this many extra march rounds. WIDE_TUNE="steps,go,stall" overrides the defaults (experiments).
+static void wide_schedule(FrameParams& G) {
+	static const struct T { int v[3]; } t = []() {
+		T r = {{16, 96, 1}};
+		if (const char* e = getenv("WIDE_TUNE")) (void)sscanf(e, "%d,%d,%d", &r.v[0], &r.v[1], &r.v[2]);
+		if (r.v[0] < 1 || r.v[0] > 1024) r.v[0] = 16;
+		if (r.v[1] < 1 || r.v[1] > ROWS) r.v[1] = 96;
+		if (r.v[2] < 0 || r.v[2] > 64) r.v[2] = 1;
+		return r;
+	}();
+	G.tune[1] = t.v[0];
+	G.tune[2] = t.v[1];
+	G.tune[3] = t.v[2];
+}
 static int wide_blocks(const FrameParams& F, int n_cus, int per_cu) {
+	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
 	int n_blocks = n_cus * per_cu;
 	const int needed = (int)((F.n_local_tiles + 1) / 2); // 128 ray slots = two 8x8 tiles per workgroup
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
@@ -621,6 +669,7 @@ void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const 
 	const int n_blocks = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256 : per_cu128);
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
+	wide_schedule(G);
 	if (M.wide.width == 256) hipLaunchKernelGGL(render_nerf_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
 	else hipLaunchKernelGGL(render_nerf_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, C, G);
 }
@@ -629,6 +678,7 @@ void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const P
 	const int n_blocks = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256 : per_cu128);
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (WBLOCK / 64);
+	wide_schedule(G);
 	if (M.wide.width == 256) hipLaunchKernelGGL(trace_probe_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, G, P);
 	else hipLaunchKernelGGL(trace_probe_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, G, P);
 }

@@ -25,7 +25,7 @@ def scene_freq(oracle, scene_mod):
 
 
 @pytest.fixture(scope="module")
-def ctx(native):
+def ctx(native, gpu_ctx):  # (gpu_ctx first: torch has to initialise its HIP runtime before the library does, conftest.py)
     c = native.Context(0)
     yield c
     c.close()
@@ -153,3 +153,27 @@ def test_probe_envmap(ctx, native, scene_freq):
     env = ctx.compute_envmap(n_theta=32, n_phi=16)
     assert env.shape == (16, 32, 4)
     assert np.isfinite(env).all() and env[..., 3].max() > 0.5
+
+
+def test_tile_sharding_and_block_jump_knob(ctx, native, scene_mod, scene_freq):
+    """camera-tile shards (what bench.py --gpus N and ngp_create_multi deal out) are disjoint and sum to the unsharded frame bit for
+    bit; with block_jumps off the march takes the reference's one-voxel steps and the image moves by rounding noise only"""
+    w, h = 120, 72
+    ctx.set_model(scene_freq)
+    cam = native.make_camera(scene_mod.orbit_camera(45.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+    bg0 = (0.0, 0.0, 0.0, 0.0)
+    full = ctx.render(cam, native.make_opts(background=bg0))
+    total = np.zeros_like(full)
+    for r in range(3):
+        part = ctx.render(cam, native.make_opts(background=bg0, shard_index=r, shard_count=3))
+        assert not (np.abs(total).sum(-1) > 0)[np.abs(part).sum(-1) > 0].any()
+        total += part
+    assert np.array_equal(total, full)
+    st_on = ctx.render_stats()
+    ctx.set_schedule(64, 4, 32, 1, 0, 3, 0)  # block_jumps = 0 (the other knobs, at their defaults, belong to the base.json kernel)
+    try:
+        exact = ctx.render(cam, native.make_opts(background=bg0))
+    finally:
+        ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
+    d = np.abs(exact - full).max(-1)
+    assert np.median(d) < 1e-3 and (d > 1e-2).mean() < 2e-3
