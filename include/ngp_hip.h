@@ -41,6 +41,9 @@ enum ngp_render_mode {
 	NGP_RENDER_COST = 5,      /* ERenderMode::Cost (shade_kernel_nerf :1382-1384): grey = samples composited on the ray / 128, opaque. The reference's
 	                           * payload.n_steps holds that count for rays that saturate and the last compaction batch's for rays that leave the
 	                           * volume (:466, :730); here it is the ray's total in both cases */
+	NGP_RENDER_NORMALS = 7,   /* ERenderMode::Normals (composite_kernel_nerf :688-693, shade_kernel_nerf :1379-1381): every sample's colour is the unit
+	                           * vector opposite to the density's gradient w.r.t. the position -- tcnn's input_gradient (src/testbed_nerf.cu:2106-2107):
+	                           * a backward pass through the density MLP and the grid encoding per sample; the pixel is (0.5 n + 0.5) alpha. Grid models. */
 	NGP_RENDER_SHADE_GRID_ENVMAP = 6 /* ERenderMode::ShadeGridEnvMap, the fork's default (testbed.h:880): meshes lit by the GRID of NeRF-derived
 	                           * irradiance probes (ngp_compute_envmap_grid), position-dependent */
 };
@@ -242,6 +245,9 @@ NGP_API int ngp_set_schedule(ngp_ctx* ctx, const int32_t* knobs, int n);
 /* --- stage entry points (what the reference launches as separate kernels; used by parity tests and tools)
  * K5a tcnn GridEncoding::inference (call site nerf_network.h:113-118): host pos01 n x 3 -> host fp16 n x (L*F) */
 NGP_API int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_fp16);
+/* tcnn DifferentiableObject::input_gradient(stream, 3, ...) as ERenderMode::Normals calls it (src/testbed_nerf.cu:2106-2107): d density
+ * logit / d position for n positions, host n x 3 floats. Grid models. */
+NGP_API int ngp_density_gradient(ngp_ctx* ctx, uint32_t n, const float* pos01, float* out_grad);
 /* K5 NerfNetwork::inference_mixed_precision (nerf_network.h:105-139): pos01/dir01 n x 3 -> fp16 n x 4 (rgb logits, density logit) */
 NGP_API int ngp_network_inference(ngp_ctx* ctx, uint32_t n, const float* pos01, const float* dir01, uint16_t* out_fp16);
 /* K8/K9 update_density_grid_mean_and_bitfield (src/testbed_nerf.cu:2863-2880): the bitfield in use, 8 x 128^3 / 8 bytes */

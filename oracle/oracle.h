@@ -140,6 +140,8 @@ void orc_grid_encode(const orc_nerf_model* m, uint32_t n, const float* pos01, ui
 void orc_sh4_encode(uint32_t n, const float* dir01, uint16_t* out);
 /* K5: full network. out: n x 4 fp16 (rgb logits, density logit) */
 void orc_nerf_network(const orc_nerf_model* m, uint32_t n, const float* pos01, const float* dir01, uint16_t* out);
+/* d density logit / d (warped) position, what ERenderMode::Normals composites (tcnn input_gradient, src/testbed_nerf.cu:2106-2107): n x 3 */
+void orc_density_gradient(const orc_nerf_model* m, uint32_t n, const float* pos01, float* grad);
 
 /* K8/K9: density grid (float, Morton order, (max_cascade+1) x 128^3) -> bitfield (8 x 128^3 / 8 bytes) */
 void orc_density_grid_to_bitfield(const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* out_mean);

@@ -262,6 +262,14 @@ class Oracle:
         self.lib.orc_frequency_encode(x.shape[0], x.shape[1], n_frequencies, _ptr(x), _ptr(out))
         return out.view(np.float16)
 
+    def density_gradient(self, m, pos01):
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        out = np.zeros((pos01.shape[0], 3), np.float32)
+        self.lib.orc_density_gradient.argtypes = [C.POINTER(NerfModel), C.c_uint32, C.c_void_p, C.c_void_p]
+        self.lib.orc_density_gradient.restype = None
+        self.lib.orc_density_gradient(C.byref(m), pos01.shape[0], _ptr(pos01), _ptr(out))
+        return out
+
     def sh4(self, dir01):
         dir01 = np.ascontiguousarray(dir01, np.float32)
         out = np.zeros((dir01.shape[0], 16), np.uint16)

@@ -410,6 +410,95 @@ static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const
 	out4[3] = dens_h[0];
 }
 
+/* ------------------------------------------------------------------ ERenderMode::Normals: d density logit / d position
+ * The reference calls tcnn's DifferentiableObject::input_gradient(stream, 3, input, input) (src/testbed_nerf.cu:2106-2107): a one-hot
+ * "loss gradient" of backprop_scale = 128 at output 3 -- the density logit, which NerfNetwork::backward_impl routes to output 0 of the
+ * density MLP (nerf_network.h) --, the MLP's backward pass (fp16 gradients between layers, ReLU masks from the forward activations),
+ * GridEncoding::backward's input path (kernel_grid_backward_input: dL_dx[d] = sum_k (float)dL_dy[k] * dy_dx[d][k] in fp32, with the
+ * dy_dx that kernel_grid forms for linear interpolation: scale * sum over the 4 corner pairs of w_other * (val_right - val_left)),
+ * and a division by the scale. tcnn is not in the mount (PARITY UNPINNED): its fused backward's rounding points are restated as
+ * "exact sum, rounded to fp32, then to fp16" like the forward pass. HashGrid models only. */
+static void density_gradient_one(const orc_nerf_model* m, const prepared_t* p, const float* x, float* grad3, uint16_t* logit_out) {
+	const uint32_t F = m->n_features_per_level, W = m->n_neurons, E = p->enc_dims, NH = m->n_hidden_density;
+	uint16_t enc_h[ORC_MAX_LEVELS * 8];
+	grid_encode_one(m, p, x, enc_h);
+	float act[9][256]; /* act[0] = encoding, act[k] = hidden layer k (as floats of the fp16 values) */
+	for (uint32_t i = 0; i < E; ++i) act[0][i] = orc_half_to_float(enc_h[i]);
+	const float* w = p->density_w;
+	const float* layer_w[9];
+	uint32_t n_in = E;
+	for (uint32_t l = 0; l < NH; ++l) {
+		layer_w[l] = w;
+		mlp_layer(w, W, n_in, act[l], 1, act[l + 1], NULL);
+		w += (size_t)W * n_in;
+		n_in = W;
+	}
+	uint16_t out_h[32];
+	float out_f[32];
+	mlp_layer(w, m->density_out_dims, W, act[NH], 0, out_f, out_h);
+	if (logit_out) *logit_out = out_h[0];
+	/* backward: d(128 * logit) / d hidden NH = 128 * W_out[0][:], masked by the forward ReLU */
+	float g[256], g_prev[256];
+	for (uint32_t i = 0; i < W; ++i) g[i] = act[NH][i] > 0.0f ? orc_half_to_float(orc_float_to_half(128.0f * w[i])) : 0.0f;
+	for (uint32_t l = NH; l-- > 0;) {
+		const uint32_t n_prev = l == 0 ? E : W;
+		for (uint32_t i = 0; i < n_prev; ++i) {
+			double acc = 0.0;
+			for (uint32_t o = 0; o < W; ++o) acc += (double)layer_w[l][(size_t)o * n_prev + i] * (double)g[o];
+			float v = (float)acc;
+			if (l > 0 && !(act[l][i] > 0.0f)) v = 0.0f;
+			g_prev[i] = orc_half_to_float(orc_float_to_half(v));
+		}
+		memcpy(g, g_prev, sizeof(float) * n_prev);
+	}
+	/* g = dL_dy over the encoding (fp16 values). dy_dx and the sum over features, level by level */
+	float result[3] = {0.0f, 0.0f, 0.0f};
+	for (uint32_t l = 0; l < m->n_levels; ++l) {
+		const uint32_t size = p->offsets[l + 1] - p->offsets[l];
+		const uint16_t* level = p->grid + (uint64_t)p->offsets[l] * F;
+		const float scale = p->scales[l];
+		const uint32_t res = p->resolutions[l];
+		float pos[3];
+		uint32_t pg[3];
+		for (int d = 0; d < 3; ++d) {
+			float v = fmaf(scale, x[d], 0.5f);
+			float fl = floorf(v);
+			pg[d] = (uint32_t)(int)fl;
+			pos[d] = v - fl;
+		}
+		for (uint32_t gd = 0; gd < 3; ++gd) {
+			float grads[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (uint32_t idx = 0; idx < 4; ++idx) {
+				float weight = scale;
+				uint32_t pgl[3];
+				for (uint32_t nd = 0; nd < 2; ++nd) {
+					const uint32_t dim = nd >= gd ? nd + 1 : nd;
+					if ((idx & (1u << nd)) == 0) {
+						weight *= 1.0f - pos[dim];
+						pgl[dim] = pg[dim];
+					} else {
+						weight *= pos[dim];
+						pgl[dim] = pg[dim] + 1u;
+					}
+				}
+				pgl[gd] = pg[gd];
+				const uint16_t* left = level + (uint64_t)grid_index(size, res, pgl) * F;
+				pgl[gd] = pg[gd] + 1u;
+				const uint16_t* right = level + (uint64_t)grid_index(size, res, pgl) * F;
+				for (uint32_t f = 0; f < F; ++f) grads[f] += weight * (orc_half_to_float(right[f]) - orc_half_to_float(left[f]));
+			}
+			for (uint32_t f = 0; f < F; ++f) result[gd] += g[l * F + f] * grads[f];
+		}
+	}
+	for (int d = 0; d < 3; ++d) grad3[d] = result[d] * (1.0f / 128.0f);
+}
+
+void orc_density_gradient(const orc_nerf_model* m, uint32_t n, const float* pos01, float* grad) {
+	const prepared_t* p = (const prepared_t*)m->prepared;
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t i = 0; i < (int64_t)n; ++i) density_gradient_one(m, p, pos01 + 3 * i, grad + 3 * i, NULL);
+}
+
 void orc_nerf_network(const orc_nerf_model* m, uint32_t n, const float* pos01, const float* dir01, uint16_t* out) {
 	const prepared_t* p = (const prepared_t*)m->prepared;
 #pragma omp parallel for schedule(dynamic, 64)
@@ -834,7 +923,21 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 		float r = network_to_rgb(orc_half_to_float(out4[0]), m->rgb_activation);
 		float g = network_to_rgb(orc_half_to_float(out4[1]), m->rgb_activation);
 		float b = network_to_rgb(orc_half_to_float(out4[2]), m->rgb_activation);
-		if (o->render_mode == 2) { /* ERenderMode::AO, testbed_nerf.cu:700-702 */
+		if (o->render_mode == 7) { /* ERenderMode::Normals, testbed_nerf.cu:688-693: opposite to the density gradient */
+			float g3[3];
+			density_gradient_one(m, p, wpos, g3, NULL);
+			float dd;
+			float sv = orc_half_to_float(out4[3]);
+			switch (m->density_activation) { /* network_to_density_derivative, nerf_device.cuh:245-254 */
+				case 1: dd = sv > 0.0f ? 1.0f : 0.0f; break;
+				case 2: { float dn = 1.0f / (1.0f + expf(-sv)); dd = dn * (1.0f - dn); } break;
+				case 3: dd = expf(fminf(fmaxf(sv, -15.0f), 15.0f)); break;
+				default: dd = 1.0f;
+			}
+			v3 nrm = v3_make(-dd * g3[0], -dd * g3[1], -dd * g3[2]);
+			float len = sqrtf(v3_dot(nrm, nrm));
+			r = nrm.x / len; g = nrm.y / len; b = nrm.z / len;
+		} else if (o->render_mode == 2) { /* ERenderMode::AO, testbed_nerf.cu:700-702 */
 			r = g = b = alpha;
 		} else if (o->render_mode == 3) { /* Positions :694-695 */
 			r = (pos.x - 0.5f) / 2.0f + 0.5f; g = (pos.y - 0.5f) / 2.0f + 0.5f; b = (pos.z - 0.5f) / 2.0f + 0.5f;
@@ -864,6 +967,10 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 static void shade_one(const orc_render_opts* o, const float* rgba, float depth, uint32_t idx, uint32_t n_steps, float* frame_buffer, float* depth_buffer) {
 	if (o->depth_test && depth > depth_buffer[idx]) return;
 	float tmp[4] = {rgba[0], rgba[1], rgba[2], rgba[3]};
+	if (o->render_mode == 7) { /* ERenderMode::Normals, :1379-1381 */
+		float len = sqrtf(tmp[0] * tmp[0] + tmp[1] * tmp[1] + tmp[2] * tmp[2]);
+		for (int c = 0; c < 3; ++c) tmp[c] = (0.5f * (tmp[c] / len) + 0.5f) * tmp[3];
+	}
 	if (o->render_mode == 5) { /* ERenderMode::Cost, :1382-1384 (n_steps: the ray's total, see include/ngp_hip.h NGP_RENDER_COST) */
 		tmp[0] = tmp[1] = tmp[2] = (float)n_steps / 128.0f;
 		tmp[3] = 1.0f;

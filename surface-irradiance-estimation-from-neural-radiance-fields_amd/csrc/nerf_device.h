@@ -909,6 +909,89 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ERenderMode::Normals: d density logit / d position -- tcnn's input_gradient(dim 3) (src/testbed_nerf.cu:2106-2107) for 16 samples
+// on one wave: the density MLP's backward pass on MFMA and GridEncoding's input path on the corner values the forward encode
+// already holds (no second gather).
+// The four A fragments of W1^T (32 encoding rows x 64 neurons, in the hidden layer's K order) follow the forward fragments in the
+// weight buffer (build_normals_fragments_kernel, nerf_kernels.hip): fragment 2t + s = rows 16t.., neurons of K block s.
+struct DensityGrad {
+	float g[3];     // d (128 logit) / d warped position, summed over this lane's two levels only (the caller adds the four lanes of a sample)
+	half_t sigma;   // the density logit (lanes with h == 0)
+};
+// dy_dx of kernel_grid for linear interpolation (scale * sum over the 4 corner pairs of w_other * (val_right - val_left), fp32)
+// times dL_dy, for the two levels of this lane; e.v[8 l + c]: corner c (bit d = +1 along dimension d) of level l
+NGP_DEV void encode_gradient(const EncodeInFlight& e, float scale0, float scale1, const float* dLdy, float* g3) {
+	g3[0] = g3[1] = g3[2] = 0.0f;
+#pragma unroll
+	for (int l = 0; l < 2; ++l) {
+		const float pos[3] = {e.wx[l], e.wy[l], e.wz[l]};
+		const float scale = l ? scale1 : scale0;
+#pragma unroll
+		for (int gd = 0; gd < 3; ++gd) {
+			float grads[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int idx = 0; idx < 4; ++idx) {
+				float weight = scale;
+				int corner = 0;
+#pragma unroll
+				for (int nd = 0; nd < 2; ++nd) {
+					const int dim = nd >= gd ? nd + 1 : nd;
+					if ((idx & (1 << nd)) == 0) {
+						weight *= 1.0f - pos[dim];
+					} else {
+						weight *= pos[dim];
+						corner |= 1 << dim;
+					}
+				}
+				union { uint2 u; half_t h[4]; } left, right;
+				left.u = e.v[8 * l + corner];
+				right.u = e.v[8 * l + (corner | (1 << gd))];
+#pragma unroll
+				for (int f = 0; f < 4; ++f) grads[f] += weight * ((float)right.h[f] - (float)left.h[f]);
+			}
+#pragma unroll
+			for (int f = 0; f < 4; ++f) g3[gd] += dLdy[4 * l + f] * grads[f];
+		}
+	}
+}
+NGP_DEV DensityGrad density_gradient_pass(const uint4* s_w, const uint4* __restrict__ g_wfrags, int lane, const EncodeInFlight& e, half8 enc, float scale0, float scale1) {
+	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+	// forward: 32 -> 64 (ReLU) -> 16
+	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
+	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
+	floatx4 d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
+	floatx4 d3 = mfma16(ld_frag(s_w, FRAG_D0 + 3, lane), enc, zero);
+	const half8 b0 = relu_pack(d0, d1), b1 = relu_pack(d2, d3);
+	floatx4 dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
+	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
+	// backward: one-hot 128 at the logit -> 128 * W2[0][:] masked by the forward ReLU (row 0 of the output layer's fragments sits in
+	// the lanes with (lane & 15) == 0, in the hidden layer's K order: exactly the order of b0 / b1)
+	const half8 w0 = ld_frag(s_w, FRAG_D1 + 0, lane & 48), w1 = ld_frag(s_w, FRAG_D1 + 1, lane & 48);
+	half8 g0, g1;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		g0[j] = b0[j] > (half_t)0 ? (half_t)((half_t)128.0f * w0[j]) : (half_t)0;
+		g1[j] = b1[j] > (half_t)0 ? (half_t)((half_t)128.0f * w1[j]) : (half_t)0;
+	}
+	union { uint4 u; half8 h; } a;
+	floatx4 lo = zero, hi = zero; // dL_dy of level h (rows 4h..4h+3 of tile 0) and of level h + 4 (tile 1)
+	a.u = g_wfrags[(FRAG_NORMALS + 0) * 64 + lane]; lo = mfma16(a.h, g0, lo);
+	a.u = g_wfrags[(FRAG_NORMALS + 1) * 64 + lane]; lo = mfma16(a.h, g1, lo);
+	a.u = g_wfrags[(FRAG_NORMALS + 2) * 64 + lane]; hi = mfma16(a.h, g0, hi);
+	a.u = g_wfrags[(FRAG_NORMALS + 3) * 64 + lane]; hi = mfma16(a.h, g1, hi);
+	float dLdy[8];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		dLdy[r] = (float)(half_t)lo[r];
+		dLdy[4 + r] = (float)(half_t)hi[r];
+	}
+	DensityGrad out;
+	encode_gradient(e, scale0, scale1, dLdy, out.g);
+	out.sigma = (half_t)dens[0];
+	return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // activations, nerf_device.cuh:203-263
 // The reference is built with --use_fast_math: its expf is __expf (ex2.approx of x * log2 e) and its divisions are
 // approximate. v_exp_f32 / v_rcp_f32 are the gfx950 counterparts (1 ulp); the oracle uses libm, the difference is
@@ -929,6 +1012,14 @@ NGP_DEV float network_to_density(float v, uint32_t act) {
 		case 2: return logistic(v);
 		case 3: return fast_exp(v);
 		default: return v;
+	}
+}
+NGP_DEV float network_to_density_derivative(float v, uint32_t act) { // nerf_device.cuh:245-254
+	switch (act) {
+		case 1: return v > 0.0f ? 1.0f : 0.0f;
+		case 2: { float d = logistic(v); return d * (1.0f - d); }
+		case 3: return fast_exp(fminf(fmaxf(v, -15.0f), 15.0f));
+		default: return 1.0f;
 	}
 }
 // powf under the reference's --use_fast_math: exp2(y * log2 x), x > 0

@@ -31,7 +31,10 @@ constexpr int BLOCK = 256;
 // exponential-stepping branches; the arithmetic that remains is the same expression for expression.
 // OUTSIDE: the render box may reach beyond the occupancy grid (geometry mode, a hand-set render box)
 // PLAIN: static pinhole camera, no depth of field, no environment map (FrameParams::plain, decided by the host)
-template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false>
+// NORMALS: ERenderMode::Normals -- every sample's colour is the unit vector opposite to the density's input gradient (one backward
+// pass through the density head and the encoding per sample, density_gradient_pass); an instantiation of its own, so that no other
+// kernel carries its registers
+template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false, bool NORMALS = false>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
@@ -113,7 +116,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		if ((exhausted || n_dead >= F.tune[0]) && __any(finished)) {
 			bool hit = false;
 			if (finished) {
-				hit = shade_ray<PROBE, PLAIN>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d); // step counts from 1 like the reference's march loop
+				hit = shade_ray<PROBE, PLAIN, NORMALS>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d); // step counts from 1 like the reference's march loop
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -338,6 +341,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// ---- K5: network, 16 samples per pass; two passes are run together whenever 17+ samples wait, so that 32
 		// gathers per lane and two independent MFMA chains are in flight (the loop is latency-, not issue-bound)
 		half_t o_r = 0, o_g = 0, o_b = 0, o_s = 0;
+		float o_nx = 0.f, o_ny = 0.f, o_nz = 0.f; // NORMALS: d logit / d warped position of the lane's sample
 		const int n_pass = (n_ready + 15) >> 4;
 		const int wave_base = threadIdx.x & ~63;
 		const int hq = lane >> 4;
@@ -365,6 +369,31 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 		};
 		int p = 0;
+		if (NORMALS) {
+			for (; p < n_pass; ++p) {
+				float ax, ay, az;
+				Sh4 sha;
+				sample_of(p, ax, ay, az, sha);
+				EncodeInFlight e;
+				encode_issue(t_grid, t_xgrid, s_lv, hq, ax, ay, az, e);
+				const half8 enc = encode_finish(e);
+				DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale);
+#pragma unroll
+				for (int k = 0; k < 3; ++k) { // the four lanes of a sample hold two levels each
+					dg.g[k] += __shfl_xor(dg.g[k], 16, 64);
+					dg.g[k] += __shfl_xor(dg.g[k], 32, 64);
+				}
+				union { half_t h[2]; int i; } sg;
+				sg.h[0] = dg.sigma; sg.h[1] = 0;
+				const float rx = __shfl(dg.g[0], from, 64), ry = __shfl(dg.g[1], from, 64), rz = __shfl(dg.g[2], from, 64);
+				const int rs = __shfl(sg.i, from, 64);
+				if (my_pass == p) {
+					sg.i = rs;
+					o_s = sg.h[0];
+					o_nx = rx * (1.0f / 128.0f); o_ny = ry * (1.0f / 128.0f); o_nz = rz * (1.0f / 128.0f);
+				}
+			}
+		}
 		for (; p + 1 < n_pass; p += 2) {
 			float ax, ay, az, bx, by, bz;
 			Sh4 sha, shb;
@@ -399,7 +428,11 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			float weight = alpha * T;
 			float cr = network_to_rgb((float)sr, M.rgb_act), cg = network_to_rgb((float)sg, M.rgb_act), cb = network_to_rgb((float)sb, M.rgb_act);
 			if (!PROBE && F.render_mode > 1) { // src/testbed_nerf.cu:689-702
-				if (F.render_mode == 2) {
+				if (NORMALS) { // :688-693: opposite to the density gradient
+					const float dd = network_to_density_derivative((float)ss, M.density_act);
+					const f3 nrm = normalize3(mk3(-dd * o_nx, -dd * o_ny, -dd * o_nz));
+					cr = nrm.x; cg = nrm.y; cb = nrm.z;
+				} else if (F.render_mode == 2) {
 					cr = cg = cb = alpha;
 				} else if (F.render_mode == 3) {
 					cr = (spos.x - 0.5f) / 2.0f + 0.5f; cg = (spos.y - 0.5f) / 2.0f + 0.5f; cb = (spos.z - 0.5f) / 2.0f + 0.5f;
@@ -522,6 +555,10 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_mid2(const ModelPa
 	fused_body<false, false, false, (int)NERF_CASCADES, true, 2>(M, C, F, P);
 }
 // diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, (int)NERF_CASCADES, true, 1, false, true>(M, C, F, P);
+}
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, true>(M, C, F, P);
@@ -654,6 +691,48 @@ __global__ __launch_bounds__(BLOCK) void network_inference_kernel(const ModelPar
 			cv.h = mo.rgb[1]; out[(size_t)s * 4 + 1] = cv.u;
 			cv.h = mo.rgb[2]; out[(size_t)s * 4 + 2] = cv.u;
 			cv.h = mo.sigma;  out[(size_t)s * 4 + 3] = cv.u;
+		}
+	}
+}
+
+// The A fragments of W1^T for the Normals mode's backward pass, permuted out of the forward fragments of W1 (FRAG_D0..+3: lane
+// (h, row), element j = W1[16 m + row][16 (j >> 2) + 4 h + (j & 3)]): fragment 2t + s, lane (h', row'), element j' =
+// W1[neuron 32 s + 16 (j' >> 2) + 4 h' + (j' & 3)][encoding row 16 t + row']. One workgroup of 256 threads; runs whenever the forward
+// fragments change (model load, the training loop's hand-over to the renderer).
+__global__ void build_normals_fragments_kernel(uint16_t* __restrict__ wfrags) {
+	const int i = threadIdx.x; // fragment 2t + s = i >> 6, lane = i & 63
+	const int t = i >> 7, s = (i >> 6) & 1, lane = i & 63, h1 = lane >> 4, row1 = lane & 15;
+	for (int j1 = 0; j1 < 8; ++j1) {
+		const int neuron = 32 * s + 16 * (j1 >> 2) + 4 * h1 + (j1 & 3), e = 16 * t + row1;
+		const int m = neuron >> 4, row = neuron & 15, h = (e & 15) >> 2, j = 4 * (e >> 4) + (e & 3);
+		wfrags[((size_t)(FRAG_NORMALS + 2 * t + s) * 64 + lane) * 8 + j1] = wfrags[((size_t)(FRAG_D0 + m) * 64 + 16 * h + row) * 8 + j];
+	}
+}
+// ngp_density_gradient: d density logit / d position for explicit positions (the stage behind ERenderMode::Normals)
+__global__ __launch_bounds__(BLOCK) void density_gradient_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
+	__shared__ uint4 s_w[FRAG_R0 * 64];
+	__shared__ LevelInfo s_lv[N_LEVELS];
+	for (int i = threadIdx.x; i < FRAG_R0 * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, c = lane & 15, hq = lane >> 4;
+	const GridRsrc t_grid = make_grid_rsrc(M.grid, M.grid_bytes), t_xgrid = make_grid_rsrc(M.xgrid, M.xgrid_bytes);
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	for (int p = 0; p < 4; ++p) {
+		const uint32_t s = wave * 64u + 16u * p + c;
+		const uint32_t sc = s < n ? s : n - 1;
+		EncodeInFlight e;
+		encode_issue(t_grid, t_xgrid, s_lv, hq, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2], e);
+		const half8 enc = encode_finish(e);
+		DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale);
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			dg.g[k] += __shfl_xor(dg.g[k], 16, 64);
+			dg.g[k] += __shfl_xor(dg.g[k], 32, 64);
+		}
+		if (s < n && lane < 16) {
+#pragma unroll
+			for (int k = 0; k < 3; ++k) out[(size_t)s * 3 + k] = dg.g[k] * (1.0f / 128.0f);
 		}
 	}
 }
@@ -876,6 +955,16 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	if (M.wide.width) return launch_render_nerf_wide(M, C, F, n_cus, stream); // configs/nerf/frequency.json: wide_kernels.hip
 	const bool unit = M.max_cascade == 0 && M.cone_angle <= 1e-5f;
 	const bool c5 = !unit && M.max_cascade < 5 && !F.outside_possible;
+	if (F.render_mode == 7) { // ERenderMode::Normals: the density head only, whatever the rgb head
+		static const int per_cu_normals = resident_blocks_per_cu(render_nerf_fused_normals);
+		int nb = n_cus * per_cu_normals;
+		const int need = (int)((F.n_local_tiles + 3) / 4);
+		if (nb > need) nb = need > 0 ? need : 1;
+		FrameParams G = F;
+		G.n_waves = (uint32_t)nb * (BLOCK / 64);
+		hipLaunchKernelGGL(render_nerf_fused_normals, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
+		return;
+	}
 	if (M.rgb_mid != 1) { // the base_1layer / base_3layer heads: one general kernel each
 		static const int per_cu_mid0 = resident_blocks_per_cu(render_nerf_fused_mid0), per_cu_mid2 = resident_blocks_per_cu(render_nerf_fused_mid2);
 		int nb = n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2);
@@ -946,6 +1035,13 @@ void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos
 	if (M.rgb_mid == 0) hipLaunchKernelGGL(network_inference_kernel<0>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 	else if (M.rgb_mid == 2) hipLaunchKernelGGL(network_inference_kernel<2>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 	else hipLaunchKernelGGL(network_inference_kernel<1>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+}
+void launch_build_normals_fragments(uint4* wfrags, hipStream_t stream) {
+	hipLaunchKernelGGL(build_normals_fragments_kernel, dim3(1), dim3(256), 0, stream, (uint16_t*)wfrags);
+}
+void launch_density_gradient(const ModelParams& M, uint32_t n, const float* pos01, float* out, hipStream_t stream) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(density_gradient_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n, pos01, out);
 }
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
                                 float* grid_tmp, hipStream_t stream) {

@@ -422,7 +422,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		M.grid_bytes = (uint32_t)(ng * sizeof(uint16_t));
 	}
 	// weight fragments
-	std::vector<uint16_t> frags((size_t)N_FRAGS_MAX * 64 * 8, 0);
+	std::vector<uint16_t> frags((size_t)(N_FRAGS_MAX + N_NORMALS_FRAGS) * 64 * 8, 0); // (the Normals mode's four are permuted out of the forward ones on the device, below)
 	const uint16_t* W = ctx->params.data();
 	emit_fragments(frags, FRAG_D0, W, 64, 32);
 	emit_fragments(frags, FRAG_D1, W + 64 * 32, 16, 64);
@@ -434,6 +434,7 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	M.rgb_mid = (uint32_t)rgb_mid;
 	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	launch_build_normals_fragments(ctx->d_wfrags, ctx->stream);
 	}
 	// occupancy: fp16 grid -> fp32 -> bitfield + mips on the device (K8/K9)
 	const size_t bitfield_bytes = (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES;
@@ -1126,9 +1127,10 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	ngp::sync_inference_model(ctx);
 	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
-	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_SHADE_GRID_ENVMAP) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Positions, Depth, Cost");
-	const bool gbuffer_mode = opts.render_mode >= NGP_RENDER_AO && opts.render_mode <= NGP_RENDER_COST;
-	if (gbuffer_mode && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Positions, Depth, Cost) apply to NeRF mode");
+	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_NORMALS) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Normals, Positions, Depth, Cost");
+	const bool gbuffer_mode = (opts.render_mode >= NGP_RENDER_AO && opts.render_mode <= NGP_RENDER_COST) || opts.render_mode == NGP_RENDER_NORMALS;
+	if (gbuffer_mode && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Normals, Positions, Depth, Cost) apply to NeRF mode");
+	if (opts.render_mode == NGP_RENDER_NORMALS && ctx->model_loaded && ctx->M.wide.width) throw std::runtime_error("render_mode Normals is built for the grid encodings (configs/nerf/base.json); not for a Frequency-encoding model");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
@@ -1794,6 +1796,27 @@ int ngp_grid_encode(ngp_ctx* ctx, uint32_t n, const float* pos01, uint16_t* out_
 		else launch_grid_encode(ctx->M, n, d_pos, d_out, ctx->stream);
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		NGP_HIP_CHECK(hipMemcpy(out_fp16, d_out, (size_t)n * width * sizeof(uint16_t), hipMemcpyDeviceToHost));
+		(void)hipFree(d_pos);
+		(void)hipFree(d_out);
+		NGP_HIP_CHECK(hipGetLastError());
+	});
+}
+
+int ngp_density_gradient(ngp_ctx* ctx, uint32_t n, const float* pos01, float* out_grad) {
+	return guarded(ctx, [&] {
+		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
+		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
+		if (ctx->M.wide.width) throw std::runtime_error("the density gradient is built for the grid encodings (configs/nerf/base.json)");
+		ngp::sync_inference_model(ctx);
+		if (n == 0) return;
+		if (!pos01 || !out_grad) throw std::runtime_error("null argument");
+		float *d_pos = nullptr, *d_out = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&d_pos, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)));
+		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+		launch_density_gradient(ctx->M, n, d_pos, d_out, ctx->stream);
+		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		NGP_HIP_CHECK(hipMemcpy(out_grad, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
 		(void)hipFree(d_pos);
 		(void)hipFree(d_out);
 		NGP_HIP_CHECK(hipGetLastError());

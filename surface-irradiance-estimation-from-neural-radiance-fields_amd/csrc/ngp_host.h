@@ -28,6 +28,8 @@ namespace ngp {
 // kernel launchers, nerf_kernels.hip
 void launch_render_nerf(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream);
+void launch_build_normals_fragments(uint4* wfrags, hipStream_t stream); // after every change of the forward fragments
+void launch_density_gradient(const ModelParams& M, uint32_t n, const float* pos01, float* out, hipStream_t stream);
 // wide_kernels.hip (ModelParams::wide): the launchers above that take a model forward to these when M.wide.width != 0
 void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream);

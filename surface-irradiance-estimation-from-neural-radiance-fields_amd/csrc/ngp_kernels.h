@@ -24,6 +24,8 @@ constexpr int FRAG_D0 = 0, FRAG_D1 = 4, FRAG_R0 = 6, FRAG_R1 = 10, FRAG_R2 = 18,
 // FRAG_R1, the output layer behind them; the fragment buffer always holds N_FRAGS_MAX
 constexpr int MAX_RGB_MID = 2, N_FRAGS_MAX = FRAG_R1 + 8 * MAX_RGB_MID + 2;
 constexpr int n_frags_for(int rgb_mid) { return FRAG_R1 + 8 * rgb_mid + 2; }
+// behind them, four fragments of the density head's first layer transposed: the backward pass of ERenderMode::Normals (nerf_device.h)
+constexpr int N_NORMALS_FRAGS = 4, FRAG_NORMALS = N_FRAGS_MAX;
 
 struct LevelInfo {
 	float scale;

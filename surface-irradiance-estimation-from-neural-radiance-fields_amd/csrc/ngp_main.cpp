@@ -149,6 +149,7 @@ int main(int argc, char** argv) {
 		else if (render_mode == "ShadeGridEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeGridEnvMap;
 		else if (render_mode == "ShadeEnvMap") testbed.m_render_mode = ngp::ERenderMode::ShadeEnvMap;
 		else if (render_mode == "AO") testbed.m_render_mode = ngp::ERenderMode::AO;
+		else if (render_mode == "Normals") testbed.m_render_mode = ngp::ERenderMode::Normals;
 		else if (render_mode == "Positions") testbed.m_render_mode = ngp::ERenderMode::Positions;
 		else if (render_mode == "Depth") testbed.m_render_mode = ngp::ERenderMode::Depth;
 		else throw std::runtime_error("unknown render mode " + render_mode);

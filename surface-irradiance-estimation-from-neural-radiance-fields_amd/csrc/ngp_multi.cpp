@@ -71,7 +71,7 @@ void sync_peer_model(ngp_ctx* primary, ngp_ctx* peer) {
 	if (params) {
 		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_params, peer->device, primary->d_params, primary->device, primary->M.grid_bytes));
 		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_xgrid, peer->device, primary->d_xgrid, primary->device, primary->M.xgrid_bytes));
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_wfrags, peer->device, primary->d_wfrags, primary->device, (size_t)N_FRAGS_MAX * 64 * sizeof(uint4)));
+		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_wfrags, peer->device, primary->d_wfrags, primary->device, (size_t)(N_FRAGS_MAX + N_NORMALS_FRAGS) * 64 * sizeof(uint4)));
 		peer->synced_params_generation = primary->params_generation;
 	}
 }

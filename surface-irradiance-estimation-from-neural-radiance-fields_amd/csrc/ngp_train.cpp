@@ -441,6 +441,7 @@ void sync_inference_model(ngp_ctx* ctx) {
 	launch_train_xor_layout(ctx->M, (const uint2*)ctx->d_params, (char*)ctx->d_xgrid, stream);
 	launch_train_build_fragments(src, T.d_tfrags_inference, T.d_kfrags_inference, stream);
 	NGP_HIP_CHECK(hipMemcpyAsync(ctx->d_wfrags, T.d_tfrags_inference, (size_t)N_FRAGS * 64 * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
+	launch_build_normals_fragments(ctx->d_wfrags, stream);
 	NGP_HIP_CHECK(hipStreamSynchronize(stream));
 	NGP_HIP_CHECK(hipGetLastError());
 	T.inference_dirty = false;

@@ -45,11 +45,17 @@ NGP_DEV float4 tonemap_pixel(const FrameParams& F, f3 bg_linear, float r, float 
 	return tmp;
 }
 
-template <bool PROBE, bool PLAIN = false>
+template <bool PROBE, bool PLAIN = false, bool NORMALS = false>
 NGP_DEV bool shade_ray(const FrameParams& F, const ProbeParams& P, f3 bg_linear, uint32_t idx, const Accum& acc, uint32_t n_steps, f3 dir) {
 	if (!(acc.a > 0.001f)) return false;
 	if (!PROBE && F.depth_test && acc.depth > F.depth_buffer[idx]) return true;
 	float r = acc.r, g = acc.g, b = acc.b, a = acc.a;
+	if (NORMALS) { // ERenderMode::Normals (:1379-1381): the composited normal, normalised again, as a premultiplied colour
+		const f3 n = normalize3(mk3(r, g, b));
+		r = (0.5f * n.x + 0.5f) * a;
+		g = (0.5f * n.y + 0.5f) * a;
+		b = (0.5f * n.z + 0.5f) * a;
+	}
 	if (!PROBE && F.render_mode == 5) { // ERenderMode::Cost: the ray's sample count as a grey level, opaque (:1382-1384)
 		r = g = b = (float)n_steps / 128.0f;
 		a = 1.0f;

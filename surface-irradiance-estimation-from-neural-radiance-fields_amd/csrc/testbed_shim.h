@@ -383,9 +383,10 @@ public:
 			set_camera_from_time(start_time + (end_time - start_time) * (((float)spp - 0.5f) / (float)spp * shutter_fraction));
 			return;
 		}
-		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth || m_render_mode == ERenderMode::Cost;
+		const bool gbuffer = m_render_mode == ERenderMode::AO || m_render_mode == ERenderMode::Positions || m_render_mode == ERenderMode::Depth || m_render_mode == ERenderMode::Cost ||
+		                     m_render_mode == ERenderMode::Normals;
 		const bool shade_family = m_render_mode == ERenderMode::Shade || m_render_mode == ERenderMode::ShadeEnvMap || m_render_mode == ERenderMode::ShadeGridEnvMap;
-		if (!shade_family && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Positions, Depth, Cost");
+		if (!shade_family && !gbuffer) throw std::runtime_error("render modes supported: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Normals, Positions, Depth, Cost");
 		// pre computation of the envmap: src/main.cu:184-188 runs it before the first frame; a Python session has no such hook
 		// (python_api.cu binds neither function), so the first Geometry-mode render in these modes runs it with the defaults
 		if (m_testbed_mode == ETestbedMode::Geometry && ngp_n_meshes(m_ctx) > 0) {
@@ -417,7 +418,7 @@ public:
 		}
 		ngp_render_opts o{};
 		o.render_mode = m_render_mode == ERenderMode::ShadeEnvMap ? NGP_RENDER_SHADE_ENVMAP : m_render_mode == ERenderMode::ShadeGridEnvMap ? NGP_RENDER_SHADE_GRID_ENVMAP : m_render_mode == ERenderMode::AO ? NGP_RENDER_AO
-		              : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : m_render_mode == ERenderMode::Cost ? NGP_RENDER_COST : NGP_RENDER_SHADE;
+		              : m_render_mode == ERenderMode::Normals ? NGP_RENDER_NORMALS : m_render_mode == ERenderMode::Positions ? NGP_RENDER_POSITIONS : m_render_mode == ERenderMode::Depth ? NGP_RENDER_DEPTH : m_render_mode == ERenderMode::Cost ? NGP_RENDER_COST : NGP_RENDER_SHADE;
 		o.min_transmittance = nerf.render_min_transmittance;
 		memcpy(o.background, m_background_color.data(), sizeof(o.background));
 		o.exposure = m_exposure;

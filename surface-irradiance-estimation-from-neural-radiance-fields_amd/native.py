@@ -86,7 +86,7 @@ class ProbeGridDesc(C.Structure):
 
 
 MODE_NERF, MODE_GEOMETRY = 0, 1
-RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH, RENDER_COST, RENDER_SHADE_GRID_ENVMAP = 0, 1, 2, 3, 4, 5, 6
+RENDER_SHADE, RENDER_SHADE_ENVMAP, RENDER_AO, RENDER_POSITIONS, RENDER_DEPTH, RENDER_COST, RENDER_SHADE_GRID_ENVMAP, RENDER_NORMALS = 0, 1, 2, 3, 4, 5, 6, 7
 PROBE_CENTER, PROBE_CENTER_OUTWARD, PROBE_MULTI_CENTER = 0, 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left_idx", "<i4"), ("right_idx", "<i4")])
 TRIANGLE_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3)])
@@ -173,6 +173,7 @@ def load_library():
     L.ngp_set_schedule.argtypes = [vp, vp, ip]
     L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
     L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.ngp_density_gradient.argtypes = [vp, C.c_uint32, vp, vp]
     L.ngp_get_density_bitfield.argtypes = [vp, vp, vp]
     L.ngp_init_rays.argtypes = [vp, C.POINTER(Camera), vp]
     L.ngp_load_scene.argtypes = [vp, C.c_char_p]
@@ -557,6 +558,13 @@ class Context:
         out = np.zeros((pos01.shape[0], width), np.uint16)
         self._check(self.L.ngp_grid_encode(self.h, pos01.shape[0], _p(pos01), _p(out)))
         return out.view(np.float16)
+
+    def density_gradient(self, pos01):
+        """d density logit / d position (what ERenderMode::Normals composites): n x 3 floats"""
+        pos01 = np.ascontiguousarray(pos01, np.float32)
+        out = np.zeros((pos01.shape[0], 3), np.float32)
+        self._check(self.L.ngp_density_gradient(self.h, pos01.shape[0], _p(pos01), _p(out)))
+        return out
 
     def network(self, pos01, dir01):
         pos01 = np.ascontiguousarray(pos01, np.float32)

@@ -400,3 +400,67 @@ def test_density_grid_refresh_oracle(oracle, scene_unit):
     assert np.all(g1 >= np.float32(0.95) * grid0 - 1e-6) and np.all(g1[touched] > 0)
     # the non-uniform half only lands in cells that were above the optical-thickness threshold
     assert np.isfinite(g1).all()
+
+
+def test_density_gradient_against_central_differences(oracle, scene_mod):
+    """ERenderMode::Normals' input gradient (orc_density_gradient: fp16 backward pass + tcnn's dy_dx) against central differences of a
+    float64 restatement of the same density head (no fp16 rounding anywhere: the two can differ by the fp16 noise only)."""
+    from conftest import pkg
+
+    from conftest import _with_bitfield
+
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=17, log2_hashmap_size=14))
+    m = oracle.make_model(sc)
+    enc = sc["encoding"]
+    F = enc["n_features_per_level"]
+    offsets, resolutions, scales = scene_mod.grid_layout(enc)
+    params = np.asarray(sc["params"], np.uint16).view(np.float16).astype(np.float64)
+    nd, nr, ng = scene_mod.n_params(sc)
+    W1 = params[:64 * 32].reshape(64, 32)
+    W2 = params[64 * 32:64 * 32 + 16 * 64].reshape(16, 64)
+    grid = params[nd + nr:]
+
+    def logit(x):  # x: float64[3]
+        feats = []
+        for l in range(enc["n_levels"]):
+            size = offsets[l + 1] - offsets[l]
+            table = grid[offsets[l] * F:offsets[l + 1] * F].reshape(size, F)
+            p = x * float(np.float32(scales[l])) + 0.5
+            pg = np.floor(p)
+            w = p - pg
+            pg = pg.astype(np.int64)
+            acc = np.zeros(F)
+            res = resolutions[l]
+            for c in range(8):
+                wt, g = 1.0, []
+                for d in range(3):
+                    bit = (c >> d) & 1
+                    wt *= w[d] if bit else 1 - w[d]
+                    g.append(int(pg[d]) + bit)
+                stride, index = 1, 0
+                for d in range(3):
+                    if stride > size:
+                        break
+                    index = (index + g[d] * stride) & 0xFFFFFFFF
+                    stride *= res
+                if size < stride:
+                    index = (g[0] ^ ((g[1] * 2654435761) & 0xFFFFFFFF) ^ ((g[2] * 805459861) & 0xFFFFFFFF))
+                acc += wt * table[index % size]
+            feats.append(acc)
+        h = np.maximum(W1 @ np.concatenate(feats), 0)
+        return (W2 @ h)[0]
+
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(0.2, 0.8, (48, 3)).astype(np.float32)
+    got = oracle.density_gradient(m, pos)
+    oracle.release(m)
+    eps = 1e-6
+    cos = []
+    for i in range(pos.shape[0]):
+        x = pos[i].astype(np.float64)
+        fd = np.array([(logit(x + eps * e) - logit(x - eps * e)) / (2 * eps) for e in np.eye(3)])
+        if np.linalg.norm(fd) < 1e-3:
+            continue
+        cos.append(float(fd @ got[i] / (np.linalg.norm(fd) * np.linalg.norm(got[i]))))
+        assert abs(np.linalg.norm(got[i]) / np.linalg.norm(fd) - 1) < 0.1
+    assert len(cos) > 30 and np.median(cos) > 0.999 and min(cos) > 0.97, (np.median(cos), min(cos))

@@ -727,3 +727,54 @@ def test_moving_camera_and_rolling_shutter(shutter, native, oracle, scene_mod, s
     with pytest.raises(RuntimeError, match="moving camera"):
         ctx.render(native.make_camera(m0, w, h, focal, matrix1_3x4=m1), native.make_opts(testbed_mode=native.MODE_GEOMETRY))
     ctx.close()
+
+
+@pytest.mark.parametrize("which", ["unit", "big"])
+def test_density_gradient(which, gpu_ctx, oracle, scene_unit, scene_big):
+    """the stage behind ERenderMode::Normals (tcnn input_gradient of the density logit): same fp16 backward pass and dy_dx as the
+    oracle; the MFMA's fp32 accumulation order can move one fp16 dL/dy by an ulp and the four lanes of a sample add their level
+    pairs in a different order"""
+    sc = scene_unit if which == "unit" else scene_big
+    gpu_ctx.set_model(sc)
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(21)
+    pos = rng.uniform(0, 1, (4096 + 7, 3)).astype(np.float32)
+    got = gpu_ctx.density_gradient(pos)
+    ref = oracle.density_gradient(m, pos)
+    oracle.release(m)
+    assert np.isfinite(got).all()
+    nr = np.linalg.norm(ref, axis=1)
+    ok = nr > 1e-3 * np.median(nr)
+    cos = (got[ok] * ref[ok]).sum(1) / (np.linalg.norm(got[ok], axis=1) * nr[ok])
+    assert ok.mean() > 0.95 and np.median(cos) > 0.99999 and cos.min() > 0.995, (np.median(cos), cos.min())
+    rel = np.linalg.norm(got[ok] - ref[ok], axis=1) / nr[ok]
+    assert np.median(rel) < 2e-3 and rel.max() < 0.1, (np.median(rel), rel.max())
+    assert gpu_ctx.density_gradient(np.zeros((0, 3), np.float32)).shape == (0, 3)
+
+
+def test_render_mode_normals(gpu_ctx, oracle, native, scene_mod, scene_unit):
+    """ERenderMode::Normals (composite_kernel_nerf :688-693, shade_kernel_nerf :1379-1381) against the oracle"""
+    w, h = 96, 54
+    gpu_ctx.set_model(scene_unit)
+    m = oracle.make_model(scene_unit)
+    cam, ocam = _cam_pair(native, oracle, scene_mod, w, h, az=70.0)
+    img = gpu_ctx.render(cam, native.make_opts(render_mode=native.RENDER_NORMALS))
+    st = gpu_ctx.render_stats()
+    fb, db, ost = oracle.render_nerf(m, ocam, oracle.make_opts(render_mode=7))
+    ref = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    oracle.release(m)
+    assert abs(int(st["n_samples"]) - int(ost["n_samples"])) <= 1e-4 * ost["n_samples"] + 2
+    assert np.isfinite(img).all()
+    hit = ref[..., 3] > 0.5
+    assert hit.sum() > 500
+    # the pixel is (0.5 n + 0.5) alpha: undo it and compare directions
+    n_got = img[..., :3][hit] / img[..., 3:][hit] * 2 - 1
+    n_ref = ref[..., :3][hit] / ref[..., 3:][hit] * 2 - 1
+    cos = (n_got * n_ref).sum(1) / (np.linalg.norm(n_got, axis=1) * np.linalg.norm(n_ref, axis=1))
+    assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.995, (np.median(cos), (cos > 0.99).mean())
+    # (a sample whose gradient nearly vanishes has a direction that one fp16 ulp of dL/dy can turn: such samples move a pixel visibly)
+    # and where a ray's normals nearly cancel, the renormalisation in the shade step amplifies it: measured 41.6 dB, 99.4 % within 0.05)
+    assert_image_close(img, ref, 38.0, tol=5e-2, frac=0.99, hard=1.01)
+    # the normals of a shape seen from outside face the camera
+    cam_dir = scene_mod.orbit_camera(70.0)[:, 2]
+    assert np.median(n_got @ cam_dir) < -0.1
