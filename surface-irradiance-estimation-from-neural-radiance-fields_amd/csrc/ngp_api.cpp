@@ -1637,6 +1637,10 @@ uint32_t ngp_packed_tiles(int32_t width, int32_t height, uint32_t shard_index, u
 	return tiles_total > shard_index ? (tiles_total - shard_index + shard_count - 1) / shard_count : 0;
 }
 
+namespace {
+void* pinned_device_alias(const void* host, size_t bytes); // below, with the pool
+}
+
 int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out) {
 	return guarded(ctx, [&] {
 		if (!cam || !opts || !rgba_out) throw std::runtime_error("null argument");
@@ -1644,10 +1648,17 @@ int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts,
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 		const size_t n_pixels = (size_t)cam->width * cam->height;
 		ensure_frame_buffers(ctx, n_pixels);
-		if (!ctx->peers.empty() && opts->shard_count <= 1) ngp::render_frames_multi(ctx, *cam, *opts, ctx->d_rgba, ctx->d_depth, ctx->stream);
-		else render_frames(ctx, *cam, *opts, ctx->d_rgba, nullptr, ctx->stream);
-		// (a destination from ngp_host_alloc is page-locked: the copy is one DMA at the link's rate instead of a staged one)
-		NGP_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_rgba, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+		// A destination from ngp_host_alloc is page-locked AND mapped into the device's address space: the image is write-only for
+		// every kernel that produces it (the fused kernel's direct output, accumulate + tonemap, the multi-device tile scatter), so
+		// they write it over the link while they run and no copy follows the frame -- the 33 MB of a 1080p frame would take the
+		// copy engine 0.8 ms after a 2.4 ms render. NGP_HOST_DIRECT=0 restores render-then-copy (A/B measurements).
+		static const bool host_direct = []() { const char* e = getenv("NGP_HOST_DIRECT"); return !e || atoi(e) != 0; }();
+		float4* d_image = host_direct ? (float4*)pinned_device_alias(rgba_out, n_pixels * sizeof(float4)) : nullptr;
+		float4* d_target = d_image ? d_image : ctx->d_rgba;
+		if (!ctx->peers.empty() && opts->shard_count <= 1) ngp::render_frames_multi(ctx, *cam, *opts, d_target, ctx->d_depth, ctx->stream);
+		else render_frames(ctx, *cam, *opts, d_target, nullptr, ctx->stream);
+		// (otherwise: one DMA at the link's rate into page-locked memory, a staged copy into ordinary memory)
+		if (!d_image) NGP_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_rgba, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
 		if (depth_out) NGP_HIP_CHECK(hipMemcpyAsync(depth_out, ctx->d_depth, n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	});
@@ -1666,6 +1677,24 @@ struct HostPool {
 	}
 } g_host_pool;
 constexpr size_t HOST_POOL_KEEP = 8; // buffers kept for reuse per process
+} // namespace
+
+namespace {
+// the device-side address of [host, host + bytes) if that range lies inside a live page-locked buffer of the pool, else nullptr
+void* pinned_device_alias(const void* host, size_t bytes) {
+	std::lock_guard<std::mutex> lock(g_host_pool.mu);
+	auto it = g_host_pool.live.upper_bound(const_cast<void*>(host));
+	if (it == g_host_pool.live.begin()) return nullptr;
+	--it;
+	const char* base = (const char*)it->first;
+	if (it->second == 0 || (const char*)host < base || (const char*)host + bytes > base + it->second) return nullptr;
+	void* dev = nullptr;
+	if (hipHostGetDevicePointer(&dev, it->first, 0) != hipSuccess || !dev) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return (char*)dev + ((const char*)host - base);
+}
 } // namespace
 
 void* ngp_host_alloc(size_t bytes) {
