@@ -119,7 +119,8 @@ def pmc_evidence():
         out["ta_busy_max"] = round(l1["TA_BUSY_max"] / cyc, 3)
         out["l1_hit_rate"] = round(1.0 - l1["TCP_TCC_READ_REQ_sum"] / l1["TCP_TOTAL_CACHE_ACCESSES_sum"], 3)
         out["l2_hit_rate"] = round(l1["TCC_HIT_sum"] / (l1["TCC_HIT_sum"] + l1["TCC_MISS_sum"]), 3)
-        lane_loads = l1["TA_FLAT_READ_WAVEFRONTS_sum"] * 64.0
+        # (flat loads in round 1, buffer loads since: the latter count in TA_TOTAL_WAVEFRONTS only)
+        lane_loads = max(l1["TA_FLAT_READ_WAVEFRONTS_sum"], l1.get("TA_TOTAL_WAVEFRONTS_sum", 0.0)) * 64.0
         out["lane_loads_per_clk_per_cu"] = round(lane_loads / 256.0 / cyc, 3)
         out["l1_source"] = "profiles/" + name
     return out

@@ -29,7 +29,7 @@ write_kb, nw = vals["WRITE_SIZE"]
 out = {
     "FETCH_SIZE_KB_per_launch": fetch_kb, "FETCH_SIZE_launches": nf,
     "WRITE_SIZE_KB_per_launch": write_kb, "WRITE_SIZE_launches": nw,
-    "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --warmup 1), kernel render_nerf_fused_unit, 1080p. "
+    "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --warmup 1), kernel render_nerf_fused_unit_plain, 1080p. "
             "Counters are in KB; gfx950 reports half of the fetched bytes (MI355X_MICROARCH.md), so read bytes = 2 x FETCH_SIZE. Infinity-Cache hits are included.",
     "traffic_bytes_per_launch_corrected": int((2.0 * fetch_kb + write_kb) * 1024.0),
 }
@@ -44,7 +44,7 @@ if "SQ_INSTS_VALU" in vals:
     comp["kernel_cycles_per_xcd"] = cyc
     comp["valu_issue_utilisation"] = comp["SQ_INSTS_VALU"] * 4.0 / simds / cyc
     comp["mfma_pipe_utilisation"] = comp["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cyc
-    comp["note"] = "per launch of render_nerf_fused_unit at 1080p (bench.py --steps 3 --warmup 1, kernels serialised by the counter collection)"
+    comp["note"] = "per launch of render_nerf_fused_unit_plain at 1080p (bench.py --steps 3 --warmup 1, kernels serialised by the counter collection)"
     json.dump(comp, open(f"gpurun_out/{tag}_pmc_compute.json", "w"), indent=1)
     print(comp)
 PY
