@@ -72,7 +72,8 @@ def nerf_config(name, sc, w, h, azimuths, radius=4.03, check_wh=(240, 135)):
     bytes_alg = st["n_samples"] * 512 + rays * 80
     out = {"config": name, "resolution": [w, h], "Mrays_s": round(rays / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3, 3), "kernel_ms": round(st["kernel_ms"], 3),
            "samples_per_hit_ray": round(S, 2), "hit_fraction": round(st["n_rays_hit"] / rays, 4),
-           "hbm_roofline_frac": round(bytes_alg / (st["kernel_ms"] * 1e-3) / 8e12, 3), "mfma_roofline_frac": round(st["n_samples"] * 20480 / (st["kernel_ms"] * 1e-3) / 2.5e15, 4),
+           # over the frame time with two frames in flight (the HIP-event duration of a launch that overlaps its neighbour is not a rate)
+           "gather_ceiling_frac": round(bytes_alg / dt / 9.437e12, 3), "hbm_roofline_frac": round(bytes_alg / dt / 8e12, 3), "mfma_roofline_frac": round(st["n_samples"] * 20480 / dt / 2.5e15, 4),
            "psnr_vs_oracle_db": round(psnr(srgb(img[..., :3]), srgb(ref[..., :3])), 1), "max_abs_diff": float(np.abs(img - ref).max()),
            "cpu_oracle_Mrays_s": round(cw * ch / cpu_s / 1e6, 4), "cpu_cores": CORES, "levels_hashed": int(sum(1 for r in scene.grid_layout(sc["encoding"])[1] if r ** 3 > 2 ** sc["encoding"]["log2_hashmap_size"]))}
     print(json.dumps(out), flush=True)
@@ -105,7 +106,8 @@ def mesh_config(ctx, sc):
     lo, hi = orc.mesh_scene_aabb(hnd)
     s2["render_aabb"] = (tuple(lo.tolist()), tuple(hi.tolist()))
     m = orc.make_model(s2)
-    fb2, _, _ = orc.render_nerf(m, ocam, orc.make_opts(depth_test=True, n_threads=CORES), frame_buffer=fb, depth_buffer=db)
+    # (render_mode 1 = ShadeEnvMap: only ERenderMode::Shade linearises the NeRF's sRGB output in shade_kernel_nerf, :1393)
+    fb2, _, _ = orc.render_nerf(m, ocam, orc.make_opts(depth_test=True, n_threads=CORES, render_mode=1), frame_buffer=fb, depth_buffer=db)
     ref = orc.tonemap(orc.accumulate(fb2.reshape(-1, 4), np.zeros((cw * ch, 4), np.float32), 0)).reshape(ch, cw, 4)
     # irradiance parity: E(n) on 512 random normals, HIP probe vs oracle probe
     m0 = orc.make_model(sc)
