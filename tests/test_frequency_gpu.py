@@ -177,3 +177,54 @@ def test_tile_sharding_and_block_jump_knob(ctx, native, scene_mod, scene_freq):
         ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
     d = np.abs(exact - full).max(-1)
     assert np.median(d) < 1e-3 and (d > 1e-2).mean() < 2e-3
+
+
+def test_hybrid_frame_with_meshes(ctx, oracle, native, scene_mod, scene_freq):
+    """Geometry mode with this architecture: mesh pass, then the NeRF pass inside the inflated scene box, depth-tested against the
+    meshes (shade_kernel_nerf_geometry); the march starts outside the occupancy grid's cube"""
+    ctx.set_model(scene_freq)
+    ctx.clear_meshes()
+    mi = pkg("meshio")
+    meshes = [(mi.icosphere(3), (0.55, -0.1, 0.0)), (mi.torus(32, 16), (-0.3, 0.25, 0.4))]
+    for tris, c in meshes:
+        ctx.add_mesh(tris, c)
+    hnd = oracle.mesh_scene(meshes)
+    w, h = 128, 72
+    mat = scene_mod.orbit_camera(60.0, 25.0, 5.5)
+    focal = scene_mod.focal_from_fov_x(w, 0.8)
+    try:
+        img = ctx.render(native.make_camera(mat, w, h, focal), native.make_opts(testbed_mode=native.MODE_GEOMETRY))
+        st = ctx.render_stats()
+    finally:
+        ctx.clear_meshes()
+    ocam = oracle.make_camera(mat, w, h, focal)
+    fb, db = oracle.render_mesh(hnd, ocam)
+    sc = dict(scene_freq)
+    lo, hi = oracle.mesh_scene_aabb(hnd)
+    sc["render_aabb"] = (tuple(lo.tolist()), tuple(hi.tolist()))
+    m = oracle.make_model(sc)
+    fb2, db2, ost = oracle.render_nerf(m, ocam, oracle.make_opts(depth_test=True), frame_buffer=fb, depth_buffer=db)
+    ref = oracle.tonemap(oracle.accumulate(fb2.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    oracle.release(m)
+    oracle.mesh_scene_destroy(hnd)
+    assert ost["n_rays_hit"] > 300 and abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 3
+    assert (np.abs(fb2 - fb).sum(-1) > 0).mean() > 0.05  # the NeRF shows in front of / beside the meshes
+    assert psnr(img[..., :3], ref[..., :3]) > 45.0
+    assert (np.abs(img - ref).max(-1) < 1e-2).mean() > 0.995
+
+
+def test_multi_device_context(native, scene_mod, scene_freq, gpu_ctx):
+    """ngp_create_multi with this architecture (the same device listed twice on a one-GPU box): the assembled frame is the
+    single-device frame bit for bit"""
+    single = native.Context(0)
+    multi = native.Context(devices=[0, 0])
+    try:
+        single.set_model(scene_freq)
+        multi.set_model(scene_freq)
+        w, h = 101, 67
+        cam = native.make_camera(scene_mod.orbit_camera(60.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+        assert np.array_equal(multi.render(cam), single.render(cam))
+        assert multi.render_stats()["n_samples"] == single.render_stats()["n_samples"]
+    finally:
+        multi.close()
+        single.close()
