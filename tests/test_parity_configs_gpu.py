@@ -334,3 +334,32 @@ def test_multi_device_context_assembles_the_single_device_frame(n_dev, native, s
         multi.render(cam, native.make_opts(testbed_mode=native.MODE_GEOMETRY))
     multi.close()
     single.close()
+
+
+def test_render_into_page_locked_images(native, scene_mod, scene_unit, gpu_ctx):
+    """ngp_render with a destination from ngp_host_alloc: the kernels write the device-mapped image themselves (direct output at
+    1 spp, accumulate + tonemap at several, the tile scatter of a multi-device context) and no copy follows; the pixels are those of
+    the render-then-copy path into ordinary memory, bit for bit"""
+    import ctypes as C
+
+    single = native.Context(0)
+    multi = native.Context(devices=[0, 0])
+    try:
+        single.set_model(scene_unit)
+        multi.set_model(scene_unit)
+        w, h = 200, 112
+        cam = native.make_camera(scene_mod.orbit_camera(30.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911), snap=False)
+        for opts in (native.make_opts(to_srgb=True), native.make_opts(spp=3, background=(0.2, 0.3, 0.4, 1.0)), native.make_opts(render_mode=native.RENDER_DEPTH)):
+            ref = single.render(cam, opts)
+            assert np.array_equal(single.render_pinned(cam, opts), ref)
+            assert np.array_equal(multi.render_pinned(cam, opts), ref)
+        # a destination INSIDE a page-locked buffer (an image of a batch): the alias carries the offset
+        batch = native.host_image((3, h, w, 4))
+        batch[:] = -1.0
+        opts = native.make_opts()
+        ref = single.render(cam, opts)
+        single._check(single.L.ngp_render(single.h, C.byref(cam), C.byref(opts), batch[1].ctypes.data_as(C.c_void_p), None))
+        assert np.array_equal(batch[1], ref) and (batch[0] == -1.0).all() and (batch[2] == -1.0).all()
+    finally:
+        multi.close()
+        single.close()
