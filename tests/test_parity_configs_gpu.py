@@ -363,3 +363,34 @@ def test_render_into_page_locked_images(native, scene_mod, scene_unit, gpu_ctx):
     finally:
         multi.close()
         single.close()
+
+
+def test_fox_shaped_4k_across_eight_shards(native, scene_mod, scene_big, gpu_ctx):
+    """BASELINE config 4's tiling (fox-shaped model: aabb_scale 4, exponential stepping, 3 cascades; 3840 x 2160 over 8 ranks),
+    rehearsed on one GPU: every rank's tile-packed share rendered in turn, assembled the way the gather does, equals the frame one
+    device renders -- the c5 kernel, packed output and the unpack indices at the size the scaling run uses."""
+    import torch
+    from conftest import pkg
+
+    par = pkg("parallel")
+    w, h, world = 3840, 2160, 8
+    ctx = native.Context(0)
+    try:
+        ctx.set_model(scene_big)
+        cam = native.make_camera(scene_mod.orbit_camera(120.0, 25.0, 5.0), w, h, scene_mod.focal_from_fov_x(w, 0.6911))
+        full, full_depth = ctx.render(cam, native.make_opts(), want_depth=True)
+        n_full = ctx.render_stats()["n_samples"]
+        g = par.PackedFrameGather(w, h, world, torch.device("cuda", 0))
+        parts_rgba, parts_depth, n_parts = [], [], 0
+        for r in range(world):
+            rgba, depth = g.buffers()
+            ctx.render_device(cam, native.make_opts(shard_index=r, shard_count=world, packed_output=True), rgba.data_ptr(), depth.data_ptr(), None)
+            n_parts += ctx.render_stats()["n_samples"]  # (synchronises the context's stream)
+            parts_rgba.append(rgba.clone())
+            parts_depth.append(depth.clone())
+        img, dep = g.unpack(torch.cat(parts_rgba), torch.cat(parts_depth))
+        assert n_parts == n_full and full[..., 3].min() >= 0.0 and (full[..., :3] > 0).mean() > 0.3
+        assert np.array_equal(img.cpu().numpy(), full)
+        assert np.array_equal(dep.cpu().numpy(), full_depth)
+    finally:
+        ctx.close()
