@@ -395,7 +395,7 @@ def main():
         if solo:
             out["single_frame_ms"] = round(solo["frame_s"] * 1e3, 4)          # one frame at a time, image left in HBM
             out["single_frame_mrays"] = round(n_rays / solo["frame_s"] / 1e6, 2)
-            out["with_host_copy_ms"] = round(solo["host_s"] * 1e3, 4)         # ngp_render: render + copy into a page-locked host array (PCIe-inclusive; never `value`)
+            out["with_host_copy_ms"] = round(solo["host_s"] * 1e3, 4)         # ngp_render into a page-locked, device-mapped host array: the kernels write it over the link themselves (PCIe-inclusive; never `value`)
             out["with_host_copy_mrays"] = round(n_rays / solo["host_s"] / 1e6, 2)
             out["with_host_copy_pageable_mrays"] = round(n_rays / solo["pageable_s"] / 1e6, 2)  # into ordinary (pageable) memory
         if gather_diff is not None:
