@@ -336,6 +336,7 @@ def test_multi_device_context_assembles_the_single_device_frame(n_dev, native, s
     single.close()
 
 
+@pytest.mark.gpu
 def test_render_into_page_locked_images(native, scene_mod, scene_unit, gpu_ctx):
     """ngp_render with a destination from ngp_host_alloc: the kernels write the device-mapped image themselves (direct output at
     1 spp, accumulate + tonemap at several, the tile scatter of a multi-device context) and no copy follows; the pixels are those of
@@ -365,6 +366,7 @@ def test_render_into_page_locked_images(native, scene_mod, scene_unit, gpu_ctx):
         single.close()
 
 
+@pytest.mark.gpu
 def test_fox_shaped_4k_across_eight_shards(native, scene_mod, scene_big, gpu_ctx):
     """BASELINE config 4's tiling (fox-shaped model: aabb_scale 4, exponential stepping, 3 cascades; 3840 x 2160 over 8 ranks),
     rehearsed on one GPU: every rank's tile-packed share rendered in turn, assembled the way the gather does, equals the frame one
