@@ -228,3 +228,40 @@ def test_multi_device_context(native, scene_mod, scene_freq, gpu_ctx):
     finally:
         multi.close()
         single.close()
+
+
+def test_envmap_moving_camera_and_lens(ctx, oracle, native, scene_mod, scene_freq):
+    """what sits around the network in the base kernel sits around this one too: an environment map behind the NeRF (1 spp direct
+    output and 2 spp through accumulate + tonemap), a camera that moves within the frame with a rolling shutter, and a lens
+    (OpenCV distortion) -- against the oracle"""
+    ctx.set_model(scene_freq)
+    m = oracle.make_model(scene_freq)
+    rng = np.random.default_rng(12)
+    env = np.zeros((16, 32, 4), np.float32)
+    env[..., :3] = rng.uniform(0, 1, (16, 32, 3))
+    env[..., 3] = rng.uniform(0.5, 1.0, (16, 32))
+    env[..., :3] *= env[..., 3:4]
+    w, h = 96, 54
+    focal = scene_mod.focal_from_fov_x(w, 1.0)
+    m0, m1 = scene_mod.orbit_camera(250.0, 10.0, 2.6), scene_mod.orbit_camera(262.0, 14.0, 2.8)
+    lens = dict(lens_mode=native.LENS_OPENCV, lens_params=(0.1, -0.05, 0.01, -0.02)) if hasattr(native, "LENS_OPENCV") else {}
+    try:
+        ctx.set_envmap(env)
+        for spp in (1, 2):
+            kw = dict(background=(0.1, 0.2, 0.3, 1.0), exposure=0.25, to_srgb=True)
+            cam_kw = dict(snap=(spp == 1), matrix1_3x4=m1, rolling_shutter=(0.0, 0.0, 0.3, 0.7))
+            img = ctx.render(native.make_camera(m0, w, h, focal, **cam_kw, **lens), native.make_opts(spp=spp, **kw))
+            acc = np.zeros((w * h, 4), np.float32)
+            for s in range(spp):
+                okw = dict(spp_index=s, snap=(spp == 1), matrix1_4x3=m1, rolling_shutter=(0.0, 0.0, 0.3, 0.7))
+                if lens:
+                    okw.update(lens_mode=1, lens_params=lens["lens_params"])
+                fb, _, ost = oracle.render_nerf(m, oracle.make_camera(m0, w, h, focal, **okw), oracle.make_opts(envmap=env))
+                acc = oracle.accumulate(fb.reshape(-1, 4), acc, s)
+            ref = oracle.tonemap(acc, kw["background"], kw["exposure"], kw["to_srgb"]).reshape(h, w, 4)
+            assert ost["n_rays_hit"] > 300
+            assert psnr(img[..., :3], ref[..., :3]) > 45.0
+            assert (np.abs(img - ref).max(-1) < 2e-2).mean() > 0.995
+    finally:
+        ctx.set_envmap(None)
+        oracle.release(m)
