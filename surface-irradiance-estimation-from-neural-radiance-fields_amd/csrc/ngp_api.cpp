@@ -328,9 +328,9 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	if (!wide && d.dir_encoding != 0) throw std::runtime_error("unsupported network architecture: a Frequency direction encoding is implemented together with a Frequency position encoding (configs/nerf/frequency.json)");
 	if (wide) {
 		if ((d.n_neurons != 128 && d.n_neurons != 256) || d.n_hidden_density < 1 || d.n_hidden_rgb < 1 || d.n_hidden_density + d.n_hidden_rgb + 2 > (uint32_t)WIDE_MAX_LAYERS ||
-		    d.density_out_dims != 16 || d.pos_n_frequencies < 1 || d.pos_n_frequencies > 40 || (d.dir_encoding == 1 && (d.dir_n_frequencies < 1 || d.dir_n_frequencies > 5))) {
+		    d.density_out_dims != 16 || d.pos_n_frequencies < 1 || d.pos_n_frequencies > 40 || (d.dir_encoding == 1 && (d.dir_n_frequencies < 1 || d.dir_n_frequencies > 4))) {
 			throw std::runtime_error("unsupported network architecture: with a Frequency position encoding (configs/nerf/frequency.json) the HIP path implements MLPs of 128 or 256 "
-			                         "neurons with 1 or more hidden layers, a 16-wide density output, up to 40 position and 5 direction frequencies");
+			                         "neurons with 1 or more hidden layers, a 16-wide density output, up to 40 position and 4 direction frequencies");
 		}
 	} else
 	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density != 1 ||

@@ -4,9 +4,10 @@
 // src/testbed_nerf.cu:2056-2138 chain, with every layer a cutlass GEMM launch).
 //
 // One persistent kernel per sample-per-pixel, like the base.json kernel (nerf_kernels.hip), but organised around the GEMMs that
-// now dominate (0.87 MFLOP per sample, 42x base.json's). A workgroup of 4 waves owns 128 ray slots (threads 0..127): every round
-// each live slot marches to its next sample, the workgroup runs the network on the 128 samples with the activations resident in
-// LDS, and each slot composites its own sample. TWO workgroups share a CU (80 KB of LDS each, 2 waves per SIMD): while one
+// now dominate (0.87 MFLOP per sample, 42x base.json's). A workgroup of 4 waves owns 256 ray slots, one per thread: every round
+// each live slot marches to its next sample, the workgroup runs the network on 128 of the waiting samples (those that waited
+// before go first) with the activations resident in LDS, and each slot composites its own sample: twice as many slots as rows
+// keep the rows full. TWO workgroups share a CU (80 KB of LDS each, 2 waves per SIMD): while one
 // marches, evaluates sines or exchanges activations, the other one's MFMAs run -- the phases of one workgroup are serial, and
 // with one workgroup per CU the matrix pipe idled through all but the GEMM phase. Rays never leave registers; the only HBM
 // traffic is occupancy bits, the weight fragments (868 KB, L2-resident) and one frame-buffer write per pixel.
@@ -32,20 +33,23 @@
 
 namespace ngp {
 
-constexpr int WBLOCK = 256;    // threads of a workgroup
-constexpr int ROWS = 128;      // ray slots = samples per round
-constexpr int XS = 264;        // halves per activation row
-constexpr int DIR_STRIDE = 32; // halves per direction-encoding row
+constexpr int WBLOCK = 256;    // threads of a workgroup = ray slots
+constexpr int ROWS = 128;      // samples per round: the first 128 slots (waiting ones first) that hold a sample
+constexpr int XS = 264;        // halves per activation row: 256 + 8 of padding, which also carries the row's position / outputs (row_meta)
+constexpr int DIR_STRIDE = 24; // halves per direction-encoding row (4 frequencies x 3 x 2, or 16 SH coefficients)
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct WideShared {
 	half_t x[ROWS * XS];
-	half_t dir[ROWS * DIR_STRIDE];         // per ray slot: the encoded direction, constant along the ray
-	float4 pos[ROWS];                      // the slot's sample position (w != 0: there is one) for the threads that encode it
-	uint2 out[ROWS];                       // rgb of the slot's sample
+	half_t dir[WBLOCK * DIR_STRIDE];       // per ray slot: the encoded direction, constant along the ray
+	uint16_t owner[ROWS];                  // the slot whose sample a row carries this round
+	uint32_t cnt[8];                       // per wave: waiting / new samples (the round's selection)
 	uint32_t coarse16[NERF_CASCADES * 16]; // per cascade: which 16^3-cell blocks of the occupancy grid hold anything (ModelParams::coarse, tail)
 	unsigned long long prof[8];            // diagnostic (NGP_PROFILE_SECTIONS=1): the workgroup's section sums, kept here rather than in registers
 };
+// the 16 bytes behind a row's 256 activations: before the network the sample's position (x, y, z, 1; w = 0: the row is empty), after
+// it the sample's rgb outputs
+NGP_DEV float4* row_meta(WideShared& S, int row) { return (float4*)(S.x + row * XS + 256); }
 static_assert(2 * sizeof(WideShared) <= 160 * 1024, "two workgroups per CU");
 
 // The march's occupancy lookup (cf. empty_block_size_at, nerf_device.h): 0 = the cell is occupied, else the side (in cells of this
@@ -247,9 +251,9 @@ NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[4][MT], int t
 // NerfNetwork::inference_mixed_precision_impl (nerf_network.h:105-139) for the workgroup's 128 sample rows. On entry row r of
 // S.x holds the position encoding of slot r's sample (zeros beyond it up to the first layer's K) and S.dir its direction
 // encoding, both visible (the caller has passed a barrier), and the first layer's fragments have been requested
-// (wide_network_prefetch); on exit threads 0..127 have their slot's outputs and X may be overwritten.
+// (wide_network_prefetch); on exit the thread that owns row `my_row` (-1: none) has its outputs and X may be overwritten.
 template <int MT>
-NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[4][MT]) {
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[4][MT], int my_row) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
 	const int row_id = tid & (ROWS - 1), part = tid >> 7;
@@ -273,9 +277,10 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 			lds_barrier();
 			// [density out | direction encoding | ones up to the network's input alignment | zeros up to the next layer's K]; two threads per row
 			half_t* row = S.x + row_id * XS;
+			if (my_row >= 0) o.sigma = S.x[my_row * XS];
 			if (part == 0) {
-				o.sigma = row[0];
-				for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(S.dir + row_id * DIR_STRIDE + c);
+				const half_t* d = S.dir + (int)S.owner[row_id] * DIR_STRIDE;
+				for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(d + c);
 			} else {
 				const uint32_t k_end = 16u * W.layers[l + 1u].n_kblocks;
 				for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
@@ -286,11 +291,13 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 			}
 			lds_barrier();
 		} else {
-			if (h == 0) S.out[32 * wave + n] = pack4(acc[0], acc[1], acc[2], 0.f, false);
+			if (h == 0) *(uint2*)row_meta(S, 32 * wave + n) = pack4(acc[0], acc[1], acc[2], 0.f, false);
 			lds_barrier();
-			union { uint2 u; half_t hh[4]; } r;
-			r.u = S.out[row_id];
-			o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
+			if (my_row >= 0) {
+				union { uint2 u; half_t hh[4]; } r;
+				r.u = *(const uint2*)row_meta(S, my_row);
+				o.r = r.hh[0]; o.g = r.hh[1]; o.b = r.hh[2];
+			}
 		}
 	}
 	return o;
@@ -306,7 +313,7 @@ NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int slot, f3 d)
 // the position encodings of the round's samples: row r by threads r (low frequencies) and r + 128 (high frequencies, padding)
 NGP_DEV void encode_positions(const WideModel& W, WideShared& S, int tid) {
 	const int row = tid & (ROWS - 1), part = tid >> 7;
-	const float4 p = S.pos[row];
+	const float4 p = *row_meta(S, row);
 	if (p.w == 0.0f) return;
 	const uint32_t split = (W.pos_freqs + 1u) / 2u;
 	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, 16u * W.layers[0].n_kblocks);
@@ -343,8 +350,8 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	f3 idir = mk3(0.f, 0.f, 0.f);
 	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint32_t step = 1, skip_i = 1;
-	// threads 128..255 (waves 2, 3) own no ray slot: they take part in the encodings and the GEMMs only
-	bool ready = false, counted = false, finished = false, exhausted = tid >= ROWS;
+	bool ready = false, counted = false, finished = false, exhausted = false;
+	bool held = false; // ready, but the round's 128 rows went to others: first in line next round
 	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0;
 	int stall = 0;
@@ -496,30 +503,57 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		}
 		n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
 
-		// ---- workgroup decision: run the network once most slots hold a sample or nothing else can fill them
-		const int n_ready = __syncthreads_count(ready);
+		// ---- workgroup decision: run the network once (nearly) a round's worth of samples waits or nothing else can add to them
+		const int wave_id = tid >> 6;
+		const unsigned long long held_mask = __ballot(ready && held), new_mask = __ballot(ready && !held);
+		if (lane == 0) {
+			S.cnt[wave_id] = (uint32_t)__popcll(held_mask);
+			S.cnt[4 + wave_id] = (uint32_t)__popcll(new_mask);
+		}
 		const int n_progress = __syncthreads_count((ray.alive && !ready) || finished || (!ray.alive && !exhausted));
+		uint32_t held_before = 0, new_before = 0, held_total = 0, new_total = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t hc = S.cnt[k], nc = S.cnt[4 + k];
+			if (k < wave_id) { held_before += hc; new_before += nc; }
+			held_total += hc;
+			new_total += nc;
+		}
+		const int n_ready = (int)(held_total + new_total);
 		if (prof) lap(1);
 		if (n_ready == 0) {
 			if (n_progress == 0) break;
+			__syncthreads(); // (S.cnt is rewritten next round)
 			continue;
 		}
 		if (n_ready < F.tune[2] && n_progress > 0 && stall < F.tune[3]) {
 			++stall;
+			__syncthreads();
 			continue;
 		}
 		stall = 0;
 
-		// ---- K5: position encoding into the slot's row, then the network on the whole block
-		const bool run = ready;
-		if (tid < ROWS) S.pos[tid] = make_float4(wx, wy, wz, run ? 1.0f : 0.0f);
+		// ---- the round's rows: samples that waited go first, then new ones in slot order
+		const uint32_t rank = (ready && held) ? held_before + lanes_below(held_mask) : held_total + new_before + lanes_below(new_mask);
+		const bool run = ready && rank < (uint32_t)ROWS;
+		const int my_row = run ? (int)rank : -1;
+		held = ready && !run;
+		// ---- K5: positions to the rows, encodings by thread pairs, then the network on the whole block
+		if (run) {
+			*row_meta(S, my_row) = make_float4(wx, wy, wz, 1.0f);
+			S.owner[my_row] = (uint16_t)tid;
+		}
+		if (tid < ROWS && tid >= n_ready) {
+			*row_meta(S, tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+			S.owner[tid] = 0;
+		}
 		u32x4 ar[4][MT];
 		wide_network_prefetch<MT>(W, ar, tid); // the first layer's weights travel while the sines are computed
 		lds_barrier();
 		encode_positions(W, S, tid);
 		lds_barrier();
-		if (prof) { lap(3); S.prof[5] += 1ull; S.prof[7] += (unsigned long long)n_ready; }
-		const WideOut o = wide_network<MT>(W, S, tid, ar);
+		if (prof) { lap(3); S.prof[5] += 1ull; S.prof[7] += (unsigned long long)(n_ready < ROWS ? n_ready : ROWS); }
+		const WideOut o = wide_network<MT>(W, S, tid, ar, my_row);
 		if (prof) lap(2);
 
 		// ---- K6: composite_kernel_nerf (:569-726)
@@ -601,8 +635,9 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 		const bool run = i < n;
 		u32x4 ar[4][MT];
 		wide_network_prefetch<MT>(W, ar, tid);
-		if (part == 0) {
-			S.pos[row] = run ? make_float4(pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+		if (part == 0) { // row r carries sample base + r; its direction sits in slot r
+			*row_meta(S, row) = run ? make_float4(pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+			S.owner[row] = (uint16_t)row;
 		} else if (run) {
 			half_t* d = S.dir + row * DIR_STRIDE;
 			if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d, 0u, W.dir_freqs, true);
@@ -611,7 +646,7 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 		lds_barrier();
 		encode_positions(W, S, tid);
 		lds_barrier();
-		const WideOut o = wide_network<MT>(W, S, tid, ar);
+		const WideOut o = wide_network<MT>(W, S, tid, ar, (run && part == 0) ? row : -1);
 		if (run && part == 0) {
 			union { half_t h[4]; uint2 u; } p;
 			p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
@@ -642,15 +677,15 @@ static int wide_blocks_per_cu(K kernel) {
 	return n;
 }
 // The round's schedule (FrameParams::tune as this kernel reads it; of ngp_set_schedule's knobs only block_jumps applies here):
-// [1] voxel steps a marching slot may take per round, [2] run the network once this many of the 128 slots hold a sample ...
+// [1] voxel steps a marching slot may take per round, [2] run the network once this many samples wait (of the 128 a round takes) ...
 // [3] ... or after this many extra march rounds. WIDE_TUNE="steps,go,stall" overrides the defaults (experiments).
 static void wide_schedule(FrameParams& G) {
 	static const struct T { int v[3]; } t = []() {
-		T r = {{16, 96, 1}};
+		T r = {{4, 128, 2}};
 		if (const char* e = getenv("WIDE_TUNE")) (void)sscanf(e, "%d,%d,%d", &r.v[0], &r.v[1], &r.v[2]);
-		if (r.v[0] < 1 || r.v[0] > 1024) r.v[0] = 16;
-		if (r.v[1] < 1 || r.v[1] > ROWS) r.v[1] = 96;
-		if (r.v[2] < 0 || r.v[2] > 64) r.v[2] = 1;
+		if (r.v[0] < 1 || r.v[0] > 1024) r.v[0] = 4;
+		if (r.v[1] < 1 || r.v[1] > ROWS) r.v[1] = 128;
+		if (r.v[2] < 0 || r.v[2] > 64) r.v[2] = 2;
 		return r;
 	}();
 	G.tune[1] = t.v[0];
@@ -660,7 +695,7 @@ static void wide_schedule(FrameParams& G) {
 static int wide_blocks(const FrameParams& F, int n_cus, int per_cu) {
 	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
 	int n_blocks = n_cus * per_cu;
-	const int needed = (int)((F.n_local_tiles + 1) / 2); // 128 ray slots = two 8x8 tiles per workgroup
+	const int needed = (int)((F.n_local_tiles + 3) / 4); // 256 ray slots = four 8x8 tiles per workgroup
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	return n_blocks;
 }
