@@ -18,7 +18,7 @@
 //                width / 4 neurons (2 M-tiles for 256) and all four 32-sample tiles: 8 accumulator tiles = 128 fp32 registers,
 //                every B read feeds two MFMAs (LDS at half its rate when the MFMA pipe is full)
 //   A operand    MFMA fragments prepared by the host (ngp_kernels.h WideModel), 16 B per lane, coalesced from L2, streamed through
-//                a ring of 4 K-blocks that runs 3 blocks (768 MFMA cycles) ahead of its use and on into the next layer
+//                a ring of 3 K-blocks that runs 2 blocks (512 MFMA cycles) ahead of its use and on into the next layer
 //   B operand    ds_read_b128 of X[sample][16 kb + 8 h ..], read one K-block ahead into a second register set
 //   output tile  lane (n, h) holds neurons 8q + 4h + r of sample n: four 8-byte LDS writes per tile put them back in row n
 //   encodings    the sines of a sample are split over two threads (tid and tid + 128): all four waves work through them
@@ -136,11 +136,15 @@ NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
 	return make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
-// The weights stream: a wave's MFMA A fragments of K-block kb sit in ring stage kb & 3, requested three K-blocks (24 MFMAs) before
-// their use; the ring runs on into the next layer (its first three blocks are requested while this layer's outputs are packed and
+// The weights stream: a wave's MFMA A fragments of K-block kb sit in ring stage kb % RING, requested RING - 1 K-blocks (16 MFMAs) before
+// their use; the ring runs on into the next layer (its first blocks are requested while this layer's outputs are packed and
 // exchanged). The barriers inside the network wait for LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads()
 // would also drain the outstanding global loads, i.e. the stream.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef WIDE_RING
+#define WIDE_RING 3
+#endif
+constexpr int RING = WIDE_RING, AHEAD = RING - 1; // stages of the weight ring, K-blocks it runs ahead
 NGP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 NGP_DEV half8 as_half8(u32x4 u) { return __builtin_bit_cast(half8, u); }
 
@@ -149,9 +153,9 @@ struct LayerFrags { // where this wave's fragments of a layer start (lane includ
 	int nkb, mt;
 };
 template <int MT>
-NGP_DEV void ring_preload(u32x4 (&ar)[4][MT], LayerFrags L) {
+NGP_DEV void ring_preload(u32x4 (&ar)[RING][MT], LayerFrags L) {
 #pragma unroll
-	for (int st = 0; st < 3; ++st)
+	for (int st = 0; st < AHEAD; ++st)
 #pragma unroll
 		for (int m = 0; m < MT; ++m)
 			if (m < L.mt) ar[st][m] = *(const u32x4*)(L.base + ((size_t)m * L.nkb + st) * 64);
@@ -159,7 +163,7 @@ NGP_DEV void ring_preload(u32x4 (&ar)[4][MT], LayerFrags L) {
 
 // One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)); ring stages 0..2 hold (or await) K-blocks 0..2.
 template <int MT, int NKB>
-NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[4][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
+NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
 	const int n = lane & 31, h = lane >> 5;
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	floatx16 acc[MT][4];
@@ -169,9 +173,9 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[4][MT], const uint4* __res
 	for (int t = 0; t < 4; ++t) b[0][t] = *(const half8*)(col + 32 * t * XS);
 #pragma unroll
 	for (int kb = 0; kb < NKB; ++kb) {
-		if (kb + 3 < NKB) {
+		if (kb + AHEAD < NKB) {
 #pragma unroll
-			for (int m = 0; m < MT; ++m) ar[(kb + 3) & 3][m] = *(const u32x4*)(wf + ((size_t)m * NKB + kb + 3) * 64);
+			for (int m = 0; m < MT; ++m) ar[(kb + AHEAD) % RING][m] = *(const u32x4*)(wf + ((size_t)m * NKB + kb + AHEAD) * 64);
 		}
 		if (kb + 1 < NKB) {
 #pragma unroll
@@ -181,7 +185,7 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[4][MT], const uint4* __res
 #pragma unroll
 		for (int t = 0; t < 4; ++t)
 #pragma unroll
-			for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(ar[kb & 3][m]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
+			for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(ar[kb % RING][m]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	ring_preload<MT>(ar, next);
@@ -206,7 +210,7 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[4][MT], const uint4* __res
 
 // An output layer (at most 32 neurons, no activation): wave w computes its own sample tile w; fragments in ar[.][0]
 template <int MT, int NKB>
-NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[4][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
+NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
 	const int n = lane & 31, h = lane >> 5;
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	floatx16 acc = zero;
@@ -215,10 +219,10 @@ NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[4][MT], const uint4
 	b[0] = *(const half8*)col;
 #pragma unroll
 	for (int kb = 0; kb < NKB; ++kb) {
-		if (kb + 3 < NKB) ar[(kb + 3) & 3][0] = *(const u32x4*)(wf + (size_t)(kb + 3) * 64);
+		if (kb + AHEAD < NKB) ar[(kb + AHEAD) % RING][0] = *(const u32x4*)(wf + (size_t)(kb + AHEAD) * 64);
 		if (kb + 1 < NKB) b[(kb + 1) & 1] = *(const half8*)(col + 16 * (kb + 1));
 		__builtin_amdgcn_sched_barrier(0);
-		acc = mfma32(as_half8(ar[kb & 3][0]), b[kb & 1], acc);
+		acc = mfma32(as_half8(ar[kb % RING][0]), b[kb & 1], acc);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	ring_preload<MT>(ar, next);
@@ -244,7 +248,7 @@ NGP_DEV LayerFrags layer_frags(const WideModel& W, uint32_t l, int wave, int lan
 	return L;
 }
 template <int MT>
-NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[4][MT], int tid) {
+NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[RING][MT], int tid) {
 	ring_preload<MT>(ar, layer_frags<MT>(W, 0, tid >> 6, tid & 63));
 }
 
@@ -253,7 +257,7 @@ NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[4][MT], int t
 // encoding, both visible (the caller has passed a barrier), and the first layer's fragments have been requested
 // (wide_network_prefetch); on exit the thread that owns row `my_row` (-1: none) has its outputs and X may be overwritten.
 template <int MT>
-NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[4][MT], int my_row) {
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[RING][MT], int my_row) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
 	const int row_id = tid & (ROWS - 1), part = tid >> 7;
@@ -547,7 +551,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			*row_meta(S, tid) = make_float4(0.f, 0.f, 0.f, 0.f);
 			S.owner[tid] = 0;
 		}
-		u32x4 ar[4][MT];
+		u32x4 ar[RING][MT];
 		wide_network_prefetch<MT>(W, ar, tid); // the first layer's weights travel while the sines are computed
 		lds_barrier();
 		encode_positions(W, S, tid);
@@ -633,7 +637,7 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 	for (uint32_t base = blockIdx.x * ROWS; base < n; base += gridDim.x * ROWS) { // (workgroup-uniform trip count)
 		const uint32_t i = base + (uint32_t)row;
 		const bool run = i < n;
-		u32x4 ar[4][MT];
+		u32x4 ar[RING][MT];
 		wide_network_prefetch<MT>(W, ar, tid);
 		if (part == 0) { // row r carries sample base + r; its direction sits in slot r
 			*row_meta(S, row) = run ? make_float4(pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
