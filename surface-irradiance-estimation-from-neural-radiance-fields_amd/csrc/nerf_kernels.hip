@@ -122,7 +122,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			n_hit += (uint32_t)__popcll(__ballot(hit));
 		}
 		if (!exhausted && n_dead >= (F.tune[0] > 16 ? F.tune[0] : 16)) {
-			// the queue deals 8x2-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
+			// the queue deals 4x4-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
 			// them, so the last units of a frame (or of a rank's share of it) are small and the waves end together
 			const uint32_t want = (uint32_t)n_dead >> 4, n_strips = F.n_local_tiles * 4u;
 			uint32_t first = 0;
@@ -135,7 +135,10 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				const uint32_t r = lanes_below(dead_mask);
 				const uint32_t strip = first + (r >> 4);
 				const bool take = !ray.alive && r < got * 16u;
-				const uint32_t tile_local = strip >> 2, slot = (strip & 3u) * 16u + (r & 15u);
+				// a strip is a 4 x 4 quarter of the tile (16 neighbouring rays share more hash-grid lines than two rows of 8: +1 %);
+				// slot = the pixel's index y * 8 + x in the tile
+				const uint32_t tile_local = strip >> 2, s4 = strip & 3u, i16 = r & 15u;
+				const uint32_t slot = ((s4 >> 1) * 4u + (i16 >> 2)) * 8u + (s4 & 1u) * 4u + (i16 & 3u);
 				const uint32_t tile = F.shard_index + F.shard_count * tile_local;
 				bool fresh = false;
 				if (PROBE) {

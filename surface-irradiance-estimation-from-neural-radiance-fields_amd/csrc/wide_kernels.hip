@@ -394,7 +394,8 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 				const uint32_t r = lanes_below(dead_mask);
 				const uint32_t strip = first + (r >> 4);
 				const bool take = !ray.alive && r < got * 16u;
-				const uint32_t tile_local = strip >> 2, slot = (strip & 3u) * 16u + (r & 15u);
+				const uint32_t tile_local = strip >> 2, s4 = strip & 3u, i16 = r & 15u; // a strip = a 4 x 4 quarter of the tile
+				const uint32_t slot = ((s4 >> 1) * 4u + (i16 >> 2)) * 8u + (s4 & 1u) * 4u + (i16 & 3u);
 				const uint32_t tile = F.shard_index + F.shard_count * tile_local;
 				bool fresh = false;
 				if (PROBE) {
