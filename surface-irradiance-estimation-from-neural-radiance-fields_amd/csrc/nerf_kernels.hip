@@ -94,6 +94,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 
 	// wave-uniform tile reservoir
 	bool exhausted = false;
+	uint32_t qsel = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
 	int stall = 0;
 	uint32_t n_alive_init = 0, n_hit = 0, n_samples = 0; // wave-uniform (ballot counts)
 	unsigned long long p_skip[3] = {0, 0, 0};
@@ -125,13 +126,30 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			// the queue deals 4x4-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
 			// them, so the last units of a frame (or of a rank's share of it) are small and the waves end together
 			const uint32_t want = (uint32_t)n_dead >> 4, n_strips = F.n_local_tiles * 4u;
-			uint32_t first = 0;
-			if (lane == 0) first = atomicAdd(F.queue, want);
-			first = __builtin_amdgcn_readfirstlane(first);
-			if (first >= n_strips) {
+			uint32_t first = 0, limit = n_strips;
+			if (!PROBE && F.xqueue) {
+				// one queue per XCD over an eighth of the share's tiles (a band of the image): the workgroups of an XCD march through
+				// neighbouring tiles and share their hash-grid lines in that XCD's L2; a wave whose band is dealt out moves on to the next
+				// XCD's (and stays there), so the bands need not be equally heavy
+				for (int tries = 0; tries < 8; ++tries) {
+					const uint32_t lo = (uint32_t)(((unsigned long long)n_strips * qsel) >> 3), hi = (uint32_t)(((unsigned long long)n_strips * (qsel + 1u)) >> 3);
+					uint32_t off = 0;
+					if (lane == 0) off = atomicAdd(F.xqueue + qsel, want);
+					off = __builtin_amdgcn_readfirstlane(off);
+					first = lo + off;
+					limit = hi;
+					if (off < hi - lo) break;
+					first = limit = n_strips; // (nothing here)
+					qsel = (qsel + 1u) & 7u;
+				}
+			} else {
+				if (lane == 0) first = atomicAdd(F.queue, want);
+				first = __builtin_amdgcn_readfirstlane(first);
+			}
+			if (first >= limit) {
 				exhausted = true;
 			} else {
-				const uint32_t got = n_strips - first < want ? n_strips - first : want;
+				const uint32_t got = limit - first < want ? limit - first : want;
 				const uint32_t r = lanes_below(dead_mask);
 				const uint32_t strip = first + (r >> 4);
 				const bool take = !ray.alive && r < got * 16u;

@@ -1145,6 +1145,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.depth_buffer = d_depth_out ? d_depth_out : ctx->d_depth;
 	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
 	ctx->bind_slot(F, slot); // every call has its own queue word and counters: frames on different streams may overlap
+	if (shard_count > 1) F.xqueue = nullptr; // per-XCD bands pay for a whole frame (+1.4 %); a rank's interleaved share is too small for them (N = 4: -3 %, N = 8: -6 %)
 	F.tiles_x = (uint32_t)(cam.width + 7) / 8;
 	F.tiles_y = (uint32_t)(cam.height + 7) / 8;
 	const uint32_t n_tiles = F.tiles_x * F.tiles_y;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <sys/stat.h>
@@ -236,6 +237,8 @@ struct ngp_ctx {
 		F.done = F.queue + 1;
 		F.results = w + 4;
 		F.add_results = 0;
+		static const bool xcd_queues = []() { const char* e = getenv("NGP_XCD_QUEUES"); return !e || atoi(e) != 0; }(); // 0: one queue (A/B)
+		F.xqueue = xcd_queues ? (uint32_t*)(w + 9) : nullptr; // bytes 72..103 of the 128-byte slot
 	}
 	hipEvent_t ev_frame0[HISTORY] = {}, ev_frame1[HISTORY] = {}, ev_kern0[HISTORY] = {}, ev_kern1[HISTORY] = {};
 	uint64_t hist_n_rays[HISTORY] = {};

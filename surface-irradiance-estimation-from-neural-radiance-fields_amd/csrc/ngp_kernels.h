@@ -120,6 +120,7 @@ struct FrameParams {
 	float4* frame_buffer;
 	float* depth_buffer;
 	uint32_t* queue;               // [0]: next strip (quarter tile) of this rank's share
+	uint32_t* xqueue;              // [0..7]: one queue per XCD over an eighth of the share each (nullptr: the single queue); nerf_kernels.hip
 	unsigned long long* counters;  // [0] alive after init, [1] hit, [2] samples: accumulators of the launch; its last wave moves them to `results` and leaves the slot zeroed
 	unsigned long long* results;   // [0..2]: what ngp_get_render_stats reads; [3] the launch(es) in ticks of the 100 MHz device clock; [4] scratch (start stamp, left zero)
 	uint32_t* done;                // waves of this launch that have left

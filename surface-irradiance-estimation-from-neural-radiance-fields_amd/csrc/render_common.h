@@ -192,6 +192,10 @@ NGP_DEV void finish_launch(const FrameParams& F, int lane, uint32_t n_alive_init
 			const unsigned long long t_start = ~atomicExch(&F.results[4], 0ull), ticks = realtime() - t_start;
 			F.results[3] = F.add_results ? F.results[3] + ticks : ticks;
 			atomicExch(F.queue, 0u);
+			if (F.xqueue) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) atomicExch(F.xqueue + k, 0u);
+			}
 			atomicExch(F.done, 0u);
 		}
 	}
