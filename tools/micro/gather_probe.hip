@@ -58,7 +58,7 @@ void run(const char* name, void* d_table, size_t table_bytes, int blocks, uint32
 	CHECK(hipEventElapsedTime(&ms, a, b));
 	double loads = (double)blocks * 256.0 * iters * UNROLL;
 	double per_clk_cu = loads / (ms * 1e-3 * 2.4e9 * 256.0);
-	printf("%-34s table %9.3f MB blocks %4d: %8.3f ms  %7.1f Glane-loads/s  %5.2f lane-loads/clk/CU (2.4 GHz)  %6.0f GB/s useful\n", name,
+	printf("%-34s table %10.4f MB blocks %4d: %8.3f ms  %7.1f Glane-loads/s  %5.2f lane-loads/clk/CU (2.4 GHz)  %6.0f GB/s useful\n", name,
 	       table_bytes / 1048576.0, blocks, ms, loads / ms * 1e-6, per_clk_cu, loads * sizeof(T) / ms * 1e-6);
 }
 
@@ -69,9 +69,9 @@ int main() {
 	CHECK(hipMalloc(&d_table, max_bytes));
 	CHECK(hipMemset(d_table, 1, max_bytes));
 	CHECK(hipMalloc(&d_out, 4));
-	size_t sizes[] = {16ull << 10, 1ull << 20, 32ull << 20};
+	size_t sizes[] = {256ull, 1ull << 10, 2ull << 10, 4ull << 10, 8ull << 10, 16ull << 10, 1ull << 20, 32ull << 20}; // 4 lines (every lane shares one), L1-resident, L2-resident, beyond L2
 	for (size_t sz : sizes) {
-		for (int blocks : {512}) {
+		for (int blocks : {512, 2048}) {
 			run<uint32_t, 16, 0>("4 B random, 16 in flight", d_table, sz, blocks, d_out);
 			run<uint2, 16, 0>("8 B random, 16 in flight", d_table, sz, blocks, d_out);
 			run<uint2, 32, 0>("8 B random, 32 in flight", d_table, sz, blocks, d_out);
