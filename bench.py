@@ -32,8 +32,8 @@ BYTES_PER_SAMPLE = 512.0  # 8 levels x 8 corners x 8 B of hash-grid
 BYTES_PER_RAY = 80.0  # payload/rgba/depth once + frame-buffer scatter
 FLOP_PER_SAMPLE = 20480.0  # both MLPs
 # What binds the fused kernel is the CU's texture-address / vector-L1 path, which is paced by LANE-loads, not bytes
-# (profiles/r2_v3_pmc_l1.json; tools/micro/gather_probe.hip: a CU sustains at most 1.92 scattered lane-loads per clock from its
-# L1 whether a lane asks for 4, 8 or 16 bytes). The kernel's gathers are 8-byte lane-loads, 64 per sample = the 512
+# (profiles/r2_*_pmc_l1.json; tools/micro/gather_probe.hip, output profiles/r2_gather_probe.txt: a CU sustains 1.92-1.93 scattered
+# lane-loads per clock when every one hits its L1 -- 8 KB table -- whether a lane asks for 4, 8 or 16 bytes). The kernel's gathers are 8-byte lane-loads, 64 per sample = the 512
 # algorithmic bytes, so that ceiling, in the same unit as the algorithmic figure, is
 GATHER_PEAK_GBS = 1.92 * 8.0 * 256 * 2.4  # lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz = 9437 GB/s
 
@@ -360,7 +360,7 @@ def main():
             "kernel_ms_how": ("HIP events around launches issued one at a time (%d frames after the timed region)" % solo["n"]) if solo else "device clock, timed region (launches of consecutive frames overlap)",
             "kernel_ms_timed_region_device_clock": round(k_ms_timed, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
-            "peak_is": "measured L1 gather ceiling for 8-byte lane-loads (tools/micro/gather_probe.hip): 1.92 lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz",
+            "peak_is": "measured L1 gather ceiling for 8-byte lane-loads (tools/micro/gather_probe.hip, profiles/r2_gather_probe.txt): 1.92 lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz",
             "hbm_algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),  # SURVEY 8(d)'s figure: algorithmic bytes against the 8 TB/s HBM peak
             "hbm_traffic_frac": round(ev["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ev.get("traffic") else None,
             "mfma_tflops": round(mfma_tflops, 3),
