@@ -1,0 +1,30 @@
+"""Throughput of a full frame of 1/8 of the 1080p pixel count (680x382, same camera, adjacent tiles) against an interleaved 1/8 share
+of the 1080p frame: is a share slow because its tiles are scattered (no hash-grid lines shared between neighbours)?"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+PKG = "surface-irradiance-estimation-from-neural-radiance-fields_amd"
+native, synthetic, scene = (importlib.import_module(PKG + "." + m) for m in ("native", "synthetic", "scene"))
+torch.zeros(1, device="cuda")
+sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)
+ctx = native.Context(0)
+ctx.set_model(sc)
+k = int(os.environ.get("K", 6))
+streams = [torch.cuda.Stream() for _ in range(k)]
+for (w, h, shards) in ((680, 382, 1), (1920, 1080, 8)):
+    cams = [native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(w, 0.6911)) for az in (0, 45, 90, 135, 180, 225, 270, 315)]
+    bufs = [(torch.zeros((h, w, 4), device="cuda"), torch.zeros((h, w), device="cuda")) for _ in range(k)]
+    opts = native.make_opts(shard_index=0, shard_count=shards, packed_output=shards > 1)
+    def go(i):
+        ctx.render_device(cams[i % 8], opts, bufs[i % k][0].data_ptr(), bufs[i % k][1].data_ptr(), streams[i % k].cuda_stream)
+    for i in range(16):
+        go(i)
+    torch.cuda.synchronize()
+    n = 64
+    t0 = time.perf_counter()
+    for i in range(n):
+        go(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    st = ctx.render_stats()
+    print(f"{w}x{h} shards {shards}: {dt * 1e3:.4f} ms/frame, {st['n_rays']} rays, {st['n_samples']} samples -> {st['n_samples'] / dt / 1e9:.2f} Gsamples/s")
