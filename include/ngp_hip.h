@@ -241,6 +241,12 @@ NGP_API int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out);
  * as if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494) does. Out-of-range values are refused (they would
  * hang the kernel). No counterpart in the reference; the environment variable NGP_TUNE sets the same list at ngp_create. */
 NGP_API int ngp_set_schedule(ngp_ctx* ctx, const int32_t* knobs, int n);
+/* Diagnostic, no counterpart in the reference: with NGP_PROFILE_SECTIONS=1|2 and NGP_PROFILE_TRACE=<stride> in the environment the render
+ * kernel's stamped twin records the timeline of every stride-th wave that was dealt rays (one record per loop round: s_memtime at the
+ * top of the round and after refill / march / network / composite, what the round carried). Copies the last frame's trace
+ * (n_words 32-bit words at most; layout: csrc/ngp_kernels.h FrameParams::trace, decoder tools/wave_trace.py); out == NULL only
+ * reports the capacities. */
+NGP_API int ngp_get_profile_trace(ngp_ctx* ctx, uint32_t* out, uint64_t n_words, uint32_t* cap_waves, uint32_t* cap_iters);
 
 /* --- stage entry points (what the reference launches as separate kernels; used by parity tests and tools)
  * K5a tcnn GridEncoding::inference (call site nerf_network.h:113-118): host pos01 n x 3 -> host fp16 n x (L*F) */

@@ -20,6 +20,7 @@ extern "C" {
 #define ORC_MARCH_ITER 10000u /* src/testbed_nerf.cu:46 */
 
 enum { ORC_GRID_ACC_LEGACY = 0, ORC_GRID_ACC_FMA = 1 };
+enum { ORC_MLP_ACC_EXACT = 0, ORC_MLP_ACC_FP16_K16 = 1, ORC_MLP_ACC_IDEAL = 2 };
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LOGISTIC = 2, ORC_ACT_EXPONENTIAL = 3 };
 
 /* Model descriptor: what Testbed::reset_network + load_snapshot leave behind
@@ -61,6 +62,12 @@ typedef struct orc_nerf_model {
 	uint32_t pos_encoding, pos_n_frequencies;
 	uint32_t dir_encoding, dir_n_frequencies;
 	uint32_t mlp_alignment;
+	/* How a layer of the MLPs sums (orc_nerf.c mlp_layer*): ORC_MLP_ACC_EXACT = every dot product exact, rounded to fp32 and then to
+	 * fp16 (the default: what fp32 MFMA accumulators give up to summation order); ORC_MLP_ACC_FP16_K16 = the running sum rounded to
+	 * fp16 after every 16-wide block of the inner dimension -- tcnn FullyFusedMLP's __half accumulator fragments, the reference's
+	 * own arithmetic as far as it can be restated; ORC_MLP_ACC_IDEAL = the whole network (interpolation, encodings, MLPs) in float64
+	 * without any intermediate rounding. EXACT and FP16_K16 bracket the reference; IDEAL is the yardstick both are measured against. */
+	uint32_t mlp_accumulate;
 	/* derived, filled by orc_nerf_prepare */
 	void* prepared;
 } orc_nerf_model;

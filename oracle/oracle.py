@@ -53,6 +53,7 @@ class NerfModel(C.Structure):
         ("pos_encoding", C.c_uint32), ("pos_n_frequencies", C.c_uint32),
         ("dir_encoding", C.c_uint32), ("dir_n_frequencies", C.c_uint32),
         ("mlp_alignment", C.c_uint32),
+        ("mlp_accumulate", C.c_uint32),
         ("prepared", C.c_void_p),
     ]
 
@@ -228,6 +229,8 @@ class Oracle:
         m.density_grid_bitfield = bitfield.ctypes.data
         # corner sum of the grid encoding: "fma" (tvec-era tcnn, what libngp_hip.so ships) or "legacy" (oracle.h)
         m.grid_accumulate = {"legacy": 0, "fma": 1}[scene.get("grid_accumulate", "fma")]
+        # how the MLPs sum: "exact" (default), "fp16_k16" (tcnn FullyFusedMLP's fp16 accumulator fragments) or "ideal" (float64 network); oracle.h
+        m.mlp_accumulate = {"exact": 0, "fp16_k16": 1, "ideal": 2}[scene.get("mlp_accumulate", "exact")]
         m._keep = (params, bitfield)
         rc = self.lib.orc_nerf_prepare(C.byref(m))
         if rc != 0:

@@ -350,20 +350,67 @@ static void mlp_layer(const float* w, uint32_t n_out, uint32_t n_in, const float
 		out_f[o] = orc_half_to_float(h);
 	}
 }
+/* ORC_MLP_ACC_FP16_K16 -- the bracket on the reference's own arithmetic. tcnn's FullyFusedMLP (kernel_mlp_fused and its
+ * threadblock_*layer* helpers; called at nerf_network.h:120,130) keeps every layer's result in
+ * wmma::fragment<wmma::accumulator, 16, 16, 16, __half> and issues one wmma::mma_sync per 16-wide block of the inner dimension:
+ * the tensor core forms the block's 16 products exactly, adds them and the incoming fp16 accumulator in a wider internal format
+ * and hands back an fp16 accumulator. Restated as: after every 16-wide K block the running sum is rounded to fp16 once
+ * (products and the in-block sum exact). The hardware's internal width and truncation are not published, so this is a model of
+ * the reference's rounding points, not a bit-level claim; it exists to measure how far fp16 accumulation moves an image away
+ * from the exact-sum result the MI355X build (fp32 MFMA accumulators) reproduces. ReLU acts on the fp16 fragment. */
+static void mlp_layer_fp16_k16(const float* w, uint32_t n_out, uint32_t n_in, const float* in, int relu, float* out_f, uint16_t* out_h) {
+	for (uint32_t o = 0; o < n_out; ++o) {
+		const float* row = w + (size_t)o * n_in;
+		uint16_t acc = 0;
+		for (uint32_t k0 = 0; k0 < n_in; k0 += 16u) {
+			double block = (double)orc_half_to_float(acc);
+			const uint32_t k1 = k0 + 16u < n_in ? k0 + 16u : n_in;
+			for (uint32_t i = k0; i < k1; ++i) block += (double)row[i] * (double)in[i];
+			acc = orc_double_to_half(block);
+		}
+		float a = orc_half_to_float(acc);
+		if (relu && !(a > 0.0f)) { a = 0.0f; acc = 0; }
+		if (out_h) out_h[o] = acc;
+		out_f[o] = a;
+	}
+}
+/* ORC_MLP_ACC_IDEAL: no rounding anywhere between the stored parameters and the logits (float64 throughout) */
+static void mlp_layer_ideal(const float* w, uint32_t n_out, uint32_t n_in, const double* in, int relu, double* out) {
+	for (uint32_t o = 0; o < n_out; ++o) {
+		const float* row = w + (size_t)o * n_in;
+		double acc = 0.0;
+		for (uint32_t i = 0; i < n_in; ++i) acc += (double)row[i] * in[i];
+		out[o] = relu && !(acc > 0.0) ? 0.0 : acc;
+	}
+}
+static void mlp_forward_ideal(const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const double* in, double* out) {
+	double a[256], b[256];
+	mlp_layer_ideal(w, width, n_in, in, 1, a);
+	w += (size_t)width * n_in;
+	double* cur = a;
+	double* nxt = b;
+	for (uint32_t l = 1; l < n_hidden; ++l) {
+		mlp_layer_ideal(w, width, width, cur, 1, nxt);
+		w += (size_t)width * width;
+		double* t = cur; cur = nxt; nxt = t;
+	}
+	mlp_layer_ideal(w, n_out, width, cur, 0, out);
+}
 
 /* returns pointer past the consumed weights */
-static void mlp_forward(const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const float* in, float* out_f, uint16_t* out_h) {
+static void mlp_forward(uint32_t mode, const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const float* in, float* out_f, uint16_t* out_h) {
+	void (*layer)(const float*, uint32_t, uint32_t, const float*, int, float*, uint16_t*) = mode == ORC_MLP_ACC_FP16_K16 ? mlp_layer_fp16_k16 : mlp_layer;
 	float a[256], b[256];
-	mlp_layer(w, width, n_in, in, 1, a, NULL);
+	layer(w, width, n_in, in, 1, a, NULL);
 	w += (size_t)width * n_in;
 	float* cur = a;
 	float* nxt = b;
 	for (uint32_t l = 1; l < n_hidden; ++l) {
-		mlp_layer(w, width, width, cur, 1, nxt, NULL);
+		layer(w, width, width, cur, 1, nxt, NULL);
 		w += (size_t)width * width;
 		float* t = cur; cur = nxt; nxt = t;
 	}
-	mlp_layer(w, n_out, width, cur, 0, out_f, out_h);
+	layer(w, n_out, width, cur, 0, out_f, out_h);
 }
 
 /* tcnn FrequencyEncoding (encodings/frequency.h): out[j] = sin(scalbn(x[j / (2 n_freq)], (j / 2) % n_freq) * pi
@@ -386,8 +433,86 @@ void orc_frequency_encode(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, c
 	for (uint32_t i = 0; i < n; ++i) frequency_encode_one(n_dims, n_frequencies, w, x + (size_t)n_dims * i, out + (size_t)w * i);
 }
 
+/* the float64 network (ORC_MLP_ACC_IDEAL): stored fp16 parameters, everything else exact to double rounding -- trilinear
+ * interpolation, spherical harmonics / sines, both MLPs; logits out4 = rgb, density */
+static void nerf_network_one_ideal(const orc_nerf_model* m, const prepared_t* p, const float* pos01, const float* dir01, double* out4) {
+	double enc[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
+	const double PI = 3.14159265358979323846;
+	if (m->pos_encoding == 1) {
+		const uint32_t nf = m->pos_n_frequencies, n = 3u * 2u * nf;
+		for (uint32_t j = 0; j < n; ++j) enc[j] = sin(ldexp((double)pos01[j / (nf * 2u)], (int)((j / 2u) % nf)) * PI + (double)(j % 2u) * (PI / 2.0));
+		for (uint32_t j = n; j < p->enc_dims; ++j) enc[j] = 1.0;
+	} else {
+		const uint32_t F = m->n_features_per_level;
+		for (uint32_t l = 0; l < m->n_levels; ++l) {
+			const uint32_t size = p->offsets[l + 1] - p->offsets[l];
+			const uint16_t* level = p->grid + (uint64_t)p->offsets[l] * F;
+			double pos[3];
+			uint32_t pg[3];
+			for (int d = 0; d < 3; ++d) {
+				const double v = (double)p->scales[l] * (double)pos01[d] + 0.5, fl = floor(v);
+				pg[d] = (uint32_t)(int)fl;
+				pos[d] = v - fl;
+			}
+			double result[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (uint32_t idx = 0; idx < 8; ++idx) {
+				double weight = 1.0;
+				uint32_t pgl[3];
+				for (uint32_t d = 0; d < 3; ++d) {
+					if ((idx & (1u << d)) == 0) { weight *= 1.0 - pos[d]; pgl[d] = pg[d]; }
+					else { weight *= pos[d]; pgl[d] = pg[d] + 1u; }
+				}
+				const uint16_t* val = level + (uint64_t)grid_index(size, p->resolutions[l], pgl) * F;
+				for (uint32_t f = 0; f < F; ++f) result[f] += weight * (double)orc_half_to_float(val[f]);
+			}
+			for (uint32_t f = 0; f < F; ++f) enc[l * F + f] = result[f];
+		}
+	}
+	double rgb_in[128], dens[32];
+	mlp_forward_ideal(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens);
+	for (uint32_t i = 0; i < m->density_out_dims; ++i) rgb_in[i] = dens[i];
+	double* dir = rgb_in + m->density_out_dims;
+	if (m->dir_encoding == 1) {
+		const uint32_t nf = m->dir_n_frequencies, n = 3u * 2u * nf;
+		for (uint32_t j = 0; j < n; ++j) dir[j] = sin(ldexp((double)dir01[j / (nf * 2u)], (int)((j / 2u) % nf)) * PI + (double)(j % 2u) * (PI / 2.0));
+		for (uint32_t j = n; j < p->dir_dims; ++j) dir[j] = 1.0;
+	} else {
+		const double x = (double)dir01[0] * 2.0 - 1.0, y = (double)dir01[1] * 2.0 - 1.0, z = (double)dir01[2] * 2.0 - 1.0;
+		const double xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+		dir[0] = 0.28209479177387814;
+		dir[1] = -0.48860251190291987 * y;
+		dir[2] = 0.48860251190291987 * z;
+		dir[3] = -0.48860251190291987 * x;
+		dir[4] = 1.0925484305920792 * xy;
+		dir[5] = -1.0925484305920792 * yz;
+		dir[6] = 0.94617469575755997 * z2 - 0.31539156525251999;
+		dir[7] = -1.0925484305920792 * xz;
+		dir[8] = 0.54627421529603959 * x2 - 0.54627421529603959 * y2;
+		dir[9] = 0.59004358992664352 * y * (-3.0 * x2 + y2);
+		dir[10] = 2.8906114426405538 * xy * z;
+		dir[11] = 0.45704579946446572 * y * (1.0 - 5.0 * z2);
+		dir[12] = 0.3731763325901154 * z * (5.0 * z2 - 3.0);
+		dir[13] = 0.45704579946446572 * x * (1.0 - 5.0 * z2);
+		dir[14] = 1.4453057213202769 * z * (x2 - y2);
+		dir[15] = 0.59004358992664352 * x * (-x2 + 3.0 * y2);
+	}
+	for (uint32_t i = m->density_out_dims + p->dir_dims; i < p->rgb_in; ++i) rgb_in[i] = 1.0;
+	double rgb_out[16];
+	mlp_forward_ideal(p->rgb_w, p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out, rgb_in, rgb_out);
+	out4[0] = rgb_out[0];
+	out4[1] = rgb_out[1];
+	out4[2] = rgb_out[2];
+	out4[3] = dens[0];
+}
+
 /* nerf_network.h:105-139: pos enc -> density MLP -> [density out | dir enc] -> rgb MLP; row 3 <- density logit. */
 static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const float* pos01, const float* dir01, uint16_t* out4) {
+	if (m->mlp_accumulate == ORC_MLP_ACC_IDEAL) { /* (the fp16 interface rounds the float64 logits once) */
+		double o[4];
+		nerf_network_one_ideal(m, p, pos01, dir01, o);
+		for (int k = 0; k < 4; ++k) out4[k] = orc_double_to_half(o[k]);
+		return;
+	}
 	uint16_t enc_h[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
 	float enc[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
 	if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h);
@@ -395,7 +520,7 @@ static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const
 	for (uint32_t i = 0; i < p->enc_dims; ++i) enc[i] = orc_half_to_float(enc_h[i]);
 	float rgb_in[128];
 	uint16_t dens_h[32];
-	mlp_forward(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, rgb_in, dens_h);
+	mlp_forward(m->mlp_accumulate, p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, rgb_in, dens_h);
 	uint16_t dir_h[64];
 	if (m->dir_encoding == 1) frequency_encode_one(3, m->dir_n_frequencies, p->dir_dims, dir01, dir_h);
 	else sh4_one(dir01, dir_h);
@@ -403,11 +528,23 @@ static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const
 	for (uint32_t i = m->density_out_dims + p->dir_dims; i < p->rgb_in; ++i) rgb_in[i] = 1.0f; /* alignment padding of the rgb network's input */
 	float rgb_out[16];
 	uint16_t rgb_h[16];
-	mlp_forward(p->rgb_w, p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out, rgb_in, rgb_out, rgb_h);
+	mlp_forward(m->mlp_accumulate, p->rgb_w, p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out, rgb_in, rgb_out, rgb_h);
 	out4[0] = rgb_h[0];
 	out4[1] = rgb_h[1];
 	out4[2] = rgb_h[2];
 	out4[3] = dens_h[0];
+}
+/* the logits as the compositor reads them: the fp16 network outputs, or -- ORC_MLP_ACC_IDEAL -- the float64 logits rounded to fp32 */
+static void nerf_network_one_f(const orc_nerf_model* m, const prepared_t* p, const float* pos01, const float* dir01, float* out4) {
+	if (m->mlp_accumulate == ORC_MLP_ACC_IDEAL) {
+		double o[4];
+		nerf_network_one_ideal(m, p, pos01, dir01, o);
+		for (int k = 0; k < 4; ++k) out4[k] = (float)o[k];
+		return;
+	}
+	uint16_t h[4];
+	nerf_network_one(m, p, pos01, dir01, h);
+	for (int k = 0; k < 4; ++k) out4[k] = orc_half_to_float(h[k]);
 }
 
 /* ------------------------------------------------------------------ ERenderMode::Normals: d density logit / d position
@@ -911,23 +1048,23 @@ uint32_t orc_trace_ray(const orc_nerf_model* m, const float* cam_matrix, const o
 		t += dt;
 		/* ... network ... */
 		float wpos[3] = {warped.x, warped.y, warped.z};
-		uint16_t out4[4];
-		nerf_network_one(m, p, wpos, wdir, out4);
+		float out4[4];
+		nerf_network_one_f(m, p, wpos, wdir, out4);
 		++n;
 		/* ... and read back by the compositor */
 		v3 pos = v3_add(p->aabb.min, v3_mul(warped, diag)); /* unwarp_position */
 		float T = 1.0f - la;
 		float dtu = unwarp_dt(wdt);
-		float alpha = 1.0f - expf(-network_to_density(orc_half_to_float(out4[3]), m->density_activation) * dtu);
+		float alpha = 1.0f - expf(-network_to_density(out4[3], m->density_activation) * dtu);
 		float weight = alpha * T;
-		float r = network_to_rgb(orc_half_to_float(out4[0]), m->rgb_activation);
-		float g = network_to_rgb(orc_half_to_float(out4[1]), m->rgb_activation);
-		float b = network_to_rgb(orc_half_to_float(out4[2]), m->rgb_activation);
+		float r = network_to_rgb(out4[0], m->rgb_activation);
+		float g = network_to_rgb(out4[1], m->rgb_activation);
+		float b = network_to_rgb(out4[2], m->rgb_activation);
 		if (o->render_mode == 7) { /* ERenderMode::Normals, testbed_nerf.cu:688-693: opposite to the density gradient */
 			float g3[3];
 			density_gradient_one(m, p, wpos, g3, NULL);
 			float dd;
-			float sv = orc_half_to_float(out4[3]);
+			float sv = out4[3];
 			switch (m->density_activation) { /* network_to_density_derivative, nerf_device.cuh:245-254 */
 				case 1: dd = sv > 0.0f ? 1.0f : 0.0f; break;
 				case 2: { float dn = 1.0f / (1.0f + expf(-sv)); dd = dn * (1.0f - dn); } break;
@@ -1193,7 +1330,7 @@ static void grid_samples_splat(const orc_nerf_model* m, const prepared_t* p, uin
 		uint16_t dens_h[32];
 		grid_encode_one(m, p, pos01, enc_h);
 		for (uint32_t k = 0; k < p->enc_dims; ++k) enc[k] = orc_half_to_float(enc_h[k]);
-		mlp_forward(p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens_f, dens_h);
+		mlp_forward(m->mlp_accumulate == ORC_MLP_ACC_FP16_K16 ? ORC_MLP_ACC_FP16_K16 : ORC_MLP_ACC_EXACT, p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens_f, dens_h);
 		float thickness = network_to_density(orc_half_to_float(dens_h[0]), m->density_activation) * MIN_CONE_STEPSIZE();
 		/* atomicMax on the bit pattern: positive floats order like unsigned ints */
 		union { float f; uint32_t u; } nv, ov;

@@ -34,7 +34,7 @@ constexpr int BLOCK = 256;
 // NORMALS: ERenderMode::Normals -- every sample's colour is the unit vector opposite to the density's input gradient (one backward
 // pass through the density head and the encoding per sample, density_gradient_pass); an instantiation of its own, so that no other
 // kernel carries its registers
-template <bool PROBE, bool PROF = false, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false, bool NORMALS = false>
+template <bool PROBE, int PROF = 0, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false, bool NORMALS = false>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
@@ -43,6 +43,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade in use: empty-space summary of the occupancy grid (the host picks an instantiation with MIPS > max_cascade)
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
 	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
+	unsigned long long t_entry = 0, rt_entry = 0; // diagnostic build: the wave's arrival, before the workgroup stages weights and occupancy summaries
+	if (PROF) { t_entry = stamp(); rt_entry = realtime(); }
 	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += BLOCK) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
 	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
@@ -105,8 +107,28 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		rt_start = realtime();
 		if (lane == 0) atomicMax(&F.prof[8], ~rt_start); // = min over waves of the start time
 	}
+	// ---- wave timeline (diagnostic build, NGP_PROFILE_TRACE=stride): every stride-th wave that is dealt rays writes one 32-byte
+	// record per loop round -- s_memtime at the top of the round and after each section, what the round carried -- and a header
+	// (where it ran, when it started on the chip's 100 MHz clock). Layout: tools/wave_trace.py.
+	int tr_slot = -1; // -1: no rays dealt yet, -2: not a traced wave
+	uint32_t tr_it = 0, tr_info0 = 0, tr_info1 = 0, tr_march = 0;
+	uint32_t tr_net[5] = {0, 0, 0, 0, 0}; // [address arithmetic + gather issue, gather wait, corner sums, MFMA chains, hand-back] of the round's passes
+	unsigned long long tr_t[5] = {0, 0, 0, 0, 0};
+	auto trace_emit = [&](int upto) { // sections after `upto` did not run this round: their stamps repeat the last one taken
+		if (!PROF || tr_slot < 0) return;
+		if (tr_it < F.trace_cap_iters && lane == 0) {
+			uint32_t* r = F.trace + 16 + F.trace_cap_waves * 16u + ((size_t)tr_slot * F.trace_cap_iters + tr_it) * 16u;
+			r[0] = (uint32_t)tr_t[0];
+			for (int k = 1; k < 5; ++k) r[k] = (uint32_t)(tr_t[k <= upto ? k : upto] - tr_t[0]);
+			r[5] = tr_info0;
+			r[6] = tr_info1;
+			r[7] = tr_march;
+			for (int k = 0; k < 5; ++k) r[8 + k] = upto >= 3 ? tr_net[k] : 0u; // PROF 2: inside the network section
+		}
+		++tr_it;
+	};
 	for (;;) {
-		if (PROF) t0 = stamp();
+		if (PROF) { t0 = stamp(); tr_t[0] = t0; tr_info0 = tr_info1 = tr_march = 0; for (int k = 0; k < 5; ++k) tr_net[k] = 0; }
 		// ---- refill free slots from the tile queue: K1 and the start-of-ray jitter of K2. The skip to the first
 		// occupied voxel that K2 also does (advance_pos_nerf, :356) is the same loop as K4's and runs below with every
 		// other marching lane -- a ray with nothing in front of it must not stall the 63 other slots of its wave.
@@ -121,6 +143,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));
+			if (PROF) tr_info1 |= 4u << 24;
 		}
 		if (!exhausted && n_dead >= (F.tune[0] > 16 ? F.tune[0] : 16)) {
 			// the queue deals 4x4-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
@@ -150,6 +173,23 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				exhausted = true;
 			} else {
 				const uint32_t got = limit - first < want ? limit - first : want;
+				if (PROF && F.trace && tr_slot == -1) {
+					uint32_t n = 0;
+					if (lane == 0) n = atomicAdd(F.trace, 1u);
+					n = __builtin_amdgcn_readfirstlane(n);
+					tr_slot = (n % F.trace_stride == 0u && n / F.trace_stride < F.trace_cap_waves) ? (int)(n / F.trace_stride) : -2;
+					if (tr_slot >= 0 && lane == 0) {
+						uint32_t* hd = F.trace + 16 + (size_t)tr_slot * 16u;
+						hd[0] = (uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); // HW_REG_HW_ID: wave, SIMD, CU, SH, SE
+						hd[1] = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; // XCD
+						hd[2] = blockIdx.x;
+						hd[3] = threadIdx.x >> 6;
+						hd[5] = (uint32_t)rt_entry; hd[6] = (uint32_t)(rt_entry >> 32);
+						hd[9] = (uint32_t)t_entry; hd[10] = (uint32_t)tr_t[0];
+						hd[11] = n;
+					}
+				}
+				if (PROF) tr_info1 |= 8u << 24;
 				const uint32_t r = lanes_below(dead_mask);
 				const uint32_t strip = first + (r >> 4);
 				const bool take = !ray.alive && r < got * 16u;
@@ -263,13 +303,13 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 		}
 
-		if (PROF) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; }
+		if (PROF) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; tr_t[1] = t1; }
 		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494), at most SKIP_STEPS of
 		// its iterations per lane and round; a lane that reaches an occupied voxel emits its sample and waits.
 		for (int k = 0; k < F.tune[1]; ++k) {
 			const bool marching = ray.alive && !ready;
 			if (!__any(marching)) break;
-			if (PROF) { ++p_rounds; p_lane_steps += (unsigned long long)__popcll(__ballot(marching)); }
+			if (PROF) { const uint32_t nm = (uint32_t)__popcll(__ballot(marching)); ++p_rounds; p_lane_steps += (unsigned long long)nm; tr_march += 1u + (nm << 8); }
 			bool newly_counted = false;
 			if (marching) {
 				f3 pos = add3(ray.o, scale3(ray.d, ray.t));
@@ -325,14 +365,21 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		unsigned long long ready_mask = __ballot(ready);
 		int n_ready = __popcll(ready_mask);
 		const bool any_marching = __any(ray.alive && !ready);
-		if (PROF) { t1 = stamp(); pt[1] += t1 - t0; t0 = t1; ++p_iters; }
+		if (PROF) {
+			t1 = stamp(); pt[1] += t1 - t0; t0 = t1; ++p_iters; tr_t[2] = t1;
+			tr_info0 = (uint32_t)n_ready | ((uint32_t)stall << 24);
+			tr_info1 |= (uint32_t)__popcll(__ballot(ray.alive)) | ((uint32_t)__popcll(__ballot(ray.alive && !ready)) << 8) | ((uint32_t)__popcll(__ballot(crole > 0)) << 16) |
+			            ((exhausted ? 1u : 0u) << 24);
+		}
 		if (n_ready == 0) {
+			trace_emit(2);
 			if (exhausted && !__any(ray.alive) && !__any(finished)) break;
 			continue;
 		}
 		// run the network once enough samples wait, or nothing else can make progress; never starve a waiting sample
 		if (n_ready < F.tune[2] && any_marching && stall < F.tune[3]) {
 			++stall;
+			trace_emit(2);
 			continue;
 		}
 		if (!PROBE && stall < max_links) {
@@ -340,6 +387,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			const bool can_grow = __any(ray.alive && ready && chain_next < 0 && crole < max_links) && __any(!ray.alive && !finished && crole == 0);
 			if (can_grow || (exhausted && any_marching)) {
 				++stall;
+				trace_emit(2);
 				continue;
 			}
 		}
@@ -415,6 +463,14 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				}
 			}
 		}
+		unsigned long long u0 = 0, u1 = 0;
+		auto lap = [&](int k, bool drain_gathers) { // PROF 2 only: the stamps (and the explicit wait) serialise what the shipped kernel overlaps
+			if (drain_gathers) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			u1 = stamp();
+			tr_net[k] += (uint32_t)(u1 - u0);
+			u0 = u1;
+		};
+		if (PROF >= 2) u0 = stamp();
 		for (; p + 1 < n_pass; p += 2) {
 			float ax, ay, az, bx, by, bz;
 			Sh4 sha, shb;
@@ -423,23 +479,33 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			EncodeInFlight ea, eb;
 			encode_issue(t_grid, t_xgrid, s_lv, hq, ax, ay, az, ea);
 			encode_issue(t_grid, t_xgrid, s_lv, hq, bx, by, bz, eb);
+			if (PROF >= 2) { lap(0, false); lap(1, true); }
 			half8 enca = encode_finish(ea);
 			half8 encb = encode_finish(eb);
+			if (PROF >= 2) lap(2, false);
 			MlpOut moa = mlp_pass<RGB_MID>(s_w, lane, enca, sha);
 			MlpOut mob = mlp_pass<RGB_MID>(s_w, lane, encb, shb);
+			if (PROF >= 2) lap(3, false);
 			deliver(p, moa);
 			deliver(p + 1, mob);
+			if (PROF >= 2) lap(4, false);
 		}
 		if (p < n_pass) {
 			float ax, ay, az;
 			Sh4 sha;
 			sample_of(p, ax, ay, az, sha);
-			half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, hq, ax, ay, az);
+			EncodeInFlight e1;
+			encode_issue(t_grid, t_xgrid, s_lv, hq, ax, ay, az, e1);
+			if (PROF >= 2) { lap(0, false); lap(1, true); }
+			half8 enc = encode_finish(e1);
+			if (PROF >= 2) lap(2, false);
 			MlpOut mo = mlp_pass<RGB_MID>(s_w, lane, enc, sha);
+			if (PROF >= 2) lap(3, false);
 			deliver(p, mo);
+			if (PROF >= 2) lap(4, false);
 		}
 
-		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; }
+		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; tr_t[3] = t1; tr_info0 |= ((uint32_t)n_ready << 8) | ((uint32_t)n_pass << 16); }
 		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
 		// one sample (network outputs, warped dt, depth of the sample along the camera axis) onto this lane's ray
 		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth, f3 spos) {
@@ -520,11 +586,19 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			}
 			chain_next = -1;
 		}
-		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; }
+		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; tr_t[4] = t1; trace_emit(4); }
 	}
 	if (PROF) { // per-lane skip steps by jump size: reduce over the wave first
 		for (int k = 0; k < 3; ++k)
 			for (int off = 32; off > 0; off >>= 1) p_skip[k] += __shfl_down(p_skip[k], off, 64);
+	}
+	if (PROF && tr_slot >= 0 && lane == 0) {
+		uint32_t* hd = F.trace + 16 + (size_t)tr_slot * 16u;
+		const unsigned long long rt_end = realtime(), t_end = stamp();
+		hd[4] = tr_it;
+		hd[7] = (uint32_t)rt_end; hd[8] = (uint32_t)(rt_end >> 32);
+		hd[12] = (uint32_t)t_end;
+		hd[13] = n_samples;
 	}
 	if (PROF && lane == 0 && F.prof) {
 		for (int k = 0; k < 3; ++k) atomicAdd(&F.prof[12 + k], p_skip[k]);
@@ -582,7 +656,17 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_normals(const Mode
 }
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	fused_body<false, true>(M, C, F, P);
+	fused_body<false, 1>(M, C, F, P);
+}
+// the stamped twins of the kernel a benchmark frame runs (unit scene, static pinhole camera), at its occupancy: section stamps (1) and,
+// in addition, stamps inside the network section (2: they serialise gather wait and MFMA chain, so that build's totals are an upper bound)
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit_plain_prof(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, 1, true, 1, true, 1, true>(M, C, F, P);
+}
+__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit_plain_prof2(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, 2, true, 1, true, 1, true>(M, C, F, P);
 }
 
 // the same machinery fed by the probe ray fans instead of the camera (Testbed::computeEnvmap*, testbed.h:709-743)
@@ -999,9 +1083,10 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	}
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
 	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5),
+	                 per_cu_unit_plain_prof = resident_blocks_per_cu(render_nerf_fused_unit_plain_prof), per_cu_unit_plain_prof2 = resident_blocks_per_cu(render_nerf_fused_unit_plain_prof2),
 	                 per_cu_unit_plain = resident_blocks_per_cu(render_nerf_fused_unit_plain), per_cu_c5_plain = resident_blocks_per_cu(render_nerf_fused_c5_plain);
 	const bool plain = C.lens_mode == 0 && C.aperture_size == 0.0f && !C.moving && !F.envmap;
-	int per_cu = F.prof ? per_cu_prof : unit ? (plain ? per_cu_unit_plain : per_cu_unit) : c5 ? (plain ? per_cu_c5_plain : per_cu_c5) : per_cu_generic;
+	int per_cu = F.prof ? (unit && plain ? (F.prof_level >= 2 ? per_cu_unit_plain_prof2 : per_cu_unit_plain_prof) : per_cu_prof) : unit ? (plain ? per_cu_unit_plain : per_cu_unit) : c5 ? (plain ? per_cu_c5_plain : per_cu_c5) : per_cu_generic;
 	// a rank of a sharded frame leaves a third of every CU to the collective's kernels and to the next frame's launch
 	// (measured on one GPU with two frames in flight: 2 per CU is as fast as 3 from N = 2 on, tools/shard_probe.py)
 	static const int shard_per_cu = []() { const char* e = getenv("NGP_SHARD_BLOCKS_PER_CU"); int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }(); // experiments: tools/shard_probe.py
@@ -1012,7 +1097,9 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
 	FrameParams G = F;
 	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
-	if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	if (F.prof && unit && plain && F.prof_level >= 2) hipLaunchKernelGGL(render_nerf_fused_unit_plain_prof2, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (F.prof && unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (c5 && plain) hipLaunchKernelGGL(render_nerf_fused_c5_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);

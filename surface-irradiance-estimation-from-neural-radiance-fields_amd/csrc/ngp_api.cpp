@@ -1144,6 +1144,11 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.frame_buffer = ctx->d_frame;
 	F.depth_buffer = d_depth_out ? d_depth_out : ctx->d_depth;
 	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
+	// Call k reuses the queue word, exit counter and accumulators of call k - HISTORY, which may have been issued on another stream and,
+	// in an unsynchronised loop of short frames, may still be running: two live launches on one slot would deal tiles twice and zero
+	// the slot under each other. Order this call's stream behind that frame's end (a device-side wait, no host stall; free when the
+	// old frame is long done, which is the usual case).
+	if (ctx->n_calls >= (uint64_t)ngp_ctx::HISTORY) NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_frame1[slot], 0));
 	ctx->bind_slot(F, slot); // every call has its own queue word and counters: frames on different streams may overlap
 	if (shard_count > 1) F.xqueue = nullptr; // per-XCD bands pay for a whole frame (+1.4 %); a rank's interleaved share is too small for them (N = 4: -3 %, N = 8: -6 %)
 	F.tiles_x = (uint32_t)(cam.width + 7) / 8;
@@ -1161,6 +1166,19 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 512));
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 512, stream));
 		F.prof = ctx->d_prof;
+		F.prof_level = atoi(getenv("NGP_PROFILE_SECTIONS"));
+		if (const char* e = getenv("NGP_PROFILE_TRACE")) { // timelines of every stride-th working wave (tools/wave_trace.py)
+			const int stride = atoi(e);
+			if (stride > 0) {
+				const size_t words = 16 + (size_t)ngp_ctx::TRACE_WAVES * 16 + (size_t)ngp_ctx::TRACE_WAVES * ngp_ctx::TRACE_ITERS * 16;
+				if (!ctx->d_trace) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_trace, words * sizeof(uint32_t)));
+				NGP_HIP_CHECK(hipMemsetAsync(ctx->d_trace, 0, words * sizeof(uint32_t), stream));
+				F.trace = ctx->d_trace;
+				F.trace_stride = (uint32_t)stride;
+				F.trace_cap_waves = ngp_ctx::TRACE_WAVES;
+				F.trace_cap_iters = ngp_ctx::TRACE_ITERS;
+			}
+		}
 	}
 	const bool geometry = opts.testbed_mode == NGP_MODE_GEOMETRY;
 	const bool have_meshes = geometry && !ctx->meshes.empty();
@@ -1365,6 +1383,7 @@ void ngp_destroy(ngp_ctx* ctx) {
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 	if (ctx->d_rgba) (void)hipFree(ctx->d_rgba);
 	if (ctx->d_sync) (void)hipFree(ctx->d_sync);
+	if (ctx->d_trace) (void)hipFree(ctx->d_trace);
 	for (int i = 0; i < ngp_ctx::HISTORY; ++i) {
 		if (ctx->ev_frame0[i]) (void)hipEventDestroy(ctx->ev_frame0[i]);
 		if (ctx->ev_frame1[i]) (void)hipEventDestroy(ctx->ev_frame1[i]);
@@ -1788,6 +1807,19 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
 			        100.0 * p[0] / tot, 100.0 * p[1] / tot, 100.0 * p[2] / tot, 100.0 * p[3] / tot, p[4], p[5], tot / (double)p[4], (double)p[2] / (double)p[5], p[6], p[7], (double)p[7] / (double)p[6], (double)p[1] / (double)p[6]);
 		}
+	});
+}
+
+// diagnostic (NGP_PROFILE_SECTIONS + NGP_PROFILE_TRACE): the wave timelines of the last frame; layout in csrc/ngp_kernels.h (FrameParams::trace)
+int ngp_get_profile_trace(ngp_ctx* ctx, uint32_t* out, uint64_t n_words, uint32_t* cap_waves, uint32_t* cap_iters) {
+	return guarded(ctx, [&] {
+		if (!ctx->d_trace) throw std::runtime_error("no wave trace: set NGP_PROFILE_SECTIONS=1|2 and NGP_PROFILE_TRACE=<stride> before rendering");
+		const size_t words = 16 + (size_t)ngp_ctx::TRACE_WAVES * 16 + (size_t)ngp_ctx::TRACE_WAVES * ngp_ctx::TRACE_ITERS * 16;
+		if (cap_waves) *cap_waves = ngp_ctx::TRACE_WAVES;
+		if (cap_iters) *cap_iters = ngp_ctx::TRACE_ITERS;
+		if (!out) return;
+		NGP_HIP_CHECK(hipDeviceSynchronize());
+		NGP_HIP_CHECK(hipMemcpy(out, ctx->d_trace, std::min<size_t>(words, (size_t)n_words) * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	});
 }
 

@@ -146,6 +146,12 @@ struct FrameParams {
 	const float4* envmap;     // m_envmap.inference_view(): lat-long radiance behind the NeRF (read_envmap), nullptr = none
 	int32_t env_w, env_h;
 	unsigned long long* prof; // diagnostic build only (NGP_PROFILE_SECTIONS=1): [refill, march, network, composite, iterations, passes] cycle sums
+	// diagnostic build, NGP_PROFILE_TRACE=stride: timelines of single waves (nerf_kernels.hip fused_body; read back by ngp_get_profile_trace,
+	// decoded by tools/wave_trace.py). trace[0] counts the waves that were dealt rays; every stride-th of them gets a header of 16 words at
+	// trace + 16 + 16 slot and records of 16 words at trace + 16 + 16 cap_waves + 16 (slot cap_iters + round)
+	uint32_t* trace;
+	uint32_t trace_stride, trace_cap_waves, trace_cap_iters;
+	int32_t prof_level;       // NGP_PROFILE_SECTIONS: 1 section stamps, 2 also inside the network section
 };
 
 // ---- irradiance probes

@@ -382,6 +382,7 @@ void compute_probes(ngp_ctx* ctx, ngp::ProbeParams P, float min_transmittance) {
 	hipStream_t stream = ctx->stream;
 	if (ctx->last_stream && ctx->last_stream != stream) NGP_HIP_CHECK(hipStreamSynchronize(ctx->last_stream));
 	const int slot = (int)(ctx->n_calls % ngp_ctx::HISTORY);
+	if (ctx->n_calls >= (uint64_t)ngp_ctx::HISTORY) NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_frame1[slot], 0)); // the slot's previous launch (render_frames, ngp_api.cpp)
 	FrameParams F{};
 	ctx->bind_slot(F, slot);
 	F.n_local_tiles = (P.n_rays + 63) / 64;

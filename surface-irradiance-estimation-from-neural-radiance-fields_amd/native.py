@@ -171,6 +171,7 @@ def load_library():
     L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
     L.ngp_get_render_history.argtypes = [vp, ip, C.POINTER(RenderStats)]
     L.ngp_set_schedule.argtypes = [vp, vp, ip]
+    L.ngp_get_profile_trace.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
     L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.ngp_density_gradient.argtypes = [vp, C.c_uint32, vp, vp]
@@ -331,6 +332,15 @@ class Context:
         """refill_min, skip_steps, go_min, max_stall, links_busy, links_drain, block_jumps (ngp_set_schedule: validated)"""
         a = np.asarray(knobs, np.int32)
         self._check(self.L.ngp_set_schedule(self.h, _p(a), a.size))
+
+    def profile_trace(self):
+        """Wave timelines of the last frame (diagnostic build: NGP_PROFILE_SECTIONS + NGP_PROFILE_TRACE): (n_working_waves, headers [W, 16], records [W, I, 16])"""
+        cw, ci = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+        self._check(self.L.ngp_get_profile_trace(self.h, None, 0, _p(cw), _p(ci)))
+        w, it = int(cw[0]), int(ci[0])
+        buf = np.zeros(16 + w * 16 + w * it * 16, np.uint32)
+        self._check(self.L.ngp_get_profile_trace(self.h, _p(buf), buf.size, None, None))
+        return int(buf[0]), buf[16:16 + w * 16].reshape(w, 16), buf[16 + w * 16:].reshape(w, it, 16)
 
     # ---------------------------------------------------------------- model
     def set_model(self, scene):

@@ -427,6 +427,38 @@ def test_frames_on_two_streams_overlap_safely(gpu_ctx, native, scene_mod, scene_
         assert hist[i]["n_samples"] > 0 and hist[i]["n_rays"] == ((w + 7) // 8) * ((h + 7) // 8) * 64
 
 
+def test_slot_ring_survives_an_unsynchronised_loop(native, scene_mod, scene_unit):
+    """Call k binds queue word / exit counter / accumulators k % 256. 600 small frames issued without a wait over 6 streams (what
+    bench.py does beyond two GPUs, and what a video loop does) put calls k and k + 256 on different streams: the library orders the
+    later one behind the earlier one's end, so every frame still equals its serial render and its own counters."""
+    import torch
+
+    torch.zeros(1, device="cuda")
+    ctx = native.Context(0)
+    ctx.set_model(scene_unit)
+    w, h, n, n_cams = 64, 36, 600, 8
+    cams = [native.make_camera(scene_mod.orbit_camera(45.0 * i), w, h, scene_mod.focal_from_fov_x(w, 0.6911)) for i in range(n_cams)]
+    serial = []
+    for c in cams:
+        img, dep = ctx.render(c, native.make_opts(), want_depth=True)
+        serial.append((img, dep, ctx.render_stats()))
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    rgba = torch.zeros((n, h, w, 4), device="cuda")
+    depth = torch.zeros((n, h, w), device="cuda")
+    torch.cuda.synchronize()
+    for i in range(n):
+        ctx.render_device(cams[i % n_cams], native.make_opts(), rgba[i].data_ptr(), depth[i].data_ptr(), streams[i % 6].cuda_stream)
+    torch.cuda.synchronize()
+    hist = ctx.render_history(256)
+    got, got_d = rgba.cpu().numpy(), depth.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], serial[i % n_cams][0]) and np.array_equal(got_d[i], serial[i % n_cams][1]), f"frame {i}"
+    for j, st in enumerate(hist):  # the last 256 calls: i = n - 256 + j
+        ref = serial[(n - 256 + j) % n_cams][2]
+        assert (st["n_samples"], st["n_rays_hit"], st["n_rays"]) == (ref["n_samples"], ref["n_rays_hit"], ref["n_rays"]), f"call {n - 256 + j}"
+    ctx.close()
+
+
 def test_density_grid_refresh_parity(native, oracle, scene_mod, scene_unit):
     """ngp_update_density_grid vs the oracle's update_density_grid_nerf: the same cells are sampled (pcg32 stream, cell
     hash and positions are bit-exact), their optical thickness agrees to the fp16 network tolerance, and the rebuilt
