@@ -236,10 +236,12 @@ NGP_API int ngp_get_device_render_stats(ngp_ctx* ctx, int device_index, ngp_rend
 NGP_API int ngp_get_render_history(ngp_ctx* ctx, int n, ngp_render_stats* out);
 
 /* Scheduling of the persistent render kernel: knobs[0..n) = refill_min [16,64], skip_steps [1,64], go_min [1,64], max_stall [0,64],
- * chain links while tiles remain [0,3], chain links in the drain phase [0,3], block_jumps {0,1}. Performance only, except
- * block_jumps: 1 (default) leaves empty 4^3 / 16^3 blocks of the occupancy grid in one step, 0 walks them voxel by voxel exactly
- * as if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494) does. Out-of-range values are refused (they would
- * hang the kernel). No counterpart in the reference; the environment variable NGP_TUNE sets the same list at ngp_create. */
+ * samples a ray may emit per round while most of a wave's ray slots are live [1,8], at most once fewer are [1,8] (the reference's n_steps
+ * between two compactions, src/testbed_nerf.cu:2080-2086), block_jumps {0,1}, share {0,1} (a wave that has run out of work takes over half
+ * the rays of a busy wave of its workgroup). Performance only, except block_jumps: 1 (default) leaves empty 4^3 / 16^3 blocks of the occupancy grid in
+ * one step, 0 walks them voxel by voxel exactly as if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494) does.
+ * Out-of-range values are refused (they would hang the kernel). No counterpart in the reference; the environment variable
+ * NGP_TUNE sets the same list at ngp_create. */
 NGP_API int ngp_set_schedule(ngp_ctx* ctx, const int32_t* knobs, int n);
 /* Diagnostic, no counterpart in the reference: with NGP_PROFILE_SECTIONS=1|2 and NGP_PROFILE_TRACE=<stride> in the environment the render
  * kernel's stamped twin records the timeline of every stride-th wave that was dealt rays (one record per loop round: s_memtime at the

@@ -43,7 +43,7 @@ def build(force=False, verbose=False, legacy=False):
     # link to a private name and rename: another process (a rank of the same job, a test worker) may be dlopen-ing the
     # library at this moment and must see either the old file or the complete new one
     tmp = "%s.%d.tmp" % (lib, os.getpid())
-    cmd = [hipcc()] + FLAGS + (["-DNGP_TCNN_LEGACY_ENCODE"] if legacy else []) + ["-o", tmp] + srcs + ["-lz"]
+    cmd = [hipcc()] + FLAGS + (["-DNGP_TCNN_LEGACY_ENCODE"] if legacy else []) + os.environ.get("NGP_BUILD_DEFINES", "").split() + ["-o", tmp] + srcs + ["-lz"]  # NGP_BUILD_DEFINES: experiments only
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -192,6 +192,36 @@ NGP_DEV uint32_t empty_block_size_at(f3 pos, const uint8_t* __restrict__ bitfiel
 	return ((word >> (idx & 31u)) & 1u) ? 0u : 1u;
 }
 
+// The same answer for the fused kernel's march, cheapest case first. A ray spends ~18 consecutive samples inside one 4x4x4 block of cells,
+// so the lane keeps the block it read last (its 64 occupancy bits) under a key that needs no Morton code: equal key => the answer is
+// one bit test, no LDS summary and no memory is touched. Only a lane that has moved to another block pays for the Morton code of the
+// block, the two LDS summaries and -- if the block is not empty -- the 8-byte word of the bitfield.
+struct OccBlock {
+	uint32_t key; // (x >> 2) | (y >> 2) << 5 | (z >> 2) << 10 | mip << 15 of the held block; 0xffffffff = none
+	uint2 bits;   // bit (morton & 63) = cell (x & 3, y & 3, z & 3) of the block
+};
+NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip, OccBlock& cache) {
+	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
+	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
+	const int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
+	const int iy = (int)(pos.y * (float)NERF_GRIDSIZE);
+	const int iz = (int)(pos.z * (float)NERF_GRIDSIZE);
+	if (((uint32_t)ix | (uint32_t)iy | (uint32_t)iz) >= NERF_GRIDSIZE) return 1u; // (a negative coordinate has its top bit set)
+	const uint32_t x = (uint32_t)ix, y = (uint32_t)iy, z = (uint32_t)iz;
+	const uint32_t key = (x >> 2) | ((y >> 2) << 5) | ((z >> 2) << 10) | (mip << 15);
+	if (cache.key != key) {
+		const uint32_t b4 = morton3D(x >> 2, y >> 2, z >> 2), b16 = b4 >> 6; // == morton3D(x, y, z) >> 6, >> 12
+		if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
+		if (!((s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] >> (b4 & 31u)) & 1u)) return 4u;
+		cache.bits = *(const uint2*)(bitfield + (size_t)b4 * 8 + (size_t)(NERF_GRID_N_CELLS / 8) * mip);
+		cache.key = key;
+	}
+	// the Morton code of the coordinates' low two bits: bit (idx & 63) of the block word
+	const uint32_t bit = (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2) | ((x & 2u) << 2) | ((y & 2u) << 3) | ((z & 2u) << 4);
+	const uint32_t word = (bit & 32u) ? cache.bits.y : cache.bits.x;
+	return ((word >> (bit & 31u)) & 1u) ? 0u : 1u;
+}
+
 // res is a power of two, so t / res == t * (1/res) bit for bit; inv_res spares the IEEE division sequence
 NGP_DEV float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, float res, float inv_res) {
 	f3 p = scale3(adds3(pos, -0.5f), res);

@@ -18,13 +18,6 @@
 namespace ngp {
 
 constexpr int BLOCK = 256;
-// Scheduling knobs of the wave loop (FrameParams::tune, defaults set by the host):
-//   refill_min  refill once at least this many of a wave's 64 ray slots are free
-//   skip_steps  empty-space iterations per lane between two looks at the sample queue
-//   go_min      run the network once this many samples wait ...
-//   max_stall   ... or after this many rounds of waiting for marching lanes
-//   block_jumps leave empty 4^3 / 16^3 occupancy blocks in one step (1, default) or voxel by voxel like the reference (0)
-
 
 // UNIT: unit-cube scenes (aabb_scale 1 => one cascade, cone angle 0 => fixed step sqrt(3)/1024; load_nerf_post,
 // src/testbed_nerf.cu:2729-2736). The instantiation folds away the cascade climb, the mip arithmetic and both
@@ -34,7 +27,7 @@ constexpr int BLOCK = 256;
 // NORMALS: ERenderMode::Normals -- every sample's colour is the unit vector opposite to the density's input gradient (one backward
 // pass through the density head and the encoding per sample, density_gradient_pass); an instantiation of its own, so that no other
 // kernel carries its registers
-template <bool PROBE, int PROF = 0, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false, bool NORMALS = false>
+template <bool PROBE, int PROF = 0, bool UNIT = false, int MIPS = (UNIT ? 1 : (int)NERF_CASCADES), bool OUTSIDE = true, int RGB_MID = 1, bool PLAIN = false, bool NORMALS = false, int FB = BLOCK>
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
@@ -42,12 +35,28 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	__shared__ LevelInfo s_lv[N_LEVELS];
 	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade in use: empty-space summary of the occupancy grid (the host picks an instantiation with MIPS > max_cascade)
 	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
-	__shared__ uint2 s_sh[BLOCK * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
+	__shared__ uint2 s_sh[FB * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
+	constexpr int SLOTS = 64; // a wave's sample list: 4 network passes of 16
+	__shared__ float4 s_samp[FB / 64 * SLOTS]; // samples that wait for the network, in emission order: warped position, warped dt
+	__shared__ uint2 s_res[FB / 64 * SLOTS];   // .x = the lane that owns the sample; after the pass: the network's 4 fp16 outputs (rgb, density)
+	__shared__ float4 s_nrm[NORMALS ? FB / 64 * SLOTS : 1]; // Normals: d logit / d warped position and the logit
+	// Ray sharing inside a workgroup (knob 7): a wave that has run out of work asks through s_xstate, a busy wave hands it every second
+	// one of its live rays through s_xray (16 words per ray; the SH coefficients go straight into the receiver's s_sh rows), so the last
+	// tiles of a frame -- or a small frame's heavy tiles -- are finished by four waves instead of one.
+	//   s_xstate: 0 free | 0x100 + w: wave w asks | 0x200 + w: a donor is writing for w | 0x300 + w: s_xcount rays are ready for w
+	//   s_active: waves of this workgroup that hold rays or may still be dealt some; an asking wave leaves when it reaches 0
+	__shared__ uint32_t s_xstate, s_xcount, s_active;
+	__shared__ float s_xray[32 * 16];
+	if (threadIdx.x == 0) {
+		s_xstate = 0u;
+		s_xcount = 0u;
+		s_active = FB / 64;
+	}
 	unsigned long long t_entry = 0, rt_entry = 0; // diagnostic build: the wave's arrival, before the workgroup stages weights and occupancy summaries
 	if (PROF) { t_entry = stamp(); rt_entry = realtime(); }
-	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += BLOCK) s_w[i] = M.wfrags[i];
+	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += FB) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += BLOCK) s_coarse[i] = M.coarse[i];
+	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += FB) s_coarse[i] = M.coarse[i];
 	if (threadIdx.x < NERF_CASCADES * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
 	__syncthreads();
 
@@ -67,8 +76,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]);
 	const f3 adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
 
-	// per-lane ray slot. A slot is free (!alive), marching through empty space (alive && !ready) or holding a
-	// sample that waits for the network (ready).
+	// per-lane ray slot. A slot is free (!alive) or carries a ray that marches through empty space and emits samples into the wave's list.
 	RayState ray;
 	ray.alive = false;
 	ray.o = ray.d = mk3(0.f, 0.f, 0.f);
@@ -79,20 +87,19 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	Accum acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint32_t step = 1;
 	uint32_t skip_i = 1;
-	bool ready = false, counted = false;
-	bool held = false; // ready, but left out of the last network phase
-	// Drain phase (tile queue empty): a wave's free slots carry CONTINUATIONS of its live rays, so that one network
-	// phase advances a ray by up to MAX_CHAIN samples instead of one (the reference's n_steps > 1 per compaction
-	// round, src/testbed_nerf.cu:2080-2086). crole = k > 0: this slot marches / holds sample k of another slot's
-	// ray; chain_next = slot that continues after this slot's sample. Compositing walks the chain in order and
-	// stops where the ray terminates, exactly as it would have sample by sample.
-	constexpr int MAX_CHAIN = 4;
-	int crole = 0, chain_next = -1;
-	OccBlockCache occ_cache;
+	bool counted = false;
+	// A ray may have several samples in the wave's list at once (emitted this round, not yet through the network): n_pend of them,
+	// their slots packed 8 bits each in emission order. left_box: the ray has run out of the render box behind its last waiting sample.
+	uint32_t n_pend = 0, sl_lo = 0, sl_hi = 0;
+	bool left_box = false;
+	uint32_t n_slots = 0; // wave-uniform: samples in the list
+	const int wave_base = threadIdx.x & ~63;
+	OccBlock occ_cache;
 	occ_cache.key = 0xffffffffu;
 	occ_cache.bits = make_uint2(0u, 0u);
 	bool finished = false; // the ray has ended and waits to be shaded (once per round, with every other finished ray)
-	float wx = 0.f, wy = 0.f, wz = 0.f, wdt = 0.f;
+	bool idle = false;     // wave-uniform: this wave has told the workgroup that it is out of work (s_active)
+	const uint32_t my_wave = threadIdx.x >> 6;
 
 	// wave-uniform tile reservoir
 	bool exhausted = false;
@@ -132,7 +139,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// ---- refill free slots from the tile queue: K1 and the start-of-ray jitter of K2. The skip to the first
 		// occupied voxel that K2 also does (advance_pos_nerf, :356) is the same loop as K4's and runs below with every
 		// other marching lane -- a ray with nothing in front of it must not stall the 63 other slots of its wave.
-		unsigned long long dead_mask = __ballot(!ray.alive && crole == 0); // (a parked continuation is not a free slot)
+		unsigned long long dead_mask = __ballot(!ray.alive);
 		int n_dead = __popcll(dead_mask);
 		// ---- retire: K7 for the rays that ended since the last refill, all at once (sRGB->linear is three powf and a
 		// frame-buffer read-modify-write; run per round it would execute with one or two live lanes)
@@ -146,8 +153,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			if (PROF) tr_info1 |= 4u << 24;
 		}
 		if (!exhausted && n_dead >= (F.tune[0] > 16 ? F.tune[0] : 16)) {
-			// the queue deals 4x4-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of
-			// them, so the last units of a frame (or of a rank's share of it) are small and the waves end together
+			// the queue deals 4x4-pixel strips (quarters of the 8x8 tiles): one atomic hands this wave n_dead / 16 of them
 			const uint32_t want = (uint32_t)n_dead >> 4, n_strips = F.n_local_tiles * 4u;
 			uint32_t first = 0, limit = n_strips;
 			if (!PROBE && F.xqueue) {
@@ -250,192 +256,232 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					acc = Accum{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 					step = 1;
 					skip_i = 1;
-					ready = false;
-					held = false;
 					counted = PROBE; // probe rays count as alive from the start (there is no K2 for them)
 				}
 				if (PROBE) n_alive_init += (uint32_t)__popcll(__ballot(fresh));
 			}
 		}
 
-		const int want_links = (PROBE || F.render_mode > 1) ? 0 : (exhausted ? F.tune[5] : F.tune[4]); // (the G-buffer modes composite per-sample positions: no chains)
-		const int max_links = want_links < MAX_CHAIN - 1 ? want_links : MAX_CHAIN - 1;
-		if (!PROBE && max_links > 0) {
-			// ---- spawn continuations: the k-th free slot continues the k-th chain tail (a ready sample nobody continues yet)
-			const bool tail = ray.alive && ready && chain_next < 0 && crole < max_links;
-			const bool is_free = !ray.alive && !finished && crole == 0;
-			const unsigned long long tail_mask = __ballot(tail), free_mask = __ballot(is_free);
-			const int n_tail = __popcll(tail_mask), n_free = __popcll(free_mask);
-			const int n_pairs = n_tail < n_free ? n_tail : n_free;
-			if (n_pairs > 0) {
-				const uint32_t tail_rank = lanes_below(tail_mask), free_rank = lanes_below(free_mask);
-				// slot k of each table is written by the k-th tail / k-th free lane (ds_permute pushes along a bijection)
-				const uint32_t tslot = tail ? tail_rank : (uint32_t)n_tail + lanes_below(~tail_mask);
-				const uint32_t fslot = is_free ? free_rank : (uint32_t)n_free + lanes_below(~free_mask);
-				const int tail_of = __builtin_amdgcn_ds_permute((int)(tslot * 4u), lane);
-				const int free_of = __builtin_amdgcn_ds_permute((int)(fslot * 4u), lane);
-				const bool spawned = is_free && free_rank < (uint32_t)n_pairs;
-				const bool continued = tail && tail_rank < (uint32_t)n_pairs;
-				const int parent = __builtin_amdgcn_ds_bpermute((int)(free_rank * 4u), tail_of);
-				const int child = __builtin_amdgcn_ds_bpermute((int)(tail_rank * 4u), free_of);
-				const int src = spawned ? parent : lane;
-				const float pox = __shfl(ray.o.x, src, 64), poy = __shfl(ray.o.y, src, 64), poz = __shfl(ray.o.z, src, 64);
-				const float pdx = __shfl(ray.d.x, src, 64), pdy = __shfl(ray.d.y, src, 64), pdz = __shfl(ray.d.z, src, 64);
-				const float pt_after = __shfl(ray.t, src, 64); // the parent's t is already past its waiting sample
-				const int prole = __shfl(crole, src, 64);
-				if (continued) chain_next = child;
-				if (spawned) {
-					ray.o = mk3(pox, poy, poz);
-					ray.d = mk3(pdx, pdy, pdz);
-					ray.t = pt_after;
-					idir = mk3(1.0f / pdx, 1.0f / pdy, 1.0f / pdz);
-					ray.alive = true;
-					crole = prole + 1;
-					chain_next = -1;
-					ready = false;
-					held = false;
-					skip_i = 1;
-					counted = true;
-					// the direction's SH coefficients (K5c) travel with the ray
+		if (!PROBE && F.tune[7] && n_slots == 0u) {
+			// ---- a sibling without work is asking: hand it every second live ray (none of them has a sample in the list at this point)
+			const uint32_t st = __hip_atomic_load(&s_xstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const unsigned long long live_mask = __ballot(ray.alive);
+			if ((st & 0xf00u) == 0x100u && __popcll(live_mask) >= 16) {
+				const uint32_t to = st & 0xffu;
+				uint32_t won = 0;
+				if (lane == 0) won = atomicCAS(&s_xstate, st, 0x200u | to) == st ? 1u : 0u;
+				won = __builtin_amdgcn_readfirstlane(won);
+				if (won) {
+					const uint32_t rank = lanes_below(live_mask);
+					if (ray.alive && (rank & 1u)) {
+						const uint32_t k = rank >> 1;
+						float* x = s_xray + k * 16u;
+						x[0] = ray.o.x; x[1] = ray.o.y; x[2] = ray.o.z;
+						x[3] = ray.d.x; x[4] = ray.d.y; x[5] = ray.d.z;
+						x[6] = ray.t;
+						x[7] = __uint_as_float(ray.out);
+						x[8] = acc.r; x[9] = acc.g; x[10] = acc.b; x[11] = acc.a; x[12] = acc.depth; x[13] = acc.max_weight;
+						x[14] = __uint_as_float(step | (counted ? 0x80000000u : 0u));
+						x[15] = __uint_as_float(ray.idx);
 #pragma unroll
-					for (int q = 0; q < 4; ++q) s_sh[threadIdx.x * 4 + q] = s_sh[((threadIdx.x & ~63) + parent) * 4 + q];
-				}
-			}
-		}
-
-		if (PROF) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; tr_t[1] = t1; }
-		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494), at most SKIP_STEPS of
-		// its iterations per lane and round; a lane that reaches an occupied voxel emits its sample and waits.
-		for (int k = 0; k < F.tune[1]; ++k) {
-			const bool marching = ray.alive && !ready;
-			if (!__any(marching)) break;
-			if (PROF) { const uint32_t nm = (uint32_t)__popcll(__ballot(marching)); ++p_rounds; p_lane_steps += (unsigned long long)nm; tr_march += 1u + (nm << 8); }
-			bool newly_counted = false;
-			if (marching) {
-				f3 pos = add3(ray.o, scale3(ray.d, ray.t));
-				bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
-				if (PROBE && skip_i >= 200) out = true; // the 200-iteration variant of trace_mesh (:497-534)
-				if (out) {
-					ray.alive = false;
-					finished = crole == 0; // a continuation that runs out of the box is parked until its chain is composited
-				} else {
-					uint32_t mip = mip_from_pos(pos, NERF_CASCADES - 1);
-					mip = mip > max_cascade ? max_cascade : mip;
-					uint32_t empty = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip, occ_cache);
-					if (empty == 0u) {
-						float dt = calc_dt(ray.t, cone_angle);
-						f3 w = sub3(pos, amin); // warp_position: (pos - min) / diag
-						if (M.diag_pow2) w = mul3(w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
-						else w = div3(w, adiag);
-						wx = w.x; wy = w.y; wz = w.z;
-						wdt = warp_dt(dt);
-						ray.t = ray.t + dt;
-						ready = true;
-						skip_i = 1;
-						newly_counted = !counted;
-						counted = true;
-					} else {
-						// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
-						// the cell, so the block summary of the final level is looked up again
-						while (mip < max_cascade) {
-							uint32_t e = empty_block_size_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache);
-							if (e == 0u) break;
-							++mip;
-							empty = e;
-						}
-						if (PROF) p_skip[empty == 16u ? 2 : (empty == 4u ? 1 : 0)] += 1ull;
-						const float grid_half = 0.5f * (float)(1u << max_cascade);
-						const bool outside = OUTSIDE && !PROBE && empty == 1u && mip == max_cascade &&
-						                     fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f)) > grid_half;
-						const float to_grid = outside ? grid_cube_entry(pos, idir, grid_half) : 0.0f;
-						if (outside && to_grid < 0.0f) { // the ray never reaches the occupancy grid: it would leave the render box without a sample
-							ray.alive = false;
-							finished = crole == 0;
-						} else if (outside && to_grid > 0.0f) {
-							ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
-						} else {
-							ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
-						}
-						++skip_i;
+						for (int q = 0; q < 4; ++q) s_sh[(to * 64u + k) * 4u + q] = s_sh[threadIdx.x * 4 + q];
+						ray.alive = false; // (not finished: the ray lives on in the other wave)
+					}
+					if (lane == 0) {
+						atomicAdd(&s_active, 1u); // the receiver counts as busy again before it can see its rays
+						s_xcount = (uint32_t)__popcll(live_mask) >> 1;
+						__hip_atomic_store(&s_xstate, 0x300u | to, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
 			}
-			n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
 		}
-		unsigned long long ready_mask = __ballot(ready);
-		int n_ready = __popcll(ready_mask);
-		const bool any_marching = __any(ray.alive && !ready);
+		if (PROF) { t1 = stamp(); pt[0] += t1 - t0; t0 = t1; tr_t[1] = t1; }
+		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494). A lane that reaches an occupied voxel
+		// EMITS a sample -- warped position and step into the next free slot of the wave's sample list in LDS, in emission order -- and
+		// marches on: up to k_max samples per ray and round (the reference's n_steps > 1 between two compactions,
+		// src/testbed_nerf.cu:2080-2086), as long as the list (SLOTS = 4 network passes) has room. While the wave's 64 ray slots are
+		// all live that is one sample per ray; as rays end, the survivors fill the passes, so a tile's tail needs a fraction of the
+		// rounds and every pass, every march iteration and every composite runs with most lanes in use. Samples past the one that
+		// terminates a ray are dropped by the compositor, exactly as the reference drops them.
+		// (how many: k_busy while more than half of the wave's ray slots are live, else as many as fit the list, at most k_drain)
+		const int n_live = __popcll(__ballot(ray.alive));
+		const int k_fit = SLOTS / (n_live > 0 ? n_live : 1);
+		const int k_max = PROBE ? 1 : (n_live > SLOTS / 2 ? F.tune[4] : (k_fit < F.tune[5] ? k_fit : F.tune[5]));
+		const int max_it = F.tune[1] > k_max ? F.tune[1] : k_max;
+		bool blocked = false; // found a sample but the list is full: the lane stands still until the next round
+		for (int k = 0; k < max_it; ++k) {
+			const bool marching = ray.alive && !left_box && !blocked && (int)n_pend < k_max;
+			if (!__any(marching) || n_slots >= (uint32_t)SLOTS) break;
+			if (PROF) { const uint32_t nm = (uint32_t)__popcll(__ballot(marching)); ++p_rounds; p_lane_steps += (unsigned long long)nm; tr_march += 1u + (nm << 8); }
+			// One iteration, written flat: every marching lane forms its position and looks its cell up (a lane that is still in the 4^3
+			// block it read last needs one bit test); only the lanes that stand in an empty cell go through the voxel-exit arithmetic,
+			// and the wave skips that part altogether while all of its rays are inside the object.
+			const f3 pos = add3(ray.o, scale3(ray.d, ray.t));
+			bool out = ray.t >= MAX_DEPTH || !raabb_contains(M, pos);
+			if (PROBE && skip_i >= 200) out = true; // the 200-iteration variant of trace_mesh (:497-534)
+			const bool inside = marching && !out;
+			uint32_t mip = 0, empty = 1u;
+			if (inside) {
+				if (!UNIT) {
+					mip = mip_from_pos(pos, NERF_CASCADES - 1);
+					mip = mip > max_cascade ? max_cascade : mip;
+				}
+				empty = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip, occ_cache);
+			}
+			const bool emit = inside && empty == 0u;
+			const bool skip = inside && empty != 0u;
+			float e_dt = 0.f;
+			f3 e_w = mk3(0.f, 0.f, 0.f);
+			if (emit) {
+				e_dt = calc_dt(ray.t, cone_angle);
+				e_w = sub3(pos, amin); // warp_position: (pos - min) / diag
+				if (M.diag_pow2) e_w = mul3(e_w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
+				else e_w = div3(e_w, adiag);
+			}
+			bool ends = marching && out;
+			if (skip) {
+				// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
+				// the cell, so the block summary of the final level is looked up again
+				if (!UNIT) {
+					while (mip < max_cascade) {
+						uint32_t e = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache);
+						if (e == 0u) break;
+						++mip;
+						empty = e;
+					}
+				}
+				if (PROF) p_skip[empty == 16u ? 2 : (empty == 4u ? 1 : 0)] += 1ull;
+				const float grid_half = 0.5f * (float)(1u << max_cascade);
+				const bool outside = OUTSIDE && !PROBE && empty == 1u && mip == max_cascade &&
+				                     fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f)) > grid_half;
+				const float to_grid = outside ? grid_cube_entry(pos, idir, grid_half) : 0.0f;
+				if (outside && to_grid < 0.0f) { // the ray never reaches the occupancy grid: it would leave the render box without a sample
+					ends = true;
+				} else if (outside && to_grid > 0.0f) {
+					ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
+				} else {
+					ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
+				}
+				++skip_i;
+			}
+			if (ends) {
+				if (n_pend == 0) {
+					ray.alive = false;
+					finished = true;
+				} else {
+					left_box = true; // its waiting samples are composited first
+				}
+			}
+			// ---- K3: the wave64 counterpart of compact_kernel_nerf -- emitting lanes take consecutive slots (ballot + prefix count)
+			const unsigned long long emit_mask = __ballot(emit);
+			if (emit_mask) {
+				const uint32_t slot = n_slots + lanes_below(emit_mask);
+				bool newly_counted = false;
+				if (emit) {
+					newly_counted = !counted;
+					counted = true;
+					if (slot < (uint32_t)SLOTS) {
+						s_samp[wave_base + slot] = make_float4(e_w.x, e_w.y, e_w.z, warp_dt(e_dt));
+						s_res[wave_base + slot].x = (uint32_t)lane;
+						if (n_pend < 4u) sl_lo |= slot << (8u * n_pend);
+						else sl_hi |= slot << (8u * (n_pend - 4u));
+						++n_pend;
+						ray.t = ray.t + e_dt;
+						skip_i = 1;
+					} else {
+						blocked = true;
+					}
+				}
+				n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
+				n_slots += (uint32_t)__popcll(emit_mask);
+				n_slots = n_slots > (uint32_t)SLOTS ? (uint32_t)SLOTS : n_slots;
+			}
+		}
+		const bool can_march = __any(ray.alive && !left_box && !blocked && (int)n_pend < k_max);
 		if (PROF) {
 			t1 = stamp(); pt[1] += t1 - t0; t0 = t1; ++p_iters; tr_t[2] = t1;
-			tr_info0 = (uint32_t)n_ready | ((uint32_t)stall << 24);
-			tr_info1 |= (uint32_t)__popcll(__ballot(ray.alive)) | ((uint32_t)__popcll(__ballot(ray.alive && !ready)) << 8) | ((uint32_t)__popcll(__ballot(crole > 0)) << 16) |
+			tr_info0 = n_slots | ((uint32_t)stall << 24);
+			tr_info1 |= (uint32_t)__popcll(__ballot(ray.alive)) | ((uint32_t)__popcll(__ballot(ray.alive && !left_box && n_pend == 0)) << 8) | ((uint32_t)k_max << 16) |
 			            ((exhausted ? 1u : 0u) << 24);
 		}
-		if (n_ready == 0) {
+		if (n_slots == 0) {
 			trace_emit(2);
-			if (exhausted && !__any(ray.alive) && !__any(finished)) break;
+			if (exhausted && !__any(ray.alive) && !__any(finished)) {
+				if (PROBE || !F.tune[7]) break;
+				// ---- out of work: ask a busy wave of this workgroup for half of its rays; leave when no wave of the workgroup has any
+				if (!idle) {
+					idle = true;
+					if (lane == 0) atomicSub(&s_active, 1u);
+				}
+				bool got = false;
+				for (;;) {
+					uint32_t st = 0, act = 0;
+					if (lane == 0) {
+						st = __hip_atomic_load(&s_xstate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						act = __hip_atomic_load(&s_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					st = __builtin_amdgcn_readfirstlane(st);
+					act = __builtin_amdgcn_readfirstlane(act);
+					if (st == (0x300u | my_wave)) {
+						got = true;
+						break;
+					}
+					if (act == 0u) break; // (a donor raises s_active before it publishes, so rays on their way to this wave keep it above 0)
+					if (st == 0u && lane == 0) atomicCAS(&s_xstate, 0u, 0x100u | my_wave);
+					__builtin_amdgcn_s_sleep(32);
+				}
+				if (!got) break;
+				const uint32_t n_in = s_xcount;
+				if ((uint32_t)lane < n_in) {
+					const float* x = s_xray + (uint32_t)lane * 16u;
+					ray.o = mk3(x[0], x[1], x[2]);
+					ray.d = mk3(x[3], x[4], x[5]);
+					ray.t = x[6];
+					ray.out = __float_as_uint(x[7]);
+					acc = Accum{x[8], x[9], x[10], x[11], x[12], x[13]};
+					const uint32_t sw = __float_as_uint(x[14]);
+					step = sw & 0x7fffffffu;
+					counted = (sw >> 31) != 0u;
+					ray.idx = __float_as_uint(x[15]);
+					idir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+					ray.alive = true;
+					finished = false;
+					left_box = false;
+					skip_i = 1;
+					n_pend = 0;
+					sl_lo = sl_hi = 0;
+					occ_cache.key = 0xffffffffu;
+				}
+				idle = false;
+				if (lane == 0) __hip_atomic_store(&s_xstate, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // (after the reads above: LDS serves a wave's requests in order)
+			}
 			continue;
 		}
 		// run the network once enough samples wait, or nothing else can make progress; never starve a waiting sample
-		if (n_ready < F.tune[2] && any_marching && stall < F.tune[3]) {
+		if ((int)n_slots < F.tune[2] && can_march && stall < F.tune[3]) {
 			++stall;
 			trace_emit(2);
 			continue;
 		}
-		if (!PROBE && stall < max_links) {
-			// one more round per chain link while there are free slots to continue ready samples
-			const bool can_grow = __any(ray.alive && ready && chain_next < 0 && crole < max_links) && __any(!ray.alive && !finished && crole == 0);
-			if (can_grow || (exhausted && any_marching)) {
-				++stall;
-				trace_emit(2);
-				continue;
-			}
-		}
 		stall = 0;
 
-		// ---- choose the samples of this phase: while marching lanes can still deliver more, only whole 16-sample
-		// passes run and the remainder waits (first in line next time), so no MFMA pass and no gather runs part-filled
-		int n_run = n_ready;
-		if (any_marching && n_ready > 16 && F.tune[3] < 16 && max_links == 0) n_run = n_ready & ~15;
-		const unsigned long long held_mask = __ballot(ready && held);
-		const uint32_t rank = (ready && held) ? lanes_below(held_mask) : (uint32_t)__popcll(held_mask) + lanes_below(ready_mask & ~held_mask);
-		const bool run = ready && rank < (uint32_t)n_run;
-		held = ready && !run;
-		const unsigned long long run_mask = __ballot(run);
-		n_ready = n_run;
-		// ---- compact them onto MFMA sample slots: a bijection lane -> slot (running lanes first)
-		uint32_t my_slot = run ? rank : (uint32_t)n_run + lanes_below(~run_mask);
-		int slot_owner = __builtin_amdgcn_ds_permute((int)(my_slot * 4u), lane); // lane k learns who owns slot k
-
-		// ---- K5: network, 16 samples per pass; two passes are run together whenever 17+ samples wait, so that 32
-		// gathers per lane and two independent MFMA chains are in flight (the loop is latency-, not issue-bound)
-		half_t o_r = 0, o_g = 0, o_b = 0, o_s = 0;
-		float o_nx = 0.f, o_ny = 0.f, o_nz = 0.f; // NORMALS: d logit / d warped position of the lane's sample
-		const int n_pass = (n_ready + 15) >> 4;
-		const int wave_base = threadIdx.x & ~63;
+		// ---- K5: network, 16 samples per pass straight from the list; two passes are run together whenever 17+ samples wait, so that
+		// 32 gathers per lane and two independent MFMA chains are in flight (the loop is latency-, not issue-bound)
+		const int n_pass = (int)((n_slots + 15u) >> 4);
 		const int hq = lane >> 4;
-		const int from = (int)(my_slot & 15u);
-		const int my_pass = (int)(my_slot >> 4);
 		auto sample_of = [&](int p, float& sx, float& sy, float& sz, Sh4& shq) {
-			int src = __shfl(slot_owner, 16 * p + c, 64);
-			sx = __shfl(wx, src, 64);
-			sy = __shfl(wy, src, 64);
-			sz = __shfl(wz, src, 64);
+			const float4 a = s_samp[wave_base + 16 * p + c];
+			const uint32_t owner = s_res[wave_base + 16 * p + c].x;
+			sx = a.x; sy = a.y; sz = a.z;
 			union { uint2 u; half_t h[4]; } cv; // the 4 SH coefficients this lane group feeds to the rgb head
-			cv.u = s_sh[(wave_base + src) * 4 + hq];
+			cv.u = s_sh[(wave_base + (int)owner) * 4 + hq];
 #pragma unroll
 			for (int j = 0; j < 4; ++j) shq.v[j] = cv.h[j];
 		};
-		auto deliver = [&](int p, const MlpOut& mo) {
-			// results live in lanes 0..15 (h == 0); the owner of slot 16p+c pulls them from lane c
-			union { half_t h[2]; int i; } lo, hi;
-			lo.h[0] = mo.rgb[0]; lo.h[1] = mo.rgb[1];
-			hi.h[0] = mo.rgb[2]; hi.h[1] = mo.sigma;
-			int rlo = __shfl(lo.i, from, 64), rhi = __shfl(hi.i, from, 64);
-			if (my_pass == p) {
-				lo.i = rlo; hi.i = rhi;
-				o_r = lo.h[0]; o_g = lo.h[1]; o_b = hi.h[0]; o_s = hi.h[1];
-			}
+		auto deliver = [&](int p, const MlpOut& mo) { // results live in lanes 0..15 (h == 0): slot 16p + c
+			union { half_t h[4]; uint2 u; } o;
+			o.h[0] = mo.rgb[0]; o.h[1] = mo.rgb[1]; o.h[2] = mo.rgb[2]; o.h[3] = mo.sigma;
+			if (lane < 16) s_res[wave_base + 16 * p + lane] = o.u;
 		};
 		int p = 0;
 		if (NORMALS) {
@@ -452,15 +498,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					dg.g[k] += __shfl_xor(dg.g[k], 16, 64);
 					dg.g[k] += __shfl_xor(dg.g[k], 32, 64);
 				}
-				union { half_t h[2]; int i; } sg;
-				sg.h[0] = dg.sigma; sg.h[1] = 0;
-				const float rx = __shfl(dg.g[0], from, 64), ry = __shfl(dg.g[1], from, 64), rz = __shfl(dg.g[2], from, 64);
-				const int rs = __shfl(sg.i, from, 64);
-				if (my_pass == p) {
-					sg.i = rs;
-					o_s = sg.h[0];
-					o_nx = rx * (1.0f / 128.0f); o_ny = ry * (1.0f / 128.0f); o_nz = rz * (1.0f / 128.0f);
-				}
+				if (lane < 16) s_nrm[wave_base + 16 * p + lane] = make_float4(dg.g[0] * (1.0f / 128.0f), dg.g[1] * (1.0f / 128.0f), dg.g[2] * (1.0f / 128.0f), (float)dg.sigma);
 			}
 		}
 		unsigned long long u0 = 0, u1 = 0;
@@ -505,87 +543,69 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 			if (PROF >= 2) lap(4, false);
 		}
 
-		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; tr_t[3] = t1; tr_info0 |= ((uint32_t)n_ready << 8) | ((uint32_t)n_pass << 16); }
-		// ---- K6: composite_kernel_nerf (:569-726), Shade mode
-		// one sample (network outputs, warped dt, depth of the sample along the camera axis) onto this lane's ray
-		auto composite = [&](half_t sr, half_t sg, half_t sb, half_t ss, float swdt, float sdepth, f3 spos) {
-			float T = 1.0f - acc.a;
-			float dt = unwarp_dt(swdt);
-			float alpha = 1.0f - fast_exp(-network_to_density((float)ss, M.density_act) * dt);
-			float weight = alpha * T;
-			float cr = network_to_rgb((float)sr, M.rgb_act), cg = network_to_rgb((float)sg, M.rgb_act), cb = network_to_rgb((float)sb, M.rgb_act);
-			if (!PROBE && F.render_mode > 1) { // src/testbed_nerf.cu:689-702
-				if (NORMALS) { // :688-693: opposite to the density gradient
-					const float dd = network_to_density_derivative((float)ss, M.density_act);
-					const f3 nrm = normalize3(mk3(-dd * o_nx, -dd * o_ny, -dd * o_nz));
-					cr = nrm.x; cg = nrm.y; cb = nrm.z;
-				} else if (F.render_mode == 2) {
-					cr = cg = cb = alpha;
-				} else if (F.render_mode == 3) {
-					cr = (spos.x - 0.5f) / 2.0f + 0.5f; cg = (spos.y - 0.5f) / 2.0f + 0.5f; cb = (spos.z - 0.5f) / 2.0f + 0.5f;
-				} else {
-					cr = cg = cb = dot3(cam_fwd, sub3(spos, ray.o)) * F.depth_scale;
+		if (PROF) { t1 = stamp(); pt[2] += t1 - t0; t0 = t1; p_passes += (unsigned long long)n_pass; tr_t[3] = t1; tr_info0 |= (n_slots << 8) | ((uint32_t)n_pass << 16); }
+		// ---- K6: composite_kernel_nerf (:569-726): every lane takes its own samples in emission order and stops where its ray ends
+		for (uint32_t k = 0;; ++k) {
+			const bool have = k < n_pend && ray.alive;
+			if (!__any(have)) break;
+			if (have) {
+				const uint32_t slot = ((k < 4u ? sl_lo >> (8u * k) : sl_hi >> (8u * (k - 4u))) & 0xffu);
+				const float4 a = s_samp[wave_base + slot];
+				union { uint2 u; half_t h[4]; } o;
+				o.u = s_res[wave_base + slot];
+				float gx = 0.f, gy = 0.f, gz = 0.f;
+				if (NORMALS) {
+					const float4 g = s_nrm[wave_base + slot];
+					gx = g.x; gy = g.y; gz = g.z;
+					o.h[3] = (half_t)g.w;
+				}
+				const f3 pos = add3(amin, mul3(mk3(a.x, a.y, a.z), adiag)); // unwarp_position
+				const float sdepth = dot3(cam_fwd, sub3(pos, cam_pos));
+				float T = 1.0f - acc.a;
+				float dt = unwarp_dt(a.w);
+				float alpha = 1.0f - fast_exp(-network_to_density((float)o.h[3], M.density_act) * dt);
+				float weight = alpha * T;
+				float cr = network_to_rgb((float)o.h[0], M.rgb_act), cg = network_to_rgb((float)o.h[1], M.rgb_act), cb = network_to_rgb((float)o.h[2], M.rgb_act);
+				if (!PROBE && F.render_mode > 1) { // src/testbed_nerf.cu:689-702
+					if (NORMALS) { // :688-693: opposite to the density gradient
+						const float dd = network_to_density_derivative((float)o.h[3], M.density_act);
+						const f3 nrm = normalize3(mk3(-dd * gx, -dd * gy, -dd * gz));
+						cr = nrm.x; cg = nrm.y; cb = nrm.z;
+					} else if (F.render_mode == 2) {
+						cr = cg = cb = alpha;
+					} else if (F.render_mode == 3) {
+						cr = (pos.x - 0.5f) / 2.0f + 0.5f; cg = (pos.y - 0.5f) / 2.0f + 0.5f; cb = (pos.z - 0.5f) / 2.0f + 0.5f;
+					} else {
+						cr = cg = cb = dot3(cam_fwd, sub3(pos, ray.o)) * F.depth_scale;
+					}
+				}
+				acc.r += cr * weight;
+				acc.g += cg * weight;
+				acc.b += cb * weight;
+				acc.a += weight;
+				if (weight > acc.max_weight) {
+					acc.max_weight = weight;
+					acc.depth = sdepth;
+				}
+				++step;
+				if (acc.a > (1.0f - F.min_transmittance)) {
+					acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
+					ray.alive = false;
+					finished = true;
+				} else if (step >= MARCH_ITER) {
+					ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
 				}
 			}
-			acc.r += cr * weight;
-			acc.g += cg * weight;
-			acc.b += cb * weight;
-			acc.a += weight;
-			if (weight > acc.max_weight) {
-				acc.max_weight = weight;
-				acc.depth = sdepth;
-			}
-			++step;
-			if (acc.a > (1.0f - F.min_transmittance)) {
-				acc.r /= acc.a; acc.g /= acc.a; acc.b /= acc.a; acc.a /= acc.a;
-				ray.alive = false;
-				finished = true;
-			} else if (step >= MARCH_ITER) {
-				ray.alive = false; // never compacted into the hit buffer by the reference loop (:2056)
-			}
-		};
-		float my_depth = 0.f;
-		if (run) {
-			ready = false;
-			f3 pos = add3(amin, mul3(mk3(wx, wy, wz), adiag)); // unwarp_position
-			my_depth = dot3(cam_fwd, sub3(pos, cam_pos));
-			if (crole == 0) composite(o_r, o_g, o_b, o_s, wdt, my_depth, pos);
+			n_samples += (uint32_t)__popcll(__ballot(have));
 		}
-		n_samples += (uint32_t)__popcll(__ballot(run && crole == 0));
-		if (!PROBE && __any(chain_next >= 0)) {
-			// ---- walk the continuations in order; the walk ends where the ray ends or where a link did not run
-			int cur = (run && crole == 0 && ray.alive) ? chain_next : -1;
-			union { half_t h[2]; int i; } mlo, mhi;
-			mlo.h[0] = o_r; mlo.h[1] = o_g;
-			mhi.h[0] = o_b; mhi.h[1] = o_s;
-			const int link_ok = (run && crole > 0) ? 1 : 0;
-			for (int j = 1; j < MAX_CHAIN; ++j) {
-				if (!__any(cur >= 0)) break;
-				const int src = cur >= 0 ? cur : lane;
-				const int l_ok = __shfl(link_ok, src, 64);
-				union { half_t h[2]; int i; } llo, lhi;
-				llo.i = __shfl(mlo.i, src, 64);
-				lhi.i = __shfl(mhi.i, src, 64);
-				const float l_wdt = __shfl(wdt, src, 64), l_depth = __shfl(my_depth, src, 64), l_t = __shfl(ray.t, src, 64);
-				const int l_next = __shfl(chain_next, src, 64);
-				n_samples += (uint32_t)__popcll(__ballot(cur >= 0 && l_ok != 0));
-				if (cur >= 0 && l_ok) {
-					composite(llo.h[0], llo.h[1], lhi.h[0], lhi.h[1], l_wdt, l_depth, mk3(0.f, 0.f, 0.f));
-					ray.t = l_t;
-					cur = ray.alive ? l_next : -1;
-				} else {
-					cur = -1;
-				}
-			}
-			// continuations live for one network phase
-			if (crole > 0) {
-				ray.alive = false;
-				ready = false;
-				held = false;
-				crole = 0;
-			}
-			chain_next = -1;
+		if (left_box && ray.alive) { // the ray had left the render box behind its last sample
+			ray.alive = false;
+			finished = true;
 		}
+		left_box = false;
+		n_pend = 0;
+		sl_lo = sl_hi = 0;
+		n_slots = 0;
 		if (PROF) { t1 = stamp(); pt[3] += t1 - t0; tr_t[4] = t1; trace_emit(4); }
 	}
 	if (PROF) { // per-lane skip steps by jump size: reduce over the wave first
@@ -626,9 +646,13 @@ __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelPa
 	fused_body<false, false, true>(M, C, F, P);
 }
 // the same for a static pinhole camera without depth of field or environment map -- the frame a benchmark or a screenshot renders
-__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
+// threads per workgroup of the benchmark instantiation. Waves share rays inside a workgroup (knob 7), so a larger one balances better:
+// 768 (one 12-wave workgroup per CU) renders one 1080p frame at a time 2 % faster, but such a workgroup holds its CU until its last
+// wave is done, and overlapped frames / a rank's share lose 2-10 %; 384 or 512 leave SIMDs half empty (wave placement). Measured, 256 stays.
+constexpr int FB_UNIT_PLAIN = BLOCK;
+__global__ __launch_bounds__(FB_UNIT_PLAIN, 3) void render_nerf_fused_unit_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	fused_body<false, false, true, 1, true, 1, true>(M, C, F, P);
+	fused_body<false, 0, true, 1, true, 1, true, false, FB_UNIT_PLAIN>(M, C, F, P);
 }
 __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
@@ -1049,10 +1073,20 @@ __global__ void accumulate_tonemap_kernel(uint32_t n_pixels, const float4* __res
 // Persistent grids are sized to what is resident at once (workgroups per CU from the occupancy query): a workgroup
 // that only starts when another one has drained would begin its rays late and stretch the frame by a ray lifetime.
 template <typename K>
-static int resident_blocks_per_cu(K kernel) {
+static int resident_blocks_per_cu(K kernel, int threads = BLOCK) {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 1;
 	return n;
+}
+// the persistent grid of a frame: what is resident, but no more waves than tiles
+static int grid_blocks(const FrameParams& F, int resident, int threads = BLOCK) {
+	const int waves = threads / 64, needed = (int)((F.n_local_tiles + waves - 1) / waves); // one tile per wave at least
+	return resident > needed ? (needed > 0 ? needed : 1) : resident;
+}
+static FrameParams with_grid(const FrameParams& F, int n_blocks, int threads = BLOCK) {
+	FrameParams G = F;
+	G.n_waves = (uint32_t)n_blocks * (threads / 64);
+	return G;
 }
 void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream);
@@ -1062,21 +1096,15 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	const bool c5 = !unit && M.max_cascade < 5 && !F.outside_possible;
 	if (F.render_mode == 7) { // ERenderMode::Normals: the density head only, whatever the rgb head
 		static const int per_cu_normals = resident_blocks_per_cu(render_nerf_fused_normals);
-		int nb = n_cus * per_cu_normals;
-		const int need = (int)((F.n_local_tiles + 3) / 4);
-		if (nb > need) nb = need > 0 ? need : 1;
-		FrameParams G = F;
-		G.n_waves = (uint32_t)nb * (BLOCK / 64);
+		const int nb = grid_blocks(F, n_cus * per_cu_normals);
+		const FrameParams G = with_grid(F, nb);
 		hipLaunchKernelGGL(render_nerf_fused_normals, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		return;
 	}
 	if (M.rgb_mid != 1) { // the base_1layer / base_3layer heads: one general kernel each
 		static const int per_cu_mid0 = resident_blocks_per_cu(render_nerf_fused_mid0), per_cu_mid2 = resident_blocks_per_cu(render_nerf_fused_mid2);
-		int nb = n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2);
-		const int need = (int)((F.n_local_tiles + 3) / 4);
-		if (nb > need) nb = need > 0 ? need : 1;
-		FrameParams G = F;
-		G.n_waves = (uint32_t)nb * (BLOCK / 64);
+		const int nb = grid_blocks(F, n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2));
+		const FrameParams G = with_grid(F, nb);
 		if (M.rgb_mid == 0) hipLaunchKernelGGL(render_nerf_fused_mid0, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		else hipLaunchKernelGGL(render_nerf_fused_mid2, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		return;
@@ -1084,7 +1112,7 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	static const int per_cu_generic = resident_blocks_per_cu(render_nerf_fused), per_cu_unit = resident_blocks_per_cu(render_nerf_fused_unit),
 	                 per_cu_prof = resident_blocks_per_cu(render_nerf_fused_prof), per_cu_c5 = resident_blocks_per_cu(render_nerf_fused_c5),
 	                 per_cu_unit_plain_prof = resident_blocks_per_cu(render_nerf_fused_unit_plain_prof), per_cu_unit_plain_prof2 = resident_blocks_per_cu(render_nerf_fused_unit_plain_prof2),
-	                 per_cu_unit_plain = resident_blocks_per_cu(render_nerf_fused_unit_plain), per_cu_c5_plain = resident_blocks_per_cu(render_nerf_fused_c5_plain);
+	                 per_cu_unit_plain = resident_blocks_per_cu(render_nerf_fused_unit_plain, FB_UNIT_PLAIN), per_cu_c5_plain = resident_blocks_per_cu(render_nerf_fused_c5_plain);
 	const bool plain = C.lens_mode == 0 && C.aperture_size == 0.0f && !C.moving && !F.envmap;
 	int per_cu = F.prof ? (unit && plain ? (F.prof_level >= 2 ? per_cu_unit_plain_prof2 : per_cu_unit_plain_prof) : per_cu_prof) : unit ? (plain ? per_cu_unit_plain : per_cu_unit) : c5 ? (plain ? per_cu_c5_plain : per_cu_c5) : per_cu_generic;
 	// a rank of a sharded frame leaves a third of every CU to the collective's kernels and to the next frame's launch
@@ -1092,15 +1120,14 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	static const int shard_per_cu = []() { const char* e = getenv("NGP_SHARD_BLOCKS_PER_CU"); int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }(); // experiments: tools/shard_probe.py
 	if (F.shard_count > 1 && per_cu > shard_per_cu) per_cu = shard_per_cu;
 	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
-	int n_blocks = n_cus * per_cu;
-	const int needed = (int)((F.n_local_tiles + 3) / 4); // one tile per wave at least
-	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-	FrameParams G = F;
-	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
+	const int threads = (!F.prof && unit && plain) ? FB_UNIT_PLAIN : BLOCK;
+	if (F.shard_count > 1 && threads != BLOCK) per_cu = per_cu * threads > 2 * BLOCK ? ((2 * BLOCK) / threads > 0 ? (2 * BLOCK) / threads : 1) : per_cu; // (a rank's share: two thirds of the CU, as above)
+	const int n_blocks = grid_blocks(F, n_cus * per_cu, threads);
+	const FrameParams G = with_grid(F, n_blocks, threads);
 	if (F.prof && unit && plain && F.prof_level >= 2) hipLaunchKernelGGL(render_nerf_fused_unit_plain_prof2, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (F.prof && unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (F.prof) hipLaunchKernelGGL(render_nerf_fused_prof, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
-	else if (unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
+	else if (unit && plain) hipLaunchKernelGGL(render_nerf_fused_unit_plain, dim3(n_blocks), dim3(FB_UNIT_PLAIN), 0, stream, M, C, G);
 	else if (unit) hipLaunchKernelGGL(render_nerf_fused_unit, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (c5 && plain) hipLaunchKernelGGL(render_nerf_fused_c5_plain, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
 	else if (c5) hipLaunchKernelGGL(render_nerf_fused_c5, dim3(n_blocks), dim3(BLOCK), 0, stream, M, C, G);
@@ -1109,11 +1136,8 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 void launch_trace_probe(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream) {
 	if (M.wide.width) return launch_trace_probe_wide(M, F, P, n_cus, stream);
 	static const int per_cu = resident_blocks_per_cu(trace_probe_fused);
-	int n_blocks = n_cus * per_cu;
-	const int needed = (int)((F.n_local_tiles + 3) / 4);
-	if (n_blocks > needed) n_blocks = needed > 0 ? needed : 1;
-	FrameParams G = F;
-	G.n_waves = (uint32_t)n_blocks * (BLOCK / 64);
+	const int n_blocks = grid_blocks(F, n_cus * per_cu);
+	const FrameParams G = with_grid(F, n_blocks);
 	hipLaunchKernelGGL(trace_probe_fused, dim3(n_blocks), dim3(BLOCK), 0, stream, M, G, P);
 }
 void launch_probe_reduce(const ProbeParams& P, float4* envmap, hipStream_t stream) {

@@ -1052,7 +1052,7 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 // advance a ray): a GPU hang, not an error. Hence one gate for every way of setting them.
 void validate_schedule(const int32_t* t, int n) {
 	static const struct { const char* name; int lo, hi; } range[8] = {{"refill_min", 16, 64}, {"skip_steps", 1, 64},  {"go_min", 1, 64},      {"max_stall", 0, 64},
-	                                                                  {"links_busy", 0, 3},   {"links_drain", 0, 3},  {"block_jumps", 0, 1}, {"spare", 0, 0}};
+	                                                                  {"k_busy", 1, 8},       {"k_drain", 1, 8},      {"block_jumps", 0, 1}, {"share", 0, 1}};
 	if (n < 0 || n > 8) throw std::runtime_error("schedule: at most 8 knobs");
 	for (int i = 0; i < n; ++i)
 		if (t[i] < range[i].lo || t[i] > range[i].hi)

@@ -247,7 +247,7 @@ struct ngp_ctx {
 	unsigned long long* d_prof = nullptr;
 	uint32_t* d_trace = nullptr; // wave timelines of the diagnostic build (NGP_PROFILE_TRACE)
 	static constexpr uint32_t TRACE_WAVES = 64, TRACE_ITERS = 1024;
-	int32_t tune[8] = {64, 4, 32, 1, 0, 3, 1, 0}; // FrameParams::tune; changed only through validate_schedule (ngp_api.cpp)
+	int32_t tune[8] = {64, 4, 32, 1, 1, 4, 1, 1}; // FrameParams::tune; changed only through validate_schedule (ngp_api.cpp)
 
 	// ---- several devices behind this context (ngp_multi.cpp): replicas on the auxiliary devices, tile gather at the primary
 	std::vector<ngp_ctx*> peers;  // owned; empty for a single-device context

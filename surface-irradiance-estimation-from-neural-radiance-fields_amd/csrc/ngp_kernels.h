@@ -133,8 +133,9 @@ struct FrameParams {
 	int32_t linear_colors;
 	int32_t depth_test;
 	int32_t packed;           // 1: pixel (local tile q, slot s) is written at q*64+s (tile-packed layout for the RCCL gather) instead of x+W*y
-	int32_t tune[8];          // refill_min, skip_steps, go_min, max_stall, chain links while tiles remain / once the queue is empty,
-	                          // block_jumps (0: the reference's one-voxel steps only), spare (nerf_kernels.hip; validated by ngp_set_schedule)
+	int32_t tune[8];          // refill_min, skip_steps, go_min, max_stall, samples a ray may emit per round while most of a wave's ray slots are live /
+	                          // at most, block_jumps (0: the reference's one-voxel steps only), share (a wave without work takes over half the
+	                          // rays of a busy wave of its workgroup) -- nerf_kernels.hip; validated by ngp_set_schedule
 	// direct output (1 spp, no mesh pass): the kernel writes the final pixel -- accumulate_kernel + tonemap_kernel
 	// (src/render_buffer.cu:228-262, 529-561) folded into ray setup / shading -- into frame_buffer = the caller's image
 	int32_t outside_possible; // the render box is not contained in the outermost cascade's cube (kernel selection)

@@ -329,7 +329,7 @@ class Context:
             raise RuntimeError(self.L.ngp_last_error(self.h).decode(errors="replace"))
 
     def set_schedule(self, *knobs):
-        """refill_min, skip_steps, go_min, max_stall, links_busy, links_drain, block_jumps (ngp_set_schedule: validated)"""
+        """refill_min, skip_steps, go_min, max_stall, k_busy, k_drain, block_jumps, share (ngp_set_schedule: validated)"""
         a = np.asarray(knobs, np.int32)
         self._check(self.L.ngp_set_schedule(self.h, _p(a), a.size))
 

@@ -170,11 +170,11 @@ def test_tile_sharding_and_block_jump_knob(ctx, native, scene_mod, scene_freq):
         total += part
     assert np.array_equal(total, full)
     st_on = ctx.render_stats()
-    ctx.set_schedule(64, 4, 32, 1, 0, 3, 0)  # block_jumps = 0 (the other knobs, at their defaults, belong to the base.json kernel)
+    ctx.set_schedule(64, 4, 32, 1, 1, 4, 0)  # block_jumps = 0 (the other knobs, at their defaults, belong to the base.json kernel)
     try:
         exact = ctx.render(cam, native.make_opts(background=bg0))
     finally:
-        ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
+        ctx.set_schedule(64, 4, 32, 1, 1, 4, 1)
     d = np.abs(exact - full).max(-1)
     assert np.median(d) < 1e-3 and (d > 1e-2).mean() < 2e-3
 

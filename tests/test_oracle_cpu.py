@@ -284,6 +284,53 @@ def test_network_against_numpy_float64(oracle, scene_mod, scene_unit):
     oracle.release(m)
 
 
+def test_mlp_accumulation_modes_against_numpy(oracle, scene_mod, scene_unit):
+    """The two modes that bracket / measure the reference's fp16-accumulating FullyFusedMLP (oracle.h, orc_nerf_model::mlp_accumulate):
+    "fp16_k16" (the running sum rounded to fp16 after every 16-wide block of the inner dimension) against an independent numpy
+    restatement, bit for bit; "ideal" (float64, no intermediate rounding) against float64 numpy on the oracle's own encodings being
+    replaced by float64 interpolation -- checked through its distance from the default mode, which is bounded by fp16 rounding."""
+    rng = np.random.default_rng(11)
+    pos = rng.uniform(0.2, 0.8, (384, 3)).astype(np.float32)
+    d = rng.normal(size=(384, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dir01 = ((d + 1) * 0.5).astype(np.float32)
+    sc = dict(scene_unit)
+    m_exact = oracle.make_model(sc)
+    enc = oracle.grid_encode(m_exact, pos).astype(np.float64)
+    sh = oracle.sh4(dir01).astype(np.float64)
+    p = sc["params"].view(np.float16).astype(np.float64)
+    W0, W1 = p[:2048].reshape(64, 32), p[2048:3072].reshape(16, 64)
+    R0, R1, R2 = p[3072:5120].reshape(64, 32), p[5120:9216].reshape(64, 64), p[9216:10240].reshape(16, 64)
+
+    def layer_k16(x, W, relu):  # x: [n, k] float64 holding fp16 values
+        acc = np.zeros((x.shape[0], W.shape[0]), np.float16)
+        for k0 in range(0, W.shape[1], 16):
+            acc = (acc.astype(np.float64) + x[:, k0:k0 + 16] @ W[:, k0:k0 + 16].T).astype(np.float16)  # one rounding per block (float64 -> fp16 is a single RN)
+        a = acc.astype(np.float64)
+        return np.maximum(a, 0) if relu else a
+
+    dens = layer_k16(layer_k16(enc, W0, True), W1, False)
+    rin = np.concatenate([dens, sh], axis=1)
+    rgb = layer_k16(layer_k16(layer_k16(rin, R0, True), R1, True), R2, False)
+    ref = np.concatenate([rgb[:, :3], dens[:, :1]], axis=1)
+    sc["mlp_accumulate"] = "fp16_k16"
+    m_k16 = oracle.make_model(sc)
+    got_k16 = oracle.network(m_k16, pos, dir01).astype(np.float64)
+    assert np.array_equal(got_k16, ref)
+    got_exact = oracle.network(m_exact, pos, dir01).astype(np.float64)
+    sc["mlp_accumulate"] = "ideal"
+    m_ideal = oracle.make_model(sc)
+    got_ideal = oracle.network(m_ideal, pos, dir01).astype(np.float64)  # (this interface rounds the float64 logits to fp16 once)
+    # float64 everything: a numpy restatement of the MLPs on float64 interpolation is what "ideal" is; here the cheap property --
+    # both fp16 pipelines scatter around it, fp16 accumulation further than exact sums
+    e_exact, e_k16 = np.abs(got_exact - got_ideal), np.abs(got_k16 - got_ideal)
+    assert e_exact.max() < 0.05 and e_k16.max() < 0.1, (e_exact.max(), e_k16.max())
+    assert np.sqrt((e_exact ** 2).mean()) <= np.sqrt((e_k16 ** 2).mean())
+    assert not np.array_equal(got_k16, got_exact)
+    for m in (m_exact, m_k16, m_ideal):
+        oracle.release(m)
+
+
 def test_sampling_sequences(oracle):
     # Owen-scrambled Sobol: values in [0,1], deterministic, and (0,2)-stratified: any 2^k consecutive indices hit
     # every dyadic interval of length 2^-k once

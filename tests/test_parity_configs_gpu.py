@@ -116,6 +116,34 @@ def test_bench_model_encode_and_render(gpu_ctx, oracle, native, scene_mod, scene
     oracle.release(m)
 
 
+# ---------------------------------------------------------------------------------------- fp16 vs fp32 accumulation in the MLPs
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["bench", "garden"])
+def test_mlp_accumulation_bracket(which, gpu_ctx, oracle, scene_mod, scene_bench, scene_garden):
+    """The reference's FullyFusedMLP accumulates in fp16 WMMA fragments (nerf_network.h:120,130), this build in fp32 MFMA
+    accumulators; the reference cannot run here. Both are measured against the float64 network (oracle modes, oracle.h): the HIP
+    frame must be at least as close to it as the fp16-accumulating model of the reference is, and its distance from that model --
+    the bound on 'PSNR within 0.1 dB of the CUDA reference' that BASELINE.md states -- must stay above 65 dB."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("mlp_bracket", os.path.join(os.path.dirname(HERE), "tools", "mlp_bracket.py"))
+    mb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mb)
+    sc, view = (scene_bench, (45.0, 30.0, 4.03)) if which == "bench" else (scene_garden, (40.0, 25.0, 4.03))
+    r = mb.bracket(oracle, gpu_ctx, sc, scene_mod.orbit_camera(*view), 256, 144)
+    print(which, r)
+    assert r["hit"] > 0.2 * 256 * 144
+    assert r["psnr_exact_vs_ideal"] >= r["psnr_fp16_k16_vs_ideal"]
+    if which == "bench":  # cone angle 0: with block_jumps = 0 the HIP frame has the oracle's sample sets, the comparison is arithmetic only
+        assert r["psnr_hip_vs_ideal"] >= r["psnr_fp16_k16_vs_ideal"] - 0.5
+        assert r["psnr_hip_vs_ideal"] >= 70.0 and r["psnr_hip_vs_fp16_k16"] >= 70.0
+    else:
+        # exponential stepping: device logf / expf differ from glibc by an ulp, some rays gain or lose a sample (max |d| ~ 0.09 on
+        # a handful of pixels, which is all a PSNR at this level sees): compare the typical covered pixel instead
+        assert r["q50_hip_vs_ideal"] <= 1.25 * r["q50_fp16_k16_vs_ideal"]
+        assert r["psnr_hip_vs_ideal"] >= 60.0 and r["psnr_hip_vs_fp16_k16"] >= 60.0
+
+
 # ---------------------------------------------------------------------------------------- garden-shaped / 8 cascades
 @pytest.fixture(scope="module")
 def scene_garden(oracle):
@@ -248,14 +276,14 @@ def test_block_jumps_are_the_only_source_of_sample_set_changes(which, gpu_ctx, o
     ref, _, ost = _oracle_frame(oracle, m, ocam, w, h)
     oracle.release(m)
     try:
-        gpu_ctx.set_schedule(64, 4, 32, 1, 0, 3, 0)
+        gpu_ctx.set_schedule(64, 4, 32, 1, 1, 4, 0)
         off = gpu_ctx.render(cam, native.make_opts())
         st_off = gpu_ctx.render_stats()
-        gpu_ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
+        gpu_ctx.set_schedule(64, 4, 32, 1, 1, 4, 1)
         on = gpu_ctx.render(cam, native.make_opts())
         st_on = gpu_ctx.render_stats()
     finally:
-        gpu_ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
+        gpu_ctx.set_schedule(64, 4, 32, 1, 1, 4, 1)
     d_off = np.abs(off - ref).max(-1)
     d_on = np.abs(on - ref).max(-1)
     changed = np.abs(on - off).max(-1) > 0
@@ -283,11 +311,11 @@ def test_block_jumps_are_the_only_source_of_sample_set_changes(which, gpu_ctx, o
 def test_schedule_knobs_are_validated(native):
     """out-of-range knobs would spin the persistent kernel; they are refused before they reach it."""
     ctx = native.Context(-1)
-    for bad in ((65,), (15,), (64, 0), (64, 4, 0), (64, 4, 32, -1), (64, 4, 32, 1, 4), (64, 4, 32, 1, 0, 3, 2), (64, 4, 32, 1, 0, 3, 1, 1)):
+    for bad in ((65,), (15,), (64, 0), (64, 4, 0), (64, 4, 32, -1), (64, 4, 32, 1, 0), (64, 4, 32, 1, 9), (64, 4, 32, 1, 8, 8, 2), (64, 4, 32, 1, 8, 8, 1, 2)):
         with pytest.raises(RuntimeError, match="schedule knob"):
             ctx.set_schedule(*bad)
-    ctx.set_schedule(32, 8, 16, 2, 1, 2, 0)
-    ctx.set_schedule(64, 4, 32, 1, 0, 3, 1)
+    ctx.set_schedule(32, 8, 16, 2, 1, 2, 0, 0)
+    ctx.set_schedule(64, 4, 32, 1, 1, 4, 1)
     ctx.close()
 
 

@@ -1,6 +1,6 @@
 """Diagnostic: the fixed cost of a frame. Solo frame time (one frame at a time, image left in HBM) of a 256x256 frame, of a
 1080p frame, and of rank 0's share of a 1080p frame cut 8 ways -- the quantities that cap strong scaling over 8 GPUs.
-usage: python tools/latency_probe.py [links_drain ...]   (schedule knob 5: chain links once the tile queue is empty)"""
+usage: python tools/latency_probe.py [k_drain ...]   (schedule knob 5: samples a ray may emit per round once the tile queue is empty)"""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,11 +30,11 @@ def solo(w, h, opts, n=24):
     return wall, float(np.mean([s["kernel_device_ms"] for s in hist])), float(np.mean([s["n_samples"] for s in hist]))
 
 
-for links in [int(a) for a in sys.argv[1:]] or [3]:
-    ctx.set_schedule(64, 4, 32, 1, 0, links, 1)
+for links in [int(a) for a in sys.argv[1:]] or [8]:
+    ctx.set_schedule(64, 4, 32, 1, int(os.environ.get('NGP_KBUSY', '8')), links, 1, int(os.environ.get('NGP_THIN', '1')))
     a = solo(256, 256, native.make_opts())
     b = solo(1920, 1080, native.make_opts())
     c = solo(1920, 1080, native.make_opts(shard_index=0, shard_count=8, packed_output=True))
-    print(f"links_drain {links}: 256x256 wall {a[0]:.3f} ms (kernel {a[1]:.3f}) | 1080p wall {b[0]:.3f} ms (kernel {b[1]:.3f}, {1920 * 1080 / b[0] / 1e3:.0f} Mrays/s) | "
+    print(f"k_drain {links}: 256x256 wall {a[0]:.3f} ms (kernel {a[1]:.3f}) | 1080p wall {b[0]:.3f} ms (kernel {b[1]:.3f}, {1920 * 1080 / b[0] / 1e3:.0f} Mrays/s) | "
           f"1/8 share wall {c[0]:.3f} ms (kernel {c[1]:.3f}) -> 8-way bound {b[0] / c[0]:.2f}x", flush=True)
 ctx.close()

@@ -11,7 +11,7 @@ ctx = native.Context(0)
 ctx.set_model(sc)
 k = int(os.environ.get("K", 6))
 streams = [torch.cuda.Stream() for _ in range(k)]
-for (w, h, shards) in ((680, 382, 1), (1920, 1080, 8)):
+for (w, h, shards) in ((256, 256, 1), (680, 382, 1), (1920, 1080, 8), (1920, 1080, 1)):
     cams = [native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(w, 0.6911)) for az in (0, 45, 90, 135, 180, 225, 270, 315)]
     bufs = [(torch.zeros((h, w, 4), device="cuda"), torch.zeros((h, w), device="cuda")) for _ in range(k)]
     opts = native.make_opts(shard_index=0, shard_count=shards, packed_output=shards > 1)
@@ -27,4 +27,4 @@ for (w, h, shards) in ((680, 382, 1), (1920, 1080, 8)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     st = ctx.render_stats()
-    print(f"{w}x{h} shards {shards}: {dt * 1e3:.4f} ms/frame, {st['n_rays']} rays, {st['n_samples']} samples -> {st['n_samples'] / dt / 1e9:.2f} Gsamples/s")
+    print(f"[NGP_TUNE={os.environ.get('NGP_TUNE', 'default')}, {k} in flight] {w}x{h} shards {shards}: {dt * 1e3:.4f} ms/frame, {st['n_rays']} rays, {st['n_samples']} samples -> {st['n_samples'] / dt / 1e9:.2f} Gsamples/s")

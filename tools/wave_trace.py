@@ -103,4 +103,10 @@ r = rec[longest, :n_it].astype(np.int64)
 for j in list(range(min(24, n_it))) + list(range(max(24, n_it - 8), n_it)):
     print(f"  {j:4d} | {(int(r[j, 0]) - int(r[0, 0])) & 0xffffffff:9d} | {r[j, 1]:6d} {r[j, 2] - r[j, 1]:6d} {r[j, 3] - r[j, 2]:6d} {r[j, 4] - r[j, 3]:6d} | {r[j, 5] & 255:3d} {(r[j, 5] >> 8) & 255:3d} {(r[j, 5] >> 16) & 255:2d} {(r[j, 5] >> 24) & 255:2d} | "
           f"{r[j, 6] & 255:3d} {(r[j, 6] >> 8) & 255:3d} {(r[j, 6] >> 16) & 255:3d} | {(r[j, 6] >> 24) & 255:2d}")
+# ---- the first rounds of a few waves (cold start: first touches of code, occupancy words, table lines)
+print("# first 5 rounds of 8 traced waves: wave | per round: refill/march/network/composite cycles [slots]")
+for (i, *_r) in rows[:64:8]:
+    n_it = min(int(hd[i, 4]), rec.shape[1], 5)
+    r = rec[i, :n_it].astype(np.int64)
+    print(f"  wave {i:2d} (arrives {rows[[q[0] for q in rows].index(i)][1]:.2f} us): " + " | ".join(f"{r[j, 1]}/{r[j, 2] - r[j, 1]}/{r[j, 3] - r[j, 2]}/{r[j, 4] - r[j, 3]} [{r[j, 5] & 255}]" for j in range(n_it)))
 ctx.close()
