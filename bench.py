@@ -36,6 +36,10 @@ FLOP_PER_SAMPLE = 20480.0  # both MLPs
 # lane-loads per clock when every one hits its L1 -- 8 KB table -- whether a lane asks for 4, 8 or 16 bytes). The kernel's gathers are 8-byte lane-loads, 64 per sample = the 512
 # algorithmic bytes, so that ceiling, in the same unit as the algorithmic figure, is
 GATHER_PEAK_GBS = 1.92 * 8.0 * 256 * 2.4  # lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz = 9437 GB/s
+GATHER_PEAK_LANE_LOADS = 1.92  # per clock and CU (profiles/r2_gather_probe.txt, 8 KB table: every load an L1 hit)
+# ngp_set_schedule: refill_min, skip_steps, go_min, max_stall, k_busy, k_drain, block_jumps, share (defaults of csrc/ngp_host.h)
+DEFAULT_SCHEDULE = (64, 4, 32, 1, 1, 4, 1, 1)
+EXACT_MARCH = (64, 4, 32, 1, 1, 4, 0, 1)  # block_jumps = 0: empty space is walked voxel by voxel like the reference -- its exact sample sets
 
 
 def pkg(sub):
@@ -78,6 +82,14 @@ def cpu_baseline(scene_dict, scene_mod, gpu_ctx=None, native=None):
             mse = float(np.mean((np.clip(got[..., :3], 0, 1) - np.clip(ref[..., :3], 0, 1)) ** 2))
             out["psnr_vs_oracle_db"] = round(-10.0 * math.log10(max(mse, 1e-12)), 2)
             out["max_abs_diff_vs_oracle"] = round(float(np.abs(got - ref).max()), 6)
+            out["psnr_is"] = "PSNR vs oracle (parity unpinned): the reference ships no snapshot, test or vector for this path, the oracle restates it"
+            # the same frame with block_jumps = 0 (the march takes the reference's one-voxel steps): the oracle's sample sets
+            gpu_ctx.set_schedule(*EXACT_MARCH)
+            exact = gpu_ctx.render(native.make_camera(scene_mod.orbit_camera(AZIMUTHS[1]), w, h, scene_mod.focal_from_fov_x(w, FOV_X)))
+            gpu_ctx.set_schedule(*DEFAULT_SCHEDULE)
+            mse_e = float(np.mean((np.clip(exact[..., :3], 0, 1) - np.clip(ref[..., :3], 0, 1)) ** 2))
+            out["exact_march_psnr_vs_oracle_db"] = round(-10.0 * math.log10(max(mse_e, 1e-12)), 2)
+            out["exact_march_max_abs_diff_vs_oracle"] = round(float(np.abs(exact - ref).max()), 6)
         except Exception as e:
             out["psnr_vs_oracle_db"] = None
             out["psnr_error"] = str(e)[:160]
@@ -193,6 +205,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training-probe", action="store_true")
+    ap.add_argument("--no-extra-probes", action="store_true", help="skip the exact-march and sharded-share measurements (counter passes: every launch of the run is then a full frame of the default schedule)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("NGP_BENCH_INFLIGHT", "0")),
@@ -308,6 +321,34 @@ def main():
         solo = {"frame_s": solo_dt, "kernel_ms": float(np.mean([x["kernel_ms"] for x in sh])), "kernel_device_ms": float(np.mean([x["kernel_device_ms"] for x in sh])),
                 "n_samples": float(np.mean([x["n_samples"] for x in sh])), "n_rays": float(np.mean([x["n_rays"] for x in sh])), "host_s": host_dt, "pageable_s": pageable_dt, "n": n_solo}
 
+    def in_flight_ms(render_opts, n_frames, k_streams, out_bufs):
+        """ms per frame of `n_frames` frames issued over `k_streams` streams (throughput with frames overlapped, image left in HBM)"""
+        ss = [torch.cuda.Stream(dev) for _ in range(k_streams)]
+        for i in range(2 * k_streams):
+            ctx.render_device(cams[i % len(cams)], render_opts, out_bufs[i % k_streams][0].data_ptr(), out_bufs[i % k_streams][1].data_ptr(), ss[i % k_streams].cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(n_frames):
+            ctx.render_device(cams[i % len(cams)], render_opts, out_bufs[i % k_streams][0].data_ptr(), out_bufs[i % k_streams][1].data_ptr(), ss[i % k_streams].cuda_stream)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t1) / n_frames * 1e3
+
+    exact_ms = None
+    shares = None
+    if world == 1 and args.steps > 0 and not args.no_extra_probes:
+        # the benchmarked schedule leaves empty 4^3 / 16^3 blocks in one step; with block_jumps = 0 the march is the reference's, sample for sample
+        ctx.set_schedule(*EXACT_MARCH)
+        exact_ms = in_flight_ms(opts, min(args.steps, 16), len(streams), outs)
+        ctx.set_schedule(*DEFAULT_SCHEDULE)
+        # scaling readiness on ONE GPU: rank 0's share of the frame cut N ways (tile-packed output, what a rank of an N-GPU job renders),
+        # frames overlapped as bench.py --gpus N overlaps them, and one share at a time; no gather (SURVEY 8e: 34 / 136 us on its own link)
+        shares = {}
+        for n_sh in (2, 4, 8):
+            o_sh = native.make_opts(shard_index=0, shard_count=n_sh, packed_output=True)
+            k_sh = 2 if n_sh <= 2 else 6
+            bufs = [(torch.zeros((h, w, 4), dtype=torch.float32, device=dev), torch.zeros((h, w), dtype=torch.float32, device=dev)) for _ in range(k_sh)]
+            shares[str(n_sh)] = {"in_flight_ms": round(in_flight_ms(o_sh, 48, k_sh, bufs), 4), "frames_in_flight": k_sh, "one_at_a_time_ms": round(in_flight_ms(o_sh, 16, 1, bufs[:1]), 4)}
+
     # outside the timed region: the frame the ranks assembled must be the frame one GPU renders alone
     gather_diff = None
     if world > 1 and rank == 0:
@@ -346,10 +387,22 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         ev = pmc_evidence()
         mfma_tflops = k_samples * FLOP_PER_SAMPLE / (k_ms * 1e-3) / 1e12
+        # which unit binds, by the counters of the committed profile passes of this command (fractions of each unit's ceiling):
+        # "ta" = texture-address / vector-L1 path (lane-loads per clock and CU against the measured all-hit ceiling), "valu" = issue
+        # slots of the vector ALU, "hbm" = HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) against 8 TB/s, "mfma" = matrix pipe
+        util = {}
+        if ev.get("lane_loads_per_clk_per_cu") is not None:
+            util["ta"] = ev["lane_loads_per_clk_per_cu"] / GATHER_PEAK_LANE_LOADS
+        if ev.get("valu_issue_util") is not None:
+            util["valu"] = ev["valu_issue_util"]
+        if ev.get("mfma_pipe_util") is not None:
+            util["mfma"] = ev["mfma_pipe_util"]
+        if ev.get("traffic"):
+            util["hbm"] = ev["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        bound = max(util, key=util.get) if util else "ta"
         roof = {
-            # the binder by the counters (profiles/): texture-address path ~1.5 lane-loads/clk/CU of a 1.6-1.9 ceiling, busy 53-65 %;
-            # VALU issue slots 67 %; HBM 0.37 of peak by measured traffic; MFMA pipe 12 % -- none saturated, the gather path closest
-            "bound": "ta",
+            "bound": bound,
+            "unit_utilisation_from_counters": {k: round(v, 3) for k, v in util.items()},
             "achieved": round(achieved, 2),
             "peak": round(GATHER_PEAK_GBS, 1),
             "unit": "GB/s",
@@ -360,7 +413,7 @@ def main():
             "kernel_ms_how": ("HIP events around launches issued one at a time (%d frames after the timed region)" % solo["n"]) if solo else "device clock, timed region (launches of consecutive frames overlap)",
             "kernel_ms_timed_region_device_clock": round(k_ms_timed, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
-            "peak_is": "measured L1 gather ceiling for 8-byte lane-loads (tools/micro/gather_probe.hip, profiles/r2_gather_probe.txt): 1.92 lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz",
+            "peak_is": "`achieved` / `peak` / `frac` price the algorithmic gather bytes against the measured L1 gather ceiling for 8-byte lane-loads (tools/micro/gather_probe.hip, profiles/r2_gather_probe.txt): 1.92 lane-loads/clk/CU x 8 B x 256 CUs x 2.4 GHz; `bound` names the unit the counters show closest to ITS ceiling",
             "hbm_algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),  # SURVEY 8(d)'s figure: algorithmic bytes against the 8 TB/s HBM peak
             "hbm_traffic_frac": round(ev["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ev.get("traffic") else None,
             "mfma_tflops": round(mfma_tflops, 3),
@@ -398,6 +451,12 @@ def main():
             out["with_host_copy_ms"] = round(solo["host_s"] * 1e3, 4)         # ngp_render into a page-locked, device-mapped host array: the kernels write it over the link themselves (PCIe-inclusive; never `value`)
             out["with_host_copy_mrays"] = round(n_rays / solo["host_s"] / 1e6, 2)
             out["with_host_copy_pageable_mrays"] = round(n_rays / solo["pageable_s"] / 1e6, 2)  # into ordinary (pageable) memory
+        if exact_ms is not None:
+            out["exact_march_ms"] = round(exact_ms, 4)  # block_jumps = 0: the reference's march, the oracle's sample sets (cpu_baseline.exact_march_max_abs_diff_vs_oracle)
+            out["exact_march_mrays"] = round(n_rays / exact_ms / 1e3, 2)
+        if shares is not None:
+            out["sharded_share_ms"] = shares
+            out["sharded_share_speedup_bound"] = {k: round(ms / v["in_flight_ms"], 2) for k, v in shares.items()}  # this run's ms_per_step over a rank's share: compute side only
         if gather_diff is not None:
             out["gathered_frame_max_abs_diff_vs_single_gpu"] = gather_diff  # rank 0's check of the assembled frame, outside the timed region
         if world == 1 and not args.no_cpu_baseline:

@@ -80,30 +80,41 @@ NGP_DEV float div_const(float x, float d, float rc) {
 NGP_DEV float div_stepsize(float x) { return div_const(x, stepsize(), 1.0f / stepsize()); }
 NGP_DEV float div_max_cone_stepsize(float x) { return div_const(x, max_cone_stepsize(), 1.0f / max_cone_stepsize()); }
 
-NGP_DEV float to_stepping_space(float t, float cone_angle) {
-	if (cone_angle <= 1e-5f) return div_stepsize(t);
-	float log1p_c = logf(1.0f + cone_angle);
-	float a = (logf(stepsize()) - logf(log1p_c)) / log1p_c;
-	float b = (logf(max_cone_stepsize()) - logf(log1p_c)) / log1p_c;
-	float at = expf(a * log1p_c);
-	float bt = expf(b * log1p_c);
-	if (t <= at) return div_stepsize(t - at) + a;
-	else if (t <= bt) return logf(t) / log1p_c;
-	else return div_max_cone_stepsize(t - bt) + b;
+// The piecewise map's constants depend on the cone angle alone -- five logf / expf and two divisions that the reference's inline
+// functions form on every call. A persistent kernel forms them once (make_stepping) and carries them; same expressions, same values.
+struct Stepping {
+	float cone_angle, log1p_c, a, b, at, bt;
+};
+NGP_DEV Stepping make_stepping(float cone_angle) {
+	Stepping s;
+	s.cone_angle = cone_angle;
+	s.log1p_c = s.a = s.b = s.at = s.bt = 0.0f;
+	if (cone_angle <= 1e-5f) return s;
+	s.log1p_c = logf(1.0f + cone_angle);
+	s.a = (logf(stepsize()) - logf(s.log1p_c)) / s.log1p_c;
+	s.b = (logf(max_cone_stepsize()) - logf(s.log1p_c)) / s.log1p_c;
+	s.at = expf(s.a * s.log1p_c);
+	s.bt = expf(s.b * s.log1p_c);
+	return s;
 }
-NGP_DEV float from_stepping_space(float n, float cone_angle) {
-	if (cone_angle <= 1e-5f) return n * stepsize();
-	float log1p_c = logf(1.0f + cone_angle);
-	float a = (logf(stepsize()) - logf(log1p_c)) / log1p_c;
-	float b = (logf(max_cone_stepsize()) - logf(log1p_c)) / log1p_c;
-	float at = expf(a * log1p_c);
-	float bt = expf(b * log1p_c);
-	if (n <= a) return (n - a) * stepsize() + at;
-	else if (n <= b) return expf(n * log1p_c);
-	else return (n - b) * max_cone_stepsize() + bt;
+NGP_DEV float to_stepping_space(float t, const Stepping& s) {
+	if (s.cone_angle <= 1e-5f) return div_stepsize(t);
+	if (t <= s.at) return div_stepsize(t - s.at) + s.a;
+	else if (t <= s.bt) return logf(t) / s.log1p_c;
+	else return div_max_cone_stepsize(t - s.bt) + s.b;
 }
-NGP_DEV float advance_n_steps(float t, float cone_angle, float n) { return from_stepping_space(to_stepping_space(t, cone_angle) + n, cone_angle); }
-NGP_DEV float calc_dt(float t, float cone_angle) { return advance_n_steps(t, cone_angle, 1.0f) - t; }
+NGP_DEV float from_stepping_space(float n, const Stepping& s) {
+	if (s.cone_angle <= 1e-5f) return n * stepsize();
+	if (n <= s.a) return (n - s.a) * stepsize() + s.at;
+	else if (n <= s.b) return expf(n * s.log1p_c);
+	else return (n - s.b) * max_cone_stepsize() + s.bt;
+}
+NGP_DEV float advance_n_steps(float t, const Stepping& s, float n) { return from_stepping_space(to_stepping_space(t, s) + n, s); }
+NGP_DEV float calc_dt(float t, const Stepping& s) { return advance_n_steps(t, s, 1.0f) - t; }
+NGP_DEV float to_stepping_space(float t, float cone_angle) { return to_stepping_space(t, make_stepping(cone_angle)); }
+NGP_DEV float from_stepping_space(float n, float cone_angle) { return from_stepping_space(n, make_stepping(cone_angle)); }
+NGP_DEV float advance_n_steps(float t, float cone_angle, float n) { return advance_n_steps(t, make_stepping(cone_angle), n); }
+NGP_DEV float calc_dt(float t, float cone_angle) { return calc_dt(t, make_stepping(cone_angle)); }
 NGP_DEV float warp_dt(float dt) { // nerf_device.cuh:306-309
 	const float max_stepsize = stepsize() * (float)(1u << (NERF_CASCADES - 1));
 	return div_const(dt - stepsize(), max_stepsize - stepsize(), 1.0f / (max_stepsize - stepsize()));
@@ -200,7 +211,10 @@ struct OccBlock {
 	uint32_t key; // (x >> 2) | (y >> 2) << 5 | (z >> 2) << 10 | mip << 15 of the held block; 0xffffffff = none
 	uint2 bits;   // bit (morton & 63) = cell (x & 3, y & 3, z & 3) of the block
 };
-NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip, OccBlock& cache) {
+// lds_mips: the summaries of that many cascades are in LDS (s_coarse), those of the outer ones are read from g_coarse (global, a 4 KB
+// table per cascade that the vector L1 keeps): the five-cascade kernel fits a third workgroup per CU that way.
+NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip, OccBlock& cache,
+                                    uint32_t lds_mips = NERF_CASCADES, const uint32_t* __restrict__ g_coarse = nullptr) {
 	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
 	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
 	const int ix = (int)(pos.x * (float)NERF_GRIDSIZE);
@@ -212,7 +226,8 @@ NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield
 	if (cache.key != key) {
 		const uint32_t b4 = morton3D(x >> 2, y >> 2, z >> 2), b16 = b4 >> 6; // == morton3D(x, y, z) >> 6, >> 12
 		if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
-		if (!((s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] >> (b4 & 31u)) & 1u)) return 4u;
+		const uint32_t cw = mip < lds_mips ? s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] : g_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)];
+		if (!((cw >> (b4 & 31u)) & 1u)) return 4u;
 		cache.bits = *(const uint2*)(bitfield + (size_t)b4 * 8 + (size_t)(NERF_GRID_N_CELLS / 8) * mip);
 		cache.key = key;
 	}
@@ -235,13 +250,16 @@ NGP_DEV float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, float res, float i
 // one go. Every lattice point inside an empty block is in an empty cell, so the chain of per-voxel steps would pass
 // through it without emitting a sample and leave it at the same lattice point: the first one at or after the block's
 // exit (DESIGN.md "Empty-space blocks"). Only the rounding of the exit distance differs (different start point).
-NGP_DEV float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t mip, uint32_t block = 1u) {
+NGP_DEV float advance_to_next_voxel(float t, const Stepping& s, f3 pos, f3 dir, f3 idir, uint32_t mip, uint32_t block = 1u) {
 	const int shift = block == 16u ? 4 : (block == 4u ? 2 : 0);
 	float res = __builtin_ldexpf((float)NERF_GRIDSIZE, -(int)mip - shift);
 	float t_target = t + distance_to_next_voxel(pos, dir, idir, res, __builtin_ldexpf(1.0f / (float)NERF_GRIDSIZE, (int)mip + shift));
-	t = to_stepping_space(t, cone_angle);
-	t_target = to_stepping_space(t_target, cone_angle);
-	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+	t = to_stepping_space(t, s);
+	t_target = to_stepping_space(t_target, s);
+	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), s);
+}
+NGP_DEV float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t mip, uint32_t block = 1u) {
+	return advance_to_next_voxel(t, make_stepping(cone_angle), pos, dir, idir, mip, block);
 }
 // A render box larger than the occupancy grid (geometry mode: the inflated scene box, load_scene) puts marching rays
 // outside the outermost cascade, where the reference steps one virtual cell at a time through space that cannot
@@ -258,12 +276,13 @@ NGP_DEV float grid_cube_entry(f3 pos, f3 idir, float h) {
 	return tmax >= tmin ? tmin : -1.0f;
 }
 // the whole-step rounding of advance_to_next_voxel for a given distance to the target
-NGP_DEV float advance_by_distance(float t, float cone_angle, float distance) {
+NGP_DEV float advance_by_distance(float t, const Stepping& s, float distance) {
 	float t_target = t + distance;
-	t = to_stepping_space(t, cone_angle);
-	t_target = to_stepping_space(t_target, cone_angle);
-	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+	t = to_stepping_space(t, s);
+	t_target = to_stepping_space(t_target, s);
+	return from_stepping_space(t + __builtin_ceilf(fmaxf(t_target - t, 0.5f)), s);
 }
+NGP_DEV float advance_by_distance(float t, float cone_angle, float distance) { return advance_by_distance(t, make_stepping(cone_angle), distance); }
 NGP_DEV uint32_t mip_from_pos(f3 pos, uint32_t max_cascade) {
 	int exponent;
 	float maxval = fmaxf(fmaxf(__builtin_fabsf(pos.x - 0.5f), __builtin_fabsf(pos.y - 0.5f)), __builtin_fabsf(pos.z - 0.5f));

@@ -31,22 +31,24 @@ template <bool PROBE, int PROF = 0, bool UNIT = false, int MIPS = (UNIT ? 1 : (i
 NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	const uint32_t max_cascade = UNIT ? 0u : M.max_cascade;
 	const float cone_angle = UNIT ? 0.0f : M.cone_angle;
+	const Stepping stepping = make_stepping(cone_angle); // (wave-uniform: the exponential stepping's constants, formed once)
 	__shared__ uint4 s_w[n_frags_for(RGB_MID) * 64];
 	__shared__ LevelInfo s_lv[N_LEVELS];
-	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade in use: empty-space summary of the occupancy grid (the host picks an instantiation with MIPS > max_cascade)
-	__shared__ uint32_t s_coarse16[NERF_CASCADES * 16];
+	__shared__ uint32_t s_coarse[MIPS * COARSE_WORDS_PER_MIP]; // 4 KB per cascade: empty-space summary of the occupancy grid, cascades 0 .. MIPS - 1 (outer ones: M.coarse)
+	__shared__ uint32_t s_coarse16[(UNIT ? 1 : (int)NERF_CASCADES) * 16];
 	__shared__ uint2 s_sh[FB * 4]; // per ray slot: 16 fp16 SH coefficients of its direction, written once per ray
 	constexpr int SLOTS = 64; // a wave's sample list: 4 network passes of 16
 	__shared__ float4 s_samp[FB / 64 * SLOTS]; // samples that wait for the network, in emission order: warped position, warped dt
 	__shared__ uint2 s_res[FB / 64 * SLOTS];   // .x = the lane that owns the sample; after the pass: the network's 4 fp16 outputs (rgb, density)
 	__shared__ float4 s_nrm[NORMALS ? FB / 64 * SLOTS : 1]; // Normals: d logit / d warped position and the logit
 	// Ray sharing inside a workgroup (knob 7): a wave that has run out of work asks through s_xstate, a busy wave hands it every second
-	// one of its live rays through s_xray (16 words per ray; the SH coefficients go straight into the receiver's s_sh rows), so the last
+	// one of its live rays (16 at most at a time) through s_xray (16 words per ray; the SH coefficients go straight into the receiver's s_sh rows), so the last
 	// tiles of a frame -- or a small frame's heavy tiles -- are finished by four waves instead of one.
 	//   s_xstate: 0 free | 0x100 + w: wave w asks | 0x200 + w: a donor is writing for w | 0x300 + w: s_xcount rays are ready for w
 	//   s_active: waves of this workgroup that hold rays or may still be dealt some; an asking wave leaves when it reaches 0
 	__shared__ uint32_t s_xstate, s_xcount, s_active;
-	__shared__ float s_xray[32 * 16];
+	constexpr uint32_t XRAYS = 16; // rays per hand-over
+	__shared__ float s_xray[XRAYS * 16];
 	if (threadIdx.x == 0) {
 		s_xstate = 0u;
 		s_xcount = 0u;
@@ -56,8 +58,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 	if (PROF) { t_entry = stamp(); rt_entry = realtime(); }
 	for (int i = threadIdx.x; i < n_frags_for(RGB_MID) * 64; i += FB) s_w[i] = M.wfrags[i];
 	if (threadIdx.x < N_LEVELS) s_lv[threadIdx.x] = M.levels[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < (max_cascade + 1) * COARSE_WORDS_PER_MIP; i += FB) s_coarse[i] = M.coarse[i];
-	if (threadIdx.x < NERF_CASCADES * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < (max_cascade + 1 < (uint32_t)MIPS ? max_cascade + 1 : (uint32_t)MIPS) * COARSE_WORDS_PER_MIP; i += FB) s_coarse[i] = M.coarse[i];
+	if (threadIdx.x < (UNIT ? 1 : (int)NERF_CASCADES) * 16) s_coarse16[threadIdx.x] = M.coarse[NERF_CASCADES * COARSE_WORDS_PER_MIP + threadIdx.x];
 	__syncthreads();
 
 	const int lane = threadIdx.x & 63;
@@ -240,7 +242,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 							}
 						}
 						if (ray.alive) {
-							ray.t = advance_n_steps(ray.t, cone_angle, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
+							ray.t = advance_n_steps(ray.t, stepping, ld_random_val_dim0(C.spp, ray.idx * 786433u)); // :355
 							fresh = true;
 						}
 					}
@@ -273,7 +275,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				won = __builtin_amdgcn_readfirstlane(won);
 				if (won) {
 					const uint32_t rank = lanes_below(live_mask);
-					if (ray.alive && (rank & 1u)) {
+					if (ray.alive && (rank & 1u) && (rank >> 1) < XRAYS) {
 						const uint32_t k = rank >> 1;
 						float* x = s_xray + k * 16u;
 						x[0] = ray.o.x; x[1] = ray.o.y; x[2] = ray.o.z;
@@ -289,7 +291,8 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					}
 					if (lane == 0) {
 						atomicAdd(&s_active, 1u); // the receiver counts as busy again before it can see its rays
-						s_xcount = (uint32_t)__popcll(live_mask) >> 1;
+						const uint32_t n_out = (uint32_t)__popcll(live_mask) >> 1;
+						s_xcount = n_out < XRAYS ? n_out : XRAYS;
 						__hip_atomic_store(&s_xstate, 0x300u | to, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
@@ -326,14 +329,14 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 					mip = mip_from_pos(pos, NERF_CASCADES - 1);
 					mip = mip > max_cascade ? max_cascade : mip;
 				}
-				empty = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip, occ_cache);
+				empty = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip, occ_cache, MIPS, M.coarse);
 			}
 			const bool emit = inside && empty == 0u;
 			const bool skip = inside && empty != 0u;
 			float e_dt = 0.f;
 			f3 e_w = mk3(0.f, 0.f, 0.f);
 			if (emit) {
-				e_dt = calc_dt(ray.t, cone_angle);
+				e_dt = calc_dt(ray.t, stepping);
 				e_w = sub3(pos, amin); // warp_position: (pos - min) / diag
 				if (M.diag_pow2) e_w = mul3(e_w, mk3(M.aabb_inv_diag[0], M.aabb_inv_diag[1], M.aabb_inv_diag[2]));
 				else e_w = div3(e_w, adiag);
@@ -344,7 +347,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				// the cell, so the block summary of the final level is looked up again
 				if (!UNIT) {
 					while (mip < max_cascade) {
-						uint32_t e = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache);
+						uint32_t e = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache, MIPS, M.coarse);
 						if (e == 0u) break;
 						++mip;
 						empty = e;
@@ -358,9 +361,9 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				if (outside && to_grid < 0.0f) { // the ray never reaches the occupancy grid: it would leave the render box without a sample
 					ends = true;
 				} else if (outside && to_grid > 0.0f) {
-					ray.t = advance_by_distance(ray.t, cone_angle, to_grid);
+					ray.t = advance_by_distance(ray.t, stepping, to_grid);
 				} else {
-					ray.t = advance_to_next_voxel(ray.t, cone_angle, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
+					ray.t = advance_to_next_voxel(ray.t, stepping, pos, ray.d, idir, mip, (PROBE || !F.tune[6]) ? 1u : empty);
 				}
 				++skip_i;
 			}
@@ -656,13 +659,13 @@ __global__ __launch_bounds__(FB_UNIT_PLAIN, 3) void render_nerf_fused_unit_plain
 }
 __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5_plain(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	fused_body<false, false, false, 5, false, 1, true>(M, C, F, P);
+	fused_body<false, 0, false, 4, false, 1, true>(M, C, F, P);
 }
-// scenes of up to 5 cascades (aabb_scale <= 16: fox, garden) rendered inside their occupancy grid: 20 KB of occupancy summaries instead of 32
-// leave room for a third workgroup per CU
+// scenes of up to 5 cascades (aabb_scale <= 16: fox, garden) rendered inside their occupancy grid: the block summaries of four cascades in
+// LDS (16 KB instead of 32; the fifth cascade's 4 KB table is read through the vector L1) leave room for a third workgroup per CU
 __global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_c5(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	fused_body<false, false, false, 5, false>(M, C, F, P);
+	fused_body<false, 0, false, 4, false>(M, C, F, P);
 }
 // rgb heads with 1 or 3 hidden layers (configs/nerf/base_1layer.json, base_3layer.json): the general kernel with no / two 64x64 layers
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_mid0(const ModelParams M, const CameraParams C, const FrameParams F) {

@@ -171,7 +171,8 @@ def load_library():
     L.ngp_get_render_stats.argtypes = [vp, C.POINTER(RenderStats)]
     L.ngp_get_render_history.argtypes = [vp, ip, C.POINTER(RenderStats)]
     L.ngp_set_schedule.argtypes = [vp, vp, ip]
-    L.ngp_get_profile_trace.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    if hasattr(L, "ngp_get_profile_trace"):  # (diagnostic entry; an older build loaded through NGP_HIP_LIBRARY for an A/B run lacks it)
+        L.ngp_get_profile_trace.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.ngp_grid_encode.argtypes = [vp, C.c_uint32, vp, vp]
     L.ngp_network_inference.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.ngp_density_gradient.argtypes = [vp, C.c_uint32, vp, vp]

@@ -4,7 +4,7 @@ set -e
 tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_$tag
-rocprofv3 --pmc $@ --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-training-probe > gpurun_out/pmc_$tag/bench.log 2>&1
+rocprofv3 --pmc $@ --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-training-probe --no-extra-probes > gpurun_out/pmc_$tag/bench.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]

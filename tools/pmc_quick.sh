@@ -8,7 +8,7 @@ pass() {
 	name=$1; shift
 	d=gpurun_out/pmcq_${tag}_$name
 	rm -rf $d && mkdir -p $d
-	if rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-training-probe --inflight 1 > $d/bench.log 2>&1; then
+	if rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-training-probe --no-extra-probes --inflight 1 > $d/bench.log 2>&1; then
 		python3 - "$d" "$name" >> $out <<'PY'
 import csv, glob, sys, collections
 d, name = sys.argv[1], sys.argv[2]

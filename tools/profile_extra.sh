@@ -6,7 +6,7 @@ tag=$1
 export TMPDIR=/tmp
 d=gpurun_out/prof_${tag}_inflight1
 rm -rf $d && mkdir -p $d
-rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --inflight 1 --no-cpu-baseline --no-training-probe > $d/bench.log 2>&1 && cp $d/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats_inflight1.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --inflight 1 --no-cpu-baseline --no-training-probe --no-extra-probes > $d/bench.log 2>&1 && cp $d/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats_inflight1.csv
 d=gpurun_out/prof_${tag}_wide
 rm -rf $d && mkdir -p $d
 N=8 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 tools/wide_probe.py > $d/run.log 2>&1 && cp $d/*/*kernel_stats.csv gpurun_out/${tag}_wide_kernel_stats.csv

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench done"
 rm -rf gpurun_out/prof_$tag && mkdir -p gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline --no-training-probe > gpurun_out/prof_$tag/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline --no-training-probe --no-extra-probes > gpurun_out/prof_$tag/bench.log 2>&1
 cp gpurun_out/prof_$tag/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 echo "kernel trace done"
 bash tools/pmc_pass.sh ${tag}_fetch FETCH_SIZE > gpurun_out/${tag}_pmc.txt

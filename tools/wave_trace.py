@@ -21,7 +21,8 @@ native, synthetic, scene = (importlib.import_module(PKG + "." + m) for m in ("na
 import torch
 
 torch.zeros(1, device="cuda")  # (torch bundles its own HIP runtime: it has to initialise first)
-sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19)
+aabb = int(os.environ.get("NGP_TRACE_AABB", "1"))  # 1: the bench model; 4 / 16: the fox- / garden-shaped scenes of tools/run_configs.py (the general kernel's stamped twin)
+sc = synthetic.make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19) if aabb == 1 else synthetic.make_scene(aabb_scale=aabb, seed=7 if aabb == 4 else 11, log2_hashmap_size=19, pls_rule="upstream")
 ctx = native.Context(0)
 ctx.set_model(sc)
 if os.environ.get("NGP_SCHEDULE"):
