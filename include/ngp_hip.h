@@ -181,8 +181,9 @@ NGP_API int ngp_load_snapshot(ngp_ctx* ctx, const void* bytes, size_t n_bytes, i
 NGP_API int ngp_load_snapshot_file(ngp_ctx* ctx, const char* path);
 /* Testbed::save_snapshot (src/testbed.cu:5219-5283), inference state only */
 NGP_API int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress);
-/* the model as currently loaded (pointers in the returned desc are NULL; sizes are valid) */
-NGP_API int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out);
+/* the model as currently loaded, trained parameters and a refreshed occupancy grid included; params_fp16 / density_grid_fp16 point at the
+ * context's own host copies (read-only, valid until the next call that changes the model) */
+NGP_API int ngp_get_model(ngp_ctx* ctx, ngp_model_desc* out);
 /* session state a snapshot carries beside the model and the camera (save_snapshot / load_snapshot, src/testbed.cu:5245-5263,
  * 5395-5418): m_background_color, m_exposure, m_sun_dir, m_up_dir, camera scale / aperture_size / autofocus_depth (= m_slice_plane_z).
  * get: what the loaded snapshot held (valid = 0 when nothing was loaded); set: what the next ngp_save_snapshot_file writes,

@@ -1328,7 +1328,8 @@ static void grid_samples_splat(const orc_nerf_model* m, const prepared_t* p, uin
 		uint16_t enc_h[ORC_MAX_LEVELS * 8];
 		float enc[ORC_MAX_LEVELS * 8], dens_f[64];
 		uint16_t dens_h[32];
-		grid_encode_one(m, p, pos01, enc_h);
+		if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h); /* any NerfNetwork: NerfNetwork::density, nerf_network.h */
+		else grid_encode_one(m, p, pos01, enc_h);
 		for (uint32_t k = 0; k < p->enc_dims; ++k) enc[k] = orc_half_to_float(enc_h[k]);
 		mlp_forward(m->mlp_accumulate == ORC_MLP_ACC_FP16_K16 ? ORC_MLP_ACC_FP16_K16 : ORC_MLP_ACC_EXACT, p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens_f, dens_h);
 		float thickness = network_to_density(orc_half_to_float(dens_h[0]), m->density_activation) * MIN_CONE_STEPSIZE();

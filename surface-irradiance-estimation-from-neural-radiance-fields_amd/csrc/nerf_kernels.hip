@@ -925,6 +925,40 @@ __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const Model
 		}
 	}
 }
+// The same refresh for a network without a hash grid (configs/nerf/frequency.json): update_density_grid_nerf works for any NerfNetwork
+// (src/testbed_nerf.cu:2772-2861). Three launches -- sample cells and positions, the density through the wide-MLP kernel of
+// wide_kernels.hip (its rgb head runs along: the entry point is NerfNetwork::inference; 2 M samples cost a few ms), splat.
+__global__ void density_grid_positions_kernel(const ModelParams M, uint32_t n_samples, Pcg32 rng, uint32_t step, uint32_t n_cascades, float thresh,
+                                              const float* __restrict__ grid_in, float* __restrict__ pos01, uint32_t* __restrict__ cell) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_samples) return;
+	rng.advance((uint64_t)i * 4u); // 1 random number to select the level, 3 to select the position
+	const uint32_t level = (uint32_t)(rng.next_float() * (float)n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) { // a grid cell that has density
+		idx = ((i + step * n_samples) * 56924617u + j * 19349663u + 96925573u) % NERF_GRID_N_CELLS;
+		idx += level * NERF_GRID_N_CELLS;
+		if (grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % NERF_GRID_N_CELLS;
+	const float x = (float)morton3D_invert(pos_idx >> 0), y = (float)morton3D_invert(pos_idx >> 1), z = (float)morton3D_invert(pos_idx >> 2);
+	const float rx = rng.next_float(), ry = rng.next_float(), rz = rng.next_float();
+	const float scale = __builtin_ldexpf(1.0f, (int)level);
+	const f3 pos = mk3(((x + rx) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f, ((y + ry) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f,
+	                   ((z + rz) / (float)NERF_GRIDSIZE - 0.5f) * scale + 0.5f);
+	const f3 w = div3(sub3(pos, mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2])), mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2])); // warp_position
+	pos01[3 * (size_t)i] = w.x; pos01[3 * (size_t)i + 1] = w.y; pos01[3 * (size_t)i + 2] = w.z;
+	cell[i] = idx;
+}
+__global__ void density_grid_splat_kernel(uint32_t n_samples, uint32_t density_act, const uint32_t* __restrict__ cell, const uint16_t* __restrict__ net_out, float* __restrict__ grid_tmp) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_samples) return;
+	union { uint16_t u; half_t h; } cv;
+	cv.u = net_out[(size_t)i * 4 + 3]; // the density logit
+	const float thickness = network_to_density((float)cv.h, density_act) * stepsize(); // optical thickness of the smallest step (:218)
+	atomicMax((unsigned int*)&grid_tmp[cell[i]], __float_as_uint(thickness)); // positive floats order like their bit patterns
+}
+
 // ema_grid_samples_nerf (:253-276): a decayed maximum, cells marked negative stay
 __global__ void density_grid_ema_kernel(uint32_t n_elements, float decay, float* __restrict__ grid, const float* __restrict__ grid_tmp) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1181,6 +1215,15 @@ void launch_density_gradient(const ModelParams& M, uint32_t n, const float* pos0
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
                                 float* grid_tmp, hipStream_t stream) {
 	if (n_samples) hipLaunchKernelGGL(density_grid_samples_kernel, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, grid_tmp);
+}
+void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, int n_cus, hipStream_t stream);
+// scratch: n_samples x (3 floats + 1 cell index + 4 fp16 outputs), owned by the caller
+void launch_density_grid_update_wide(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
+                                     float* grid_tmp, float* d_pos01, uint32_t* d_cell, uint16_t* d_out, int n_cus, hipStream_t stream) {
+	if (!n_samples) return;
+	hipLaunchKernelGGL(density_grid_positions_kernel, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, d_pos01, d_cell);
+	launch_network_inference_wide(M, n_samples, d_pos01, d_pos01, d_out, n_cus, stream); // (the density does not depend on the direction)
+	hipLaunchKernelGGL(density_grid_splat_kernel, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, n_samples, M.density_act, d_cell, d_out, grid_tmp);
 }
 void launch_density_grid_ema(uint32_t n_elements, float decay, float* grid, const float* grid_tmp, hipStream_t stream) {
 	hipLaunchKernelGGL(density_grid_ema_kernel, dim3((n_elements + 255) / 256), dim3(256), 0, stream, n_elements, decay, grid, grid_tmp);

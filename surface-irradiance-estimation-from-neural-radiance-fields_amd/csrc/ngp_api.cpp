@@ -1215,6 +1215,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 		for (int i = 0; i < 3; ++i) inside = inside && M.raabb_min[i] >= 0.5f - h && M.raabb_max[i] <= 0.5f + h;
 		F.outside_possible = inside ? 0 : 1;
 	}
+	ngp::order_after_model(ctx, stream); // a training step / grid refresh / peer copy that updated what this frame reads (a device-side wait)
 	NGP_HIP_CHECK(hipEventRecord(ctx->ev_frame0[slot], stream));
 	if (F.direct) {
 		F.frame_buffer = d_rgba_out;
@@ -1275,7 +1276,8 @@ void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, u
 	const uint32_t n_cascades = ctx->max_cascade + 1;
 	const uint32_t n_elements = NERF_GRID_N_CELLS * n_cascades;
 	hipStream_t stream = ctx->stream;
-	NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight on ANY stream read the bitfield and its summaries
+	ensure_frame_buffers(ctx, 0);
+	order_after_frames(ctx, stream); // frames in flight on ANY stream read the bitfield and its summaries: the refresh waits for them on the device
 	if (!ctx->d_density_tmp) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_density_tmp, (size_t)n_elements * sizeof(float)));
 	Pcg32 rng;
 	rng.state = ctx->grid_rng_state;
@@ -1287,10 +1289,28 @@ void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, u
 			else nu = nn = NERF_GRID_N_CELLS / 4 * n_cascades;
 		}
 		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_density_tmp, 0, (size_t)n_elements * sizeof(float), stream));
-		launch_density_grid_update(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, stream);
-		rng.advance();
-		launch_density_grid_update(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f /* NERF_MIN_OPTICAL_THICKNESS */, ctx->d_density_f32, ctx->d_density_tmp, stream);
-		rng.advance();
+		if (ctx->M.wide.width) { // a network without a hash grid: positions -> NerfNetwork::inference (wide_kernels.hip) -> splat
+			const size_t n_max = std::max(nu, nn);
+			if (n_max > ctx->grid_scratch_samples) {
+				if (ctx->d_grid_scratch) (void)hipFree(ctx->d_grid_scratch);
+				ctx->d_grid_scratch = nullptr;
+				ctx->grid_scratch_samples = 0;
+				NGP_HIP_CHECK(hipMalloc(&ctx->d_grid_scratch, n_max * 24));
+				ctx->grid_scratch_samples = n_max;
+			}
+			float* d_pos = (float*)ctx->d_grid_scratch;
+			uint32_t* d_cell = (uint32_t*)((char*)ctx->d_grid_scratch + n_max * 12);
+			uint16_t* d_out = (uint16_t*)((char*)ctx->d_grid_scratch + n_max * 16);
+			launch_density_grid_update_wide(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, d_pos, d_cell, d_out, ctx->n_cus, stream);
+			rng.advance();
+			launch_density_grid_update_wide(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f, ctx->d_density_f32, ctx->d_density_tmp, d_pos, d_cell, d_out, ctx->n_cus, stream);
+			rng.advance();
+		} else {
+			launch_density_grid_update(ctx->M, nu, rng, ctx->grid_ema_step, n_cascades, -0.01f, ctx->d_density_f32, ctx->d_density_tmp, stream);
+			rng.advance();
+			launch_density_grid_update(ctx->M, nn, rng, ctx->grid_ema_step, n_cascades, 0.01f /* NERF_MIN_OPTICAL_THICKNESS */, ctx->d_density_f32, ctx->d_density_tmp, stream);
+			rng.advance();
+		}
 		launch_density_grid_ema(n_elements, decay, ctx->d_density_f32, ctx->d_density_tmp, stream);
 		++ctx->grid_ema_step;
 		++ctx->grid_updates;
@@ -1300,6 +1320,7 @@ void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, u
 	// update_density_grid_mean_and_bitfield (:2863-2880) + the block summaries the march reads
 	launch_density_grid_to_bitfield(nullptr, 0, ctx->max_cascade, ctx->d_density_f32, ctx->d_partial, ctx->d_bitfield, &ctx->bitfield_mean, stream);
 	launch_coarse_occupancy(ctx->d_bitfield, ctx->d_coarse, stream);
+	mark_model_updated(ctx, stream);
 	ctx->density_grid_host_dirty = true;
 	++ctx->grid_generation;
 }
@@ -1384,12 +1405,15 @@ void ngp_destroy(ngp_ctx* ctx) {
 	if (ctx->d_rgba) (void)hipFree(ctx->d_rgba);
 	if (ctx->d_sync) (void)hipFree(ctx->d_sync);
 	if (ctx->d_trace) (void)hipFree(ctx->d_trace);
+	if (ctx->d_grid_scratch) (void)hipFree(ctx->d_grid_scratch);
 	for (int i = 0; i < ngp_ctx::HISTORY; ++i) {
 		if (ctx->ev_frame0[i]) (void)hipEventDestroy(ctx->ev_frame0[i]);
 		if (ctx->ev_frame1[i]) (void)hipEventDestroy(ctx->ev_frame1[i]);
 		if (ctx->ev_kern0[i]) (void)hipEventDestroy(ctx->ev_kern0[i]);
 		if (ctx->ev_kern1[i]) (void)hipEventDestroy(ctx->ev_kern1[i]);
 	}
+	if (ctx->ev_model) (void)hipEventDestroy(ctx->ev_model);
+	if (ctx->ev_synced) (void)hipEventDestroy(ctx->ev_synced);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1559,12 +1583,19 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 	});
 }
 
-int ngp_get_model(const ngp_ctx* ctx, ngp_model_desc* out) {
+int ngp_get_model(ngp_ctx* ctx, ngp_model_desc* out) {
 	if (!ctx || !out || !ctx->have_desc) return -1;
-	*out = ctx->desc;
-	out->n_params = ctx->params.size();
-	out->n_density_grid = ctx->density_grid.size();
-	return 0;
+	return guarded(ctx, [&] {
+		if (ctx->device >= 0) { // what was trained / refreshed on the device since is part of "the model as currently loaded"
+			ngp::sync_host_params(ctx);
+			ngp::refresh_density_grid_host(ctx);
+		}
+		*out = ctx->desc;
+		out->params_fp16 = ctx->params.data();
+		out->n_params = ctx->params.size();
+		out->density_grid_fp16 = ctx->density_grid.data();
+		out->n_density_grid = ctx->density_grid.size();
+	});
 }
 
 int ngp_get_session_state(const ngp_ctx* ctx, ngp_session_state* out) {
@@ -1972,7 +2003,6 @@ int ngp_update_density_grid(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint3
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
-		if (ctx->M.wide.width) throw std::runtime_error("the occupancy grid update is built for the configs/nerf/base.json network; a Frequency-encoding model keeps the grid of its snapshot");
 		ngp::sync_inference_model(ctx);
 		ngp::update_density_grid_device(ctx, decay, n_uniform, n_nonuniform, n_iterations);
 		ngp::refresh_density_grid_host(ctx);

@@ -39,6 +39,8 @@ void launch_frequency_encode(const ModelParams& M, uint32_t n, const float* pos0
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream);
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
                                 float* grid_tmp, hipStream_t stream);
+void launch_density_grid_update_wide(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
+                                     float* grid_tmp, float* d_pos01, uint32_t* d_cell, uint16_t* d_out, int n_cus, hipStream_t stream);
 void launch_density_grid_ema(uint32_t n_elements, float decay, float* grid, const float* grid_tmp, hipStream_t stream);
 void launch_init_rays(const ModelParams& M, const CameraParams& C, NerfPayload* payloads, hipStream_t stream);
 void launch_density_grid_to_bitfield(const uint16_t* d_grid_fp16, uint32_t n_grid, uint32_t max_cascade, float* d_grid_f32, double* d_partial,
@@ -244,7 +246,17 @@ struct ngp_ctx {
 	uint64_t hist_n_rays[HISTORY] = {};
 	uint64_t n_calls = 0; // render calls so far; call k uses slot k % HISTORY
 	hipStream_t last_stream = nullptr;
+	// Ordering between frames (any stream) and updates of what they read (render tables after training steps, the occupancy grid after a
+	// refresh, peer copies into a replica) without stalling the host: an update first orders ITS stream behind every frame issued
+	// since the previous update (ngp::order_after_frames: device-side waits on the frames' end events), does its work, and records
+	// ev_model; every later frame orders its stream behind ev_model (ngp::order_after_model).
+	uint64_t fenced_calls = 0;        // frames [0, fenced_calls) are already ordered before the last update
+	hipEvent_t ev_model = nullptr;    // end of the last update of the render model / occupancy grid on this device
+	bool ev_model_valid = false;
+	hipEvent_t ev_synced = nullptr;   // peer: its copies out of the primary's buffers are done
 	unsigned long long* d_prof = nullptr;
+	void* d_grid_scratch = nullptr; // occupancy-grid refresh of a Frequency-encoding model: positions, cells, network outputs of a batch of samples
+	size_t grid_scratch_samples = 0;
 	uint32_t* d_trace = nullptr; // wave timelines of the diagnostic build (NGP_PROFILE_TRACE)
 	static constexpr uint32_t TRACE_WAVES = 64, TRACE_ITERS = 1024;
 	int32_t tune[8] = {64, 4, 32, 1, 1, 4, 1, 1}; // FrameParams::tune; changed only through validate_schedule (ngp_api.cpp)
@@ -255,6 +267,8 @@ struct ngp_ctx {
 	uint64_t model_generation = 0, synced_generation = 0;               // the model was replaced (set_model, snapshot)
 	uint64_t grid_generation = 0, synced_grid_generation = 0;           // the occupancy grid was refreshed from the network
 	uint64_t params_generation = 0, synced_params_generation = 0;       // the inference parameters followed a training step
+	uint64_t mesh_generation = 0, synced_mesh_generation = 0;           // the mesh list / BVHs changed (Geometry mode)
+	uint64_t probe_generation = 0, synced_probe_generation = 0;         // the irradiance probe textures were (re)computed
 	float4* d_pack_rgba = nullptr;   // this device's tiles of the current frame, tile-packed
 	float* d_pack_depth = nullptr;
 	size_t pack_alloc = 0;
@@ -315,6 +329,20 @@ inline bool ends_with_ci(const std::string& s, const std::string& suffix) {
 }
 
 
+inline void order_after_frames(ngp_ctx* ctx, hipStream_t stream) {
+	const uint64_t pending = ctx->n_calls - ctx->fenced_calls, n = pending < (uint64_t)ngp_ctx::HISTORY ? pending : (uint64_t)ngp_ctx::HISTORY;
+	for (uint64_t k = 0; k < n; ++k) NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_frame1[(ctx->n_calls - 1 - k) % ngp_ctx::HISTORY], 0));
+	ctx->fenced_calls = ctx->n_calls;
+}
+inline void mark_model_updated(ngp_ctx* ctx, hipStream_t stream) {
+	if (!ctx->ev_model) NGP_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_model, hipEventDisableTiming));
+	NGP_HIP_CHECK(hipEventRecord(ctx->ev_model, stream));
+	ctx->ev_model_valid = true;
+}
+inline void order_after_model(ngp_ctx* ctx, hipStream_t stream) {
+	if (ctx->ev_model_valid) NGP_HIP_CHECK(hipStreamWaitEvent(stream, ctx->ev_model, 0));
+}
+
 void load_snapshot_path(ngp_ctx* ctx, const std::string& path);
 void install_model(ngp_ctx* ctx, const ngp_model_desc& d); // set_model_impl of ngp_api.cpp
 void update_density_grid_device(ngp_ctx* ctx, float decay, uint32_t n_uniform, uint32_t n_nonuniform, uint32_t n_iterations);
@@ -332,6 +360,8 @@ void render_frames_on(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts
 void ensure_frame_buffers_for(ngp_ctx* ctx, size_t n_pixels);
 void render_frames_multi(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba, float* d_depth, hipStream_t stream);
 void free_multi_buffers(ngp_ctx* ctx);
+// ngp_mesh.cpp: Geometry mode on an auxiliary device -- the primary's meshes (BVHs as built), shading parameters and irradiance tables
+void sync_peer_geometry(ngp_ctx* primary, ngp_ctx* peer);
 inline IrradianceMap irradiance_map_of(const ngp_ctx* ctx) {
 	IrradianceMap I{};
 	I.irradiance = ctx->d_irradiance;

@@ -113,6 +113,7 @@ void free_mesh_device(HostMesh& m) {
 
 // after any change of the mesh list: scene AABB (load_scene :3183-3189) and the device-side MeshRef table
 void rebuild_scene(ngp_ctx* ctx) {
+	++ctx->mesh_generation;
 	if (ctx->d_meshrefs) {
 		(void)hipFree(ctx->d_meshrefs);
 		ctx->d_meshrefs = nullptr;
@@ -413,6 +414,7 @@ void compute_probes(ngp_ctx* ctx, ngp::ProbeParams P, float min_transmittance) {
 	NGP_HIP_CHECK(hipGetLastError());
 	(void)hipFree(P.ray_rgba);
 	P.ray_rgba = nullptr;
+	++ctx->probe_generation;
 	ctx->env_probe = P;
 	ctx->env_n_theta = P.n_theta;
 	ctx->env_n_phi = P.n_phi;
@@ -540,3 +542,48 @@ int ngp_irradiance_at(ngp_ctx* ctx, uint32_t n, const float* positions, const fl
 }
 
 } // extern "C"
+
+// Geometry mode on a multi-device context (the reference's render_frame serves every mode on every device, src/testbed.cu:4833-4889,
+// 5575-5616): an auxiliary device gets the primary's meshes exactly as built (same triangle order, same BVH4 nodes -- rebuilt nowhere),
+// the BRDF / sun parameters and, when probes were computed, the tabulated irradiance E(n). Generation counters: only what changed moves.
+namespace ngp {
+void sync_peer_geometry(ngp_ctx* primary, ngp_ctx* peer) {
+	peer->shade = primary->shade;
+	if (peer->synced_mesh_generation != primary->mesh_generation) {
+		NGP_HIP_CHECK(hipSetDevice(peer->device));
+		NGP_HIP_CHECK(hipStreamSynchronize(peer->stream)); // (a rare event: frames on the peer still trace the old BVHs)
+		for (auto& m : peer->meshes) free_mesh_device(m);
+		peer->meshes.clear();
+		for (const HostMesh& m : primary->meshes) {
+			HostMesh c;
+			c.tris = m.tris;
+			c.nodes = m.nodes;
+			memcpy(c.bmin, m.bmin, sizeof(c.bmin));
+			memcpy(c.bmax, m.bmax, sizeof(c.bmax));
+			memcpy(c.center, m.center, sizeof(c.center));
+			peer->meshes.push_back(std::move(c));
+		}
+		rebuild_scene(peer);
+		peer->synced_mesh_generation = primary->mesh_generation;
+		NGP_HIP_CHECK(hipSetDevice(primary->device));
+	}
+	if (peer->synced_probe_generation != primary->probe_generation && primary->d_irradiance) {
+		const size_t texels = (size_t)primary->env_n_theta * primary->env_n_phi * (primary->env_probe.mode == 3 ? (size_t)primary->env_probe.grid_x * primary->env_probe.grid_y : 1u);
+		NGP_HIP_CHECK(hipSetDevice(peer->device));
+		NGP_HIP_CHECK(hipStreamSynchronize(peer->stream));
+		if (peer->d_envmap) (void)hipFree(peer->d_envmap);
+		if (peer->d_irradiance) (void)hipFree(peer->d_irradiance);
+		peer->d_envmap = peer->d_irradiance = nullptr;
+		NGP_HIP_CHECK(hipMalloc((void**)&peer->d_envmap, texels * sizeof(float4)));
+		NGP_HIP_CHECK(hipMalloc((void**)&peer->d_irradiance, texels * sizeof(float4)));
+		NGP_HIP_CHECK(hipSetDevice(primary->device));
+		NGP_HIP_CHECK(hipStreamSynchronize(primary->stream)); // compute_probes ends synchronised; a no-op in practice
+		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_envmap, peer->device, primary->d_envmap, primary->device, texels * sizeof(float4)));
+		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_irradiance, peer->device, primary->d_irradiance, primary->device, texels * sizeof(float4)));
+		peer->env_probe = primary->env_probe;
+		peer->env_n_theta = primary->env_n_theta;
+		peer->env_n_phi = primary->env_n_phi;
+		peer->synced_probe_generation = primary->probe_generation;
+	}
+}
+} // namespace ngp

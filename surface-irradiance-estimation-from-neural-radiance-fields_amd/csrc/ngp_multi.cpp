@@ -50,17 +50,23 @@ void sync_peer_model(ngp_ctx* primary, ngp_ctx* peer) {
 	}
 	const bool grid = peer->synced_grid_generation != primary->grid_generation, params = peer->synced_params_generation != primary->params_generation;
 	if (!grid && !params) return;
+	// Device to device, ordered by events (the reference's sync_device uses cudaMemcpyPeerAsync on the device's stream, :5542-5555):
+	//   the peer's stream waits for the primary's update (ev_model) -- its own earlier frames are on that stream, hence before the copies;
+	//   the copies run on the peer's stream; the primary's update stream then waits for them (ev_synced), so the next training step /
+	//   refresh cannot overwrite a source that is still being read. No host wait, no device-wide wait on either side.
 	{
 		DeviceGuard g(primary->device);
-		NGP_HIP_CHECK(hipDeviceSynchronize()); // the primary's updates are complete ...
+		if (!primary->ev_model_valid) mark_model_updated(primary, primary->stream); // (a model that was never updated on the device: everything before now)
 	}
 	DeviceGuard g(peer->device);
-	NGP_HIP_CHECK(hipDeviceSynchronize()); // ... and no frame on the peer still reads what is about to change
+	hipStream_t s = peer->stream;
+	NGP_HIP_CHECK(hipStreamWaitEvent(s, primary->ev_model, 0));
+	order_after_frames(peer, s); // (frames a caller put on another stream of the peer, if any)
 	if (grid) {
 		const size_t n_cells = (size_t)NERF_GRID_N_CELLS * (primary->max_cascade + 1);
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_bitfield, peer->device, primary->d_bitfield, primary->device, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES));
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_coarse, peer->device, primary->d_coarse, primary->device, ((size_t)NERF_CASCADES * COARSE_WORDS_PER_MIP + NERF_CASCADES * 16) * sizeof(uint32_t)));
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_density_f32, peer->device, primary->d_density_f32, primary->device, n_cells * sizeof(float)));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_bitfield, peer->device, primary->d_bitfield, primary->device, (size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, s));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_coarse, peer->device, primary->d_coarse, primary->device, ((size_t)NERF_CASCADES * COARSE_WORDS_PER_MIP + NERF_CASCADES * 16) * sizeof(uint32_t), s));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_density_f32, peer->device, primary->d_density_f32, primary->device, n_cells * sizeof(float), s));
 		peer->bitfield_mean = primary->bitfield_mean;
 		peer->grid_rng_state = primary->grid_rng_state;
 		peer->grid_rng_inc = primary->grid_rng_inc;
@@ -69,10 +75,17 @@ void sync_peer_model(ngp_ctx* primary, ngp_ctx* peer) {
 		peer->synced_grid_generation = primary->grid_generation;
 	}
 	if (params) {
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_params, peer->device, primary->d_params, primary->device, primary->M.grid_bytes));
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_xgrid, peer->device, primary->d_xgrid, primary->device, primary->M.xgrid_bytes));
-		NGP_HIP_CHECK(hipMemcpyPeer(peer->d_wfrags, peer->device, primary->d_wfrags, primary->device, (size_t)(N_FRAGS_MAX + N_NORMALS_FRAGS) * 64 * sizeof(uint4)));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_params, peer->device, primary->d_params, primary->device, primary->M.grid_bytes, s));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_xgrid, peer->device, primary->d_xgrid, primary->device, primary->M.xgrid_bytes, s));
+		NGP_HIP_CHECK(hipMemcpyPeerAsync(peer->d_wfrags, peer->device, primary->d_wfrags, primary->device, (size_t)(N_FRAGS_MAX + N_NORMALS_FRAGS) * 64 * sizeof(uint4), s));
 		peer->synced_params_generation = primary->params_generation;
+	}
+	mark_model_updated(peer, s); // the peer's frames read the new tables
+	if (!peer->ev_synced) NGP_HIP_CHECK(hipEventCreateWithFlags(&peer->ev_synced, hipEventDisableTiming));
+	NGP_HIP_CHECK(hipEventRecord(peer->ev_synced, s));
+	{
+		DeviceGuard gp(primary->device);
+		NGP_HIP_CHECK(hipStreamWaitEvent(primary->stream, peer->ev_synced, 0)); // the primary's next update of these buffers comes after the copies
 	}
 }
 
@@ -103,7 +116,6 @@ void free_multi_buffers(ngp_ctx* ctx) {
 // One frame over every device of a multi-device context; the assembled image lands in d_rgba / d_depth (device 0), enqueued
 // on `stream` of device 0. Nothing here waits for the GPUs.
 void render_frames_multi(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& opts, float4* d_rgba, float* d_depth, hipStream_t stream) {
-	if (opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("a multi-device context renders NeRF mode (meshes live on the primary device only)");
 	if (opts.packed_output) throw std::runtime_error("packed_output addresses one shard: render it through a single-device context");
 	const uint32_t n_dev = 1u + (uint32_t)ctx->peers.size();
 	const uint32_t tiles = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
@@ -127,7 +139,7 @@ void render_frames_multi(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_o
 	for (uint32_t i = 0; i < n_dev; ++i) {
 		ngp_ctx* dev = i == 0 ? ctx : ctx->peers[i - 1];
 		if (i > 0) {
-			sync_peer_model(ctx, dev);
+			if (ctx->model_loaded) sync_peer_model(ctx, dev); // (a Geometry session may hold meshes only)
 			// by-value render state follows the primary every frame (m_render_aabb, cone angle: src/testbed.cu:5529-5563 copies them on sync)
 			memcpy(dev->M.raabb_min, ctx->M.raabb_min, sizeof(ctx->M.raabb_min));
 			memcpy(dev->M.raabb_max, ctx->M.raabb_max, sizeof(ctx->M.raabb_max));
@@ -135,6 +147,7 @@ void render_frames_multi(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_o
 			dev->M.r2l_identity = ctx->M.r2l_identity;
 			dev->M.cone_angle = ctx->M.cone_angle;
 			memcpy(dev->tune, ctx->tune, sizeof(ctx->tune));
+			if (opts.testbed_mode == NGP_MODE_GEOMETRY) sync_peer_geometry(ctx, dev); // meshes + BVHs, BRDF parameters, irradiance tables
 		}
 		DeviceGuard g(dev->device);
 		ensure_pack_buffers(dev, packed);

@@ -434,7 +434,8 @@ void sync_inference_model(ngp_ctx* ctx) {
 	if (!ctx->train || !ctx->train->inference_dirty || ctx->device < 0 || !ctx->model_loaded) return;
 	TrainState& T = *ctx->train;
 	hipStream_t stream = ctx->stream;
-	NGP_HIP_CHECK(hipDeviceSynchronize()); // frames in flight on any stream read the tables
+	ensure_sync_buffers(ctx);
+	order_after_frames(ctx, stream); // frames in flight on any stream read the tables: the update waits for them on the device, the host does not
 	const uint16_t* src = T.opts.ema_decay > 0.f ? T.d_weights_ema : T.d_weights;
 	const size_t ng = (size_t)T.n_params - T.n_matrix;
 	NGP_HIP_CHECK(hipMemcpyAsync(ctx->d_params, src + T.n_matrix, ng * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
@@ -442,7 +443,7 @@ void sync_inference_model(ngp_ctx* ctx) {
 	launch_train_build_fragments(src, T.d_tfrags_inference, T.d_kfrags_inference, stream);
 	NGP_HIP_CHECK(hipMemcpyAsync(ctx->d_wfrags, T.d_tfrags_inference, (size_t)N_FRAGS * 64 * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
 	launch_build_normals_fragments(ctx->d_wfrags, stream);
-	NGP_HIP_CHECK(hipStreamSynchronize(stream));
+	mark_model_updated(ctx, stream); // (frames issued from here on wait for it: order_after_model in render_frames)
 	NGP_HIP_CHECK(hipGetLastError());
 	T.inference_dirty = false;
 	++ctx->params_generation;

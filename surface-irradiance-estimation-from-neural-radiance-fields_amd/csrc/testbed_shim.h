@@ -127,13 +127,26 @@ public:
 			size_t got;
 			while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
 			fclose(f);
-			size_t k = text.find("\"log2_hashmap_size\"");
-			if (k != std::string::npos) {
-				k = text.find(':', k);
-				if (k != std::string::npos) m_log2_hashmap_size = (uint32_t)strtoul(text.c_str() + k + 1, nullptr, 10);
+			// what the trainer builds is configs/nerf/base.json's architecture (HashGrid + FullyFusedMLP 64-wide heads, SH degree 4 over
+			// an Identity remainder); the table size is what varies between the shipped configs it accepts (base 19, small 15, base_14 14,
+			// big 21). Anything else is refused by name rather than trained as something it is not.
+			const mj::Value cfg = mj::parse_json(text);
+			auto otype = [](const mj::Value& v) { return v.is_object() && v.contains("otype") ? v.at("otype").str() : std::string(); };
+			if (cfg.contains("encoding")) {
+				const mj::Value& e = cfg.at("encoding");
+				const std::string ot = otype(e);
+				if (!ot.empty() && ot != "HashGrid" && ot != "Grid") throw std::runtime_error("network config: encoding \"" + ot + "\" cannot be trained by the MI355X path (HashGrid only)");
+				if (e.contains("log2_hashmap_size")) m_log2_hashmap_size = (uint32_t)e.at("log2_hashmap_size").integer();
 			}
-			for (const char* unsupported : {"\"TiledGrid\"", "\"Frequency\"", "\"CutlassMLP\"", "\"Identity\""})
-				if (text.find(unsupported) != std::string::npos) throw std::runtime_error(std::string("network config uses ") + unsupported + ", which the MI355X path does not implement (configs/nerf/base.json shapes only)");
+			for (const char* net : {"network", "rgb_network"})
+				if (cfg.contains(net) && !otype(cfg.at(net)).empty() && otype(cfg.at(net)) != "FullyFusedMLP")
+					throw std::runtime_error(std::string("network config: ") + net + " \"" + otype(cfg.at(net)) + "\" cannot be trained by the MI355X path (FullyFusedMLP only)");
+			if (cfg.contains("dir_encoding")) {
+				const mj::Value& de = cfg.at("dir_encoding");
+				std::string first = otype(de);
+				if (first == "Composite" && de.contains("nested") && de.at("nested").is_array() && de.at("nested").size() > 0) first = otype(de.at("nested").at(0));
+				if (first != "SphericalHarmonics") throw std::runtime_error("network config: dir_encoding \"" + first + "\" cannot be trained by the MI355X path (SphericalHarmonics degree 4)");
+			}
 		}
 		reset_network();
 	}

@@ -394,6 +394,27 @@ class Context:
         self._check(self.L.ngp_get_model(self.h, C.byref(d)))
         return d
 
+    def get_scene(self):
+        """The loaded model as the dict set_model takes (and the oracle's make_model): what a snapshot left behind, copied out of the context"""
+        from . import scene as S
+
+        d = self.get_model()
+        if d.pos_encoding != 0:
+            raise RuntimeError("get_scene: grid models only")
+        params = np.ctypeslib.as_array(C.cast(d.params_fp16, C.POINTER(C.c_uint16)), shape=(int(d.n_params),)).copy()
+        grid = np.ctypeslib.as_array(C.cast(d.density_grid_fp16, C.POINTER(C.c_uint16)), shape=(int(d.n_density_grid),)).copy().view(np.float16)
+        r2l = np.array([[d.render_aabb_to_local[c * 3 + r] for c in range(3)] for r in range(3)], np.float32)
+        return {
+            "encoding": {"otype": "HashGrid", "n_levels": d.n_levels, "n_features_per_level": d.n_features_per_level, "log2_hashmap_size": d.log2_hashmap_size,
+                         "base_resolution": d.base_resolution, "per_level_scale": float(d.per_level_scale)},
+            "network": {"otype": "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_density, "n_output_dims": d.density_out_dims},
+            "rgb_network": {"otype": "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_rgb},
+            "rgb_activation": d.rgb_activation, "density_activation": d.density_activation,
+            "params": params, "density_grid": grid,
+            "aabb": (tuple(d.aabb_min), tuple(d.aabb_max)), "render_aabb": (tuple(d.render_aabb_min), tuple(d.render_aabb_max)), "render_aabb_to_local": r2l,
+            "aabb_scale": d.aabb_scale, "max_cascade": S.max_cascade_for(d.aabb_scale), "cone_angle_constant": float(d.cone_angle_constant), "linear_colors": bool(d.linear_colors),
+        }
+
     def session_state(self):
         st = SessionState()
         self._check(self.L.ngp_get_session_state(self.h, C.byref(st)))

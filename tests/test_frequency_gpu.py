@@ -147,6 +147,34 @@ def test_snapshot_round_trip_and_modes(ctx, native, scene_mod, scene_freq, tmp_p
         other.close()
 
 
+def test_density_grid_refresh(native, oracle, scene_freq):
+    """update_density_grid_nerf works for any NerfNetwork (src/testbed_nerf.cu:2772-2861): for the Frequency architecture the sampled
+    cells and positions are the grid model's (same pcg32 stream), the density comes from the wide-MLP kernel; against the oracle."""
+    c = native.Context(0)
+    try:
+        c.set_model(scene_freq)
+        mc = scene_freq["max_cascade"]
+        grid0 = c.density_grid(mc)
+        c.update_density_grid(0.95, 40000, 20000, 2)
+        got = c.density_grid(mc)
+        m = oracle.make_model(scene_freq)
+        rng = oracle.grid_rng()
+        ref, step = oracle.update_density_grid(m, grid0, mc, rng, 0, 0.95, 40000, 20000)
+        ref, step = oracle.update_density_grid(m, ref, mc, rng, step, 0.95, 40000, 20000)
+        oracle.release(m)
+        decayed = np.float32(0.95) * (np.float32(0.95) * grid0)
+        assert np.array_equal(got != decayed, ref != decayed)  # exactly the same cells were touched
+        touched = ref != decayed
+        assert touched.sum() > 30000
+        rel = np.abs(got[touched] - ref[touched]) / np.maximum(ref[touched], 1e-12)
+        assert np.median(rel) < 5e-3 and (rel < 0.1).mean() > 0.995  # exp(logit) of a 9-layer fp16 network: a few fp16 ulps of the logit
+        bf, mean = c.density_bitfield()
+        obf, omean = oracle.density_grid_to_bitfield(ref, mc)
+        assert abs(mean - omean) <= 5e-3 * omean and np.unpackbits(bf ^ obf).sum() <= 2e-4 * 128 ** 3
+    finally:
+        c.close()
+
+
 def test_probe_envmap(ctx, native, scene_freq):
     """the irradiance probes (K10: rays from the centre) run on this architecture too"""
     ctx.set_model(scene_freq)

@@ -358,8 +358,22 @@ def test_multi_device_context_assembles_the_single_device_frame(n_dev, native, s
     a, b = multi.render(native.make_camera(scene_mod.orbit_camera(200.0), 96, 54, scene_mod.focal_from_fov_x(96, 0.6911), snap=False), o), None
     b = single.render(native.make_camera(scene_mod.orbit_camera(200.0), 96, 54, scene_mod.focal_from_fov_x(96, 0.6911), snap=False), o)
     assert np.abs(a - b).max() < 1e-6
-    with pytest.raises(RuntimeError, match="multi-device context renders NeRF mode"):
-        multi.render(cam, native.make_opts(testbed_mode=native.MODE_GEOMETRY))
+    # Geometry mode (the reference's per-device render_frame serves every mode, src/testbed.cu:4833-4889, 5575-5616): meshes and their
+    # BVHs, the BRDF / sun parameters and the irradiance tables follow to every device; mesh pass, shadow rays and the NeRF pass run per share
+    meshio = pkg("meshio")
+    for c in (single, multi):
+        c.add_mesh(meshio.icosphere(3), (0.62, -0.05, 0.05))
+        c.add_mesh(meshio.torus(24, 16), (-0.45, 0.3, 0.5))
+        c.compute_envmap(0, 32, 16)
+    for mode in (native.RENDER_SHADE, native.RENDER_SHADE_ENVMAP):
+        o = native.make_opts(testbed_mode=native.MODE_GEOMETRY, render_mode=mode)
+        gcam = native.make_camera(scene_mod.orbit_camera(60.0, 25.0, 5.5), 144, 81, scene_mod.focal_from_fov_x(144, 0.8))
+        a, da = multi.render(gcam, o, want_depth=True)
+        b, db = single.render(gcam, o, want_depth=True)
+        assert np.abs(a - b).max() < 1e-6 and np.array_equal(da, db) and a[..., 3].max() > 0.9
+    single.clear_meshes()
+    multi.clear_meshes()
+    assert np.array_equal(multi.render(cam), single.render(cam))
     multi.close()
     single.close()
 
