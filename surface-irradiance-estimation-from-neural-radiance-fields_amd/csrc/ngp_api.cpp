@@ -268,17 +268,18 @@ void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t
 
 // MFMA A fragments of one layer of the wide architecture (ngp_kernels.h WideModel): [m tile][k block][lane] x 8 fp16, zeros beyond the matrix
 WideLayer emit_wide_fragments(std::vector<uint16_t>& frags, const uint16_t* W, uint32_t n_out, uint32_t n_in) {
+	constexpr uint32_t TM = (uint32_t)ngp::WIDE_TILE_M, TK = (uint32_t)ngp::WIDE_TILE_K;
 	WideLayer L{};
 	L.frag_offset = (uint32_t)(frags.size() / 8);
-	L.n_kblocks = (uint16_t)(n_in <= 128 ? 8 : 16); // the kernels are instantiated for K = 128 and 256 (zero columns beyond the matrix)
-	L.n_mtiles = (uint16_t)((n_out + 31) / 32);
+	L.n_kblocks = (uint16_t)((n_in <= 128 ? 128u : 256u) / TK); // the kernels are instantiated for K = 128 and 256 (zero columns beyond the matrix)
+	L.n_mtiles = (uint16_t)((n_out + TM - 1) / TM);
 	frags.resize(frags.size() + (size_t)L.n_mtiles * L.n_kblocks * 64 * 8, 0);
 	uint16_t* out = frags.data() + (size_t)L.frag_offset * 8;
 	for (uint32_t m = 0; m < L.n_mtiles; ++m)
 		for (uint32_t kb = 0; kb < L.n_kblocks; ++kb)
 			for (uint32_t l = 0; l < 64; ++l)
 				for (uint32_t j = 0; j < 8; ++j) {
-					const uint32_t row = 32 * m + (l & 31), col = 16 * kb + 8 * (l >> 5) + j;
+					const uint32_t row = TM * m + (l % TM), col = TK * kb + 8 * (l / TM) + j;
 					if (row < n_out && col < n_in) out[(((size_t)m * L.n_kblocks + kb) * 64 + l) * 8 + j] = W[(size_t)row * n_in + col];
 				}
 	return L;

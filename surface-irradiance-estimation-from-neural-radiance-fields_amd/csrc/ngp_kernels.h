@@ -57,14 +57,26 @@ static_assert(sizeof(NerfPayload) == 40, "NerfPayload layout");
 
 // The "wide" architecture (configs/nerf/frequency.json, the original NeRF's: Frequency encodings, CutlassMLPs 128 or 256 wide with
 // any number of hidden layers) runs in wide_kernels.hip on v_mfma_f32_32x32x16_f16 tiles. Every layer's weights are stored as MFMA
-// A fragments: fragment (m, kb) of a layer = rows 32m..32m+31 (output neurons), columns 16kb..16kb+15 (inputs) of its row-major
-// [out][in] matrix, 64 lanes x 8 fp16 with lane (r = lane & 31, h = lane >> 5) holding W[32m + r][16kb + 8h + j]; rows and columns
-// beyond the matrix are zeros. Layer l's fragments start at uint4 index frag_offset and are ordered [m][kb][lane].
+// A fragments: fragment (m, kb) of a layer = rows TM m .. (output neurons), columns TK kb .. (inputs) of its row-major [out][in]
+// matrix (TM x TK = WIDE_TILE_M x WIDE_TILE_K: 16 x 32 or 32 x 16), 64 lanes x 8 fp16 with lane (r = lane % TM, h = lane / TM) holding
+// W[TM m + r][TK kb + 8h + j]; rows and columns beyond the matrix are zeros. Layer l's fragments start at uint4 index frag_offset and
+// are ordered [m][kb][lane].
+// WIDE_MFMA16 = 1 builds the wide-MLP kernels on v_mfma_f32_16x16x32_f16 (A fragments of 16 rows x 32 columns) instead of
+// v_mfma_f32_32x32x16_f16 (32 x 16): the same FLOP per cycle on paper, less power per FLOP under a clock that this kernel holds at
+// its power limit (MI355X_MICROARCH.md, MFMA shapes). Host fragment builder (ngp_api.cpp) and kernels (wide_kernels.hip) switch
+// together. Measured (round 3, same box, same run): the network alone 3.95 instead of 4.16 ms for 4.2 M samples (+5 %), the render
+// kernel 933 instead of 952 TFLOP/s (-2 %: twice the address / LDS instructions per FLOP, and more of the ray state spilled) -- the
+// 32x32x16 form ships; all of tests/test_frequency_gpu.py passes either way (python build.py with NGP_BUILD_DEFINES=-DWIDE_MFMA16=1).
+#ifndef WIDE_MFMA16
+#define WIDE_MFMA16 0
+#endif
+constexpr int WIDE_TILE_M = WIDE_MFMA16 ? 16 : 32; // rows (neurons) of an A fragment
+constexpr int WIDE_TILE_K = WIDE_MFMA16 ? 32 : 16; // its columns (inputs)
 constexpr int WIDE_MAX_LAYERS = 24;
 struct WideLayer {
 	uint32_t frag_offset;
-	uint16_t n_kblocks; // 16-wide blocks of the input, zero-padded to 8 or 16 blocks (K = 128 or 256: what wide_kernels.hip is instantiated for)
-	uint16_t n_mtiles;  // 32-row tiles of the (zero-padded) output
+	uint16_t n_kblocks; // WIDE_TILE_K-wide blocks of the input, zero-padded to K = 128 or 256 (what wide_kernels.hip is instantiated for)
+	uint16_t n_mtiles;  // WIDE_TILE_M-row tiles of the (zero-padded) output
 };
 struct WideModel {
 	const uint4* frags;

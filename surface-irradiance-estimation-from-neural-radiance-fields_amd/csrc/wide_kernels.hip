@@ -142,7 +142,7 @@ NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
 // would also drain the outstanding global loads, i.e. the stream.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_RING
-#define WIDE_RING 3
+#define WIDE_RING (WIDE_MFMA16 ? 2 : 3) // (a K block of the 16x16x32 form is 32 wide: one block ahead is the same 512 MFMA cycles as two of the 32x32x16 form)
 #endif
 constexpr int RING = WIDE_RING, AHEAD = RING - 1; // stages of the weight ring, K-blocks it runs ahead
 NGP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -161,6 +161,93 @@ NGP_DEV void ring_preload(u32x4 (&ar)[RING][MT], LayerFrags L) {
 			if (m < L.mt) ar[st][m] = *(const u32x4*)(L.base + ((size_t)m * L.nkb + st) * 64);
 }
 
+#if WIDE_MFMA16
+// ---- the GEMMs on v_mfma_f32_16x16x32_f16. MT counts 16-neuron tiles of a wave (4 for 256 neurons), NKB 32-wide K blocks.
+// A fragment: lane (r = lane & 15, h = lane >> 4) holds W[16 m + r][32 kb + 8 h ..]; B: lane (c, h) reads X[16 t + c][32 kb + 8 h ..]
+// (one ds_read_b128); D: lane (c, h) holds neurons 16 m + 4 h .. + 3 of sample 16 t + c -- four packed halves, one 8-byte LDS write.
+// A wave owns 16 MT neurons and all eight 16-sample tiles: MT x 8 accumulator tiles of 4 registers (128 for MT = 4, as before). The
+// B operands of half a K block (four sample tiles) are read while the MFMAs of the other half run.
+typedef float floatx4w __attribute__((ext_vector_type(4)));
+NGP_DEV floatx4w mfma16w(half8 a, half8 b, floatx4w c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <int MT, int NKB>
+NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
+	const int c = lane & 15, h = lane >> 4;
+	const floatx4w zero = {0.f, 0.f, 0.f, 0.f};
+	floatx4w acc[MT][8];
+	const half_t* col = X + c * XS + 8 * h;
+	// B operands: two sample tiles at a time, read while the MFMAs of the previous pair run (MT x 2 MFMAs = 128 cycles for MT = 4: a
+	// ds_read_b128's latency); a quarter of a K block in flight instead of a whole one keeps the loop inside 256 registers
+	half8 b[2][2];
+	b[0][0] = *(const half8*)col;
+	b[0][1] = *(const half8*)(col + 16 * XS);
+#pragma unroll
+	for (int kb = 0; kb < NKB; ++kb) {
+		if (kb + AHEAD < NKB) {
+#pragma unroll
+			for (int m = 0; m < MT; ++m) ar[(kb + AHEAD) % RING][m] = *(const u32x4*)(wf + ((size_t)m * NKB + kb + AHEAD) * 64);
+		}
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { // sample tiles 2q, 2q + 1
+			const int nq = (q + 1) & 3, nkb = q == 3 ? kb + 1 : kb;
+			if (nkb < NKB) {
+				b[(q + 1) & 1][0] = *(const half8*)(col + 16 * (2 * nq) * XS + 32 * nkb);
+				b[(q + 1) & 1][1] = *(const half8*)(col + 16 * (2 * nq + 1) * XS + 32 * nkb);
+			}
+			__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use)
+#pragma unroll
+			for (int t = 0; t < 2; ++t)
+#pragma unroll
+				for (int m = 0; m < MT; ++m) acc[m][2 * q + t] = mfma16w(as_half8(ar[kb % RING][m]), b[q & 1][t], kb == 0 ? zero : acc[m][2 * q + t]);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	ring_preload<MT>(ar, next);
+	uint2 packed[MT][8];
+#pragma unroll
+	for (int m = 0; m < MT; ++m)
+#pragma unroll
+		for (int t = 0; t < 8; ++t) packed[m][t] = pack4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3], true);
+	lds_barrier(); // every wave has read the layer's input
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		half_t* row = X + (16 * t + c) * XS + 16 * (wave * MT) + 4 * h;
+#pragma unroll
+		for (int m = 0; m < MT; ++m) *(uint2*)(row + 16 * m) = packed[m][t];
+	}
+	lds_barrier();
+}
+
+// An output layer (at most 16 neurons, no activation): wave w computes sample tiles 2w and 2w + 1; fragments in ar[.][0].
+// Returned: acc[t'] = outputs 4h .. 4h + 3 of sample 16 (2 wave + t') + c
+struct OutTiles {
+	floatx4w t[2];
+};
+template <int MT, int NKB>
+NGP_DEV OutTiles wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
+	const int c = lane & 15, h = lane >> 4;
+	const floatx4w zero = {0.f, 0.f, 0.f, 0.f};
+	OutTiles acc;
+	acc.t[0] = acc.t[1] = zero;
+	const half_t* col = X + (32 * wave + c) * XS + 8 * h;
+	half8 b[2][2];
+	b[0][0] = *(const half8*)col;
+	b[0][1] = *(const half8*)(col + 16 * XS);
+#pragma unroll
+	for (int kb = 0; kb < NKB; ++kb) {
+		if (kb + AHEAD < NKB) ar[(kb + AHEAD) % RING][0] = *(const u32x4*)(wf + (size_t)(kb + AHEAD) * 64);
+		if (kb + 1 < NKB) {
+			b[(kb + 1) & 1][0] = *(const half8*)(col + 32 * (kb + 1));
+			b[(kb + 1) & 1][1] = *(const half8*)(col + 16 * XS + 32 * (kb + 1));
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		acc.t[0] = mfma16w(as_half8(ar[kb % RING][0]), b[kb & 1][0], acc.t[0]);
+		acc.t[1] = mfma16w(as_half8(ar[kb % RING][0]), b[kb & 1][1], acc.t[1]);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	ring_preload<MT>(ar, next);
+	return acc;
+}
+#else
 // One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)); ring stages 0..2 hold (or await) K-blocks 0..2.
 template <int MT, int NKB>
 NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
@@ -229,9 +316,12 @@ NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const ui
 	return acc;
 }
 
+#endif
+
 struct WideOut {
 	half_t r, g, b, sigma;
 };
+constexpr int K256 = 256 / WIDE_TILE_K, K128 = 128 / WIDE_TILE_K; // K blocks of the two layer shapes the kernels are instantiated for
 
 template <int MT>
 NGP_DEV LayerFrags layer_frags(const WideModel& W, uint32_t l, int wave, int lane) {
@@ -260,6 +350,7 @@ template <int MT>
 NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[RING][MT], int my_row) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
+	(void)n; (void)h;
 	const int row_id = tid & (ROWS - 1), part = tid >> 7;
 	const uint32_t n_layers = W.n_hidden_density + W.n_hidden_rgb + 2u;
 	WideOut o;
@@ -268,16 +359,25 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 		const bool density_out = l == W.n_hidden_density, rgb_out = l + 1u == n_layers;
 		const LayerFrags cur = layer_frags<MT>(W, l, wave, lane), next = layer_frags<MT>(W, l + 1u, wave, lane);
 		if (!density_out && !rgb_out) {
-			if (cur.nkb == 16) wide_hidden_layer<MT, 16>(S.x, ar, cur.base, wave, lane, next);
-			else wide_hidden_layer<MT, 8>(S.x, ar, cur.base, wave, lane, next);
+			if (cur.nkb == K256) wide_hidden_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next);
+			else wide_hidden_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
 			continue;
 		}
-		const floatx16 acc = cur.nkb == 16 ? wide_out_layer<MT, 16>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, 8>(S.x, ar, cur.base, wave, lane, next);
+#if WIDE_MFMA16
+		const OutTiles acc = cur.nkb == K256 ? wide_out_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
+#else
+		const floatx16 acc = cur.nkb == K256 ? wide_out_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
+#endif
 		if (density_out) {
 			// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tile: no other wave reads them now)
+#if WIDE_MFMA16
+#pragma unroll
+			for (int q = 0; q < 2; ++q) *(uint2*)(S.x + (32 * wave + 16 * q + (lane & 15)) * XS + 4 * (lane >> 4)) = pack4(acc.t[q][0], acc.t[q][1], acc.t[q][2], acc.t[q][3], false);
+#else
 			half_t* orow = S.x + (32 * wave + n) * XS + 4 * h;
 #pragma unroll
 			for (int q = 0; q < 2; ++q) *(uint2*)(orow + 8 * q) = pack4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], false);
+#endif
 			lds_barrier();
 			// [density out | direction encoding | ones up to the network's input alignment | zeros up to the next layer's K]; two threads per row
 			half_t* row = S.x + row_id * XS;
@@ -286,7 +386,7 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 				const half_t* d = S.dir + (int)S.owner[row_id] * DIR_STRIDE;
 				for (uint32_t c = 0; c < W.dir_dims; c += 8u) *(uint4*)(row + 16u + c) = *(const uint4*)(d + c);
 			} else {
-				const uint32_t k_end = 16u * W.layers[l + 1u].n_kblocks;
+				const uint32_t k_end = (uint32_t)WIDE_TILE_K * W.layers[l + 1u].n_kblocks;
 				for (uint32_t c = 16u + W.dir_dims; c < k_end; c += 8u) {
 					const half_t v = c < W.rgb_in ? (half_t)1.0f : (half_t)0.0f;
 					const half8 fill = {v, v, v, v, v, v, v, v};
@@ -295,7 +395,14 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 			}
 			lds_barrier();
 		} else {
+#if WIDE_MFMA16
+			if ((lane >> 4) == 0) {
+#pragma unroll
+				for (int q = 0; q < 2; ++q) *(uint2*)row_meta(S, 32 * wave + 16 * q + (lane & 15)) = pack4(acc.t[q][0], acc.t[q][1], acc.t[q][2], 0.f, false);
+			}
+#else
 			if (h == 0) *(uint2*)row_meta(S, 32 * wave + n) = pack4(acc[0], acc[1], acc[2], 0.f, false);
+#endif
 			lds_barrier();
 			if (my_row >= 0) {
 				union { uint2 u; half_t hh[4]; } r;
@@ -320,7 +427,7 @@ NGP_DEV void encode_positions(const WideModel& W, WideShared& S, int tid) {
 	const float4 p = *row_meta(S, row);
 	if (p.w == 0.0f) return;
 	const uint32_t split = (W.pos_freqs + 1u) / 2u;
-	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, 16u * W.layers[0].n_kblocks);
+	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, (uint32_t)WIDE_TILE_K * W.layers[0].n_kblocks);
 }
 
 template <bool PROBE, int MT>
@@ -614,19 +721,19 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 
 NGP_WIDE_KERNEL void render_nerf_wide256(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	wide_body<false, 2>(M, C, F, P);
+	wide_body<false, 64 / WIDE_TILE_M>(M, C, F, P);
 }
 NGP_WIDE_KERNEL void render_nerf_wide128(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
-	wide_body<false, 1>(M, C, F, P);
+	wide_body<false, 32 / WIDE_TILE_M>(M, C, F, P);
 }
 NGP_WIDE_KERNEL void trace_probe_wide256(const ModelParams M, const FrameParams F, const ProbeParams P) {
 	CameraParams C{};
-	wide_body<true, 2>(M, C, F, P);
+	wide_body<true, 64 / WIDE_TILE_M>(M, C, F, P);
 }
 NGP_WIDE_KERNEL void trace_probe_wide128(const ModelParams M, const FrameParams F, const ProbeParams P) {
 	CameraParams C{};
-	wide_body<true, 1>(M, C, F, P);
+	wide_body<true, 32 / WIDE_TILE_M>(M, C, F, P);
 }
 
 // NerfNetwork::inference on explicit inputs (ngp_network_inference): 128 samples per workgroup round
@@ -661,10 +768,10 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 	}
 }
 NGP_WIDE_KERNEL void network_inference_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
-	wide_inference_body<2>(M, n, pos01, dir01, out);
+	wide_inference_body<64 / WIDE_TILE_M>(M, n, pos01, dir01, out);
 }
 NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
-	wide_inference_body<1>(M, n, pos01, dir01, out);
+	wide_inference_body<32 / WIDE_TILE_M>(M, n, pos01, dir01, out);
 }
 // the position encoding alone (ngp_grid_encode's counterpart for this architecture): n x enc_dims halves
 __global__ void frequency_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {

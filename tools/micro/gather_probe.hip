@@ -16,11 +16,15 @@ template <> __device__ uint32_t fold<uint4>(uint4 v) { return v.x ^ v.y ^ v.z ^ 
 
 // MODE 0: every lane its own random entry. MODE 1: lanes in groups of 4 read 4 consecutive entries (one 4x wider
 // contiguous piece per group). MODE 2: pairs of lanes read 2 consecutive entries.
+// lanes_on: how many of a wave's 64 lanes issue the loads (exec mask) -- is a gather priced per wave-instruction or per active lane?
+// stride_sel 1: every (64 / lanes_on)-th lane; 0: the first lanes_on lanes
 template <typename T, int UNROLL, int MODE>
-__global__ __launch_bounds__(256) void gather(const T* __restrict__ table, uint32_t mask, int iters, uint32_t* out) {
+__global__ __launch_bounds__(256) void gather(const T* __restrict__ table, uint32_t mask, int iters, uint32_t* out, uint32_t lanes_on = 64u, uint32_t stride_sel = 0u) {
 	uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
 	uint32_t acc = 0;
 	const uint32_t lane = threadIdx.x & 63u;
+	const bool on = stride_sel ? (lane % (64u / lanes_on)) == 0u : lane < lanes_on;
+	if (!on) return;
 	for (int it = 0; it < iters; ++it) {
 		T v[UNROLL];
 #pragma unroll
@@ -42,33 +46,42 @@ __global__ __launch_bounds__(256) void gather(const T* __restrict__ table, uint3
 }
 
 template <typename T, int UNROLL, int MODE>
-void run(const char* name, void* d_table, size_t table_bytes, int blocks, uint32_t* d_out) {
+void run(const char* name, void* d_table, size_t table_bytes, int blocks, uint32_t* d_out, uint32_t lanes_on = 64u, uint32_t stride_sel = 0u) {
 	uint32_t n = (uint32_t)(table_bytes / sizeof(T));
 	uint32_t mask = n - 1;
 	int iters = 2000 / UNROLL * 4;
 	hipEvent_t a, b;
 	CHECK(hipEventCreate(&a));
 	CHECK(hipEventCreate(&b));
-	gather<T, UNROLL, MODE><<<blocks, 256>>>((const T*)d_table, mask, iters / 4, d_out);
+	gather<T, UNROLL, MODE><<<blocks, 256>>>((const T*)d_table, mask, iters / 4, d_out, lanes_on, stride_sel);
 	CHECK(hipEventRecord(a));
-	gather<T, UNROLL, MODE><<<blocks, 256>>>((const T*)d_table, mask, iters, d_out);
+	gather<T, UNROLL, MODE><<<blocks, 256>>>((const T*)d_table, mask, iters, d_out, lanes_on, stride_sel);
 	CHECK(hipEventRecord(b));
 	CHECK(hipEventSynchronize(b));
 	float ms = 0;
 	CHECK(hipEventElapsedTime(&ms, a, b));
-	double loads = (double)blocks * 256.0 * iters * UNROLL;
+	double loads = (double)blocks * 256.0 * iters * UNROLL * (lanes_on / 64.0);
 	double per_clk_cu = loads / (ms * 1e-3 * 2.4e9 * 256.0);
+	if (lanes_on != 64u) printf("[%2u of 64 lanes, %s] wave-instructions/clk/CU %.4f  ", lanes_on, stride_sel ? "strided" : "first", per_clk_cu / lanes_on);
 	printf("%-34s table %10.4f MB blocks %4d: %8.3f ms  %7.1f Glane-loads/s  %5.2f lane-loads/clk/CU (2.4 GHz)  %6.0f GB/s useful\n", name,
 	       table_bytes / 1048576.0, blocks, ms, loads / ms * 1e-6, per_clk_cu, loads * sizeof(T) / ms * 1e-6);
 }
 
-int main() {
+int main(int argc, char** argv) {
 	size_t max_bytes = 1ull << 30;
 	void* d_table;
 	uint32_t* d_out;
 	CHECK(hipMalloc(&d_table, max_bytes));
 	CHECK(hipMemset(d_table, 1, max_bytes));
 	CHECK(hipMalloc(&d_out, 4));
+	if (argc > 1) { // "masked": the same scattered 8-byte gather with 64 / 32 / 16 / 8 lanes of a wave switched on
+		for (size_t sz : {8ull << 10, 1ull << 20, 32ull << 20}) {
+			run<uint2, 16, 0>("8 B random, 16 in flight", d_table, sz, 2048, d_out);
+			for (uint32_t on : {32u, 16u, 8u})
+				for (uint32_t st : {0u, 1u}) run<uint2, 16, 0>("8 B random, 16 in flight", d_table, sz, 2048, d_out, on, st);
+		}
+		return 0;
+	}
 	size_t sizes[] = {256ull, 1ull << 10, 2ull << 10, 4ull << 10, 8ull << 10, 16ull << 10, 1ull << 20, 32ull << 20}; // 4 lines (every lane shares one), L1-resident, L2-resident, beyond L2
 	for (size_t sz : sizes) {
 		for (int blocks : {512, 2048}) {
