@@ -308,7 +308,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 		// terminates a ray are dropped by the compositor, exactly as the reference drops them.
 		// (how many: k_busy while more than half of the wave's ray slots are live, else as many as fit the list, at most k_drain)
 		const int n_live = __popcll(__ballot(ray.alive));
-		const int k_fit = SLOTS / (n_live > 0 ? n_live : 1);
+		const int k_fit = n_live <= 8 ? 8 : (n_live <= 10 ? 6 : (n_live <= 12 ? 5 : (n_live <= 16 ? 4 : (n_live <= 21 ? 3 : 2)))); // SLOTS / n_live without the division (wave-uniform compares)
 		const int k_max = PROBE ? 1 : (n_live > SLOTS / 2 ? F.tune[4] : (k_fit < F.tune[5] ? k_fit : F.tune[5]));
 		const int max_it = F.tune[1] > k_max ? F.tune[1] : k_max;
 		bool blocked = false; // found a sample but the list is full: the lane stands still until the next round
