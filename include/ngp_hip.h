@@ -60,7 +60,9 @@ typedef struct ngp_model_desc {
 	uint32_t log2_hashmap_size; /* 31 = tcnn DenseGrid: no level is ever hashed or capped */
 	uint32_t base_resolution;
 	float per_level_scale; /* explicit: the fork derives it with aabb_scale = 1, src/testbed.cu:3959-3966 */
-	/* tcnn FullyFusedMLP density / rgb heads (nerf_network.h:81-101) */
+	/* tcnn FullyFusedMLP / CutlassMLP density and rgb heads (nerf_network.h:81-101). Grid architecture: n_hidden_density 1 with
+	 * n_hidden_rgb 0..3 (configs/nerf/base_0layer .. base_3layer.json; base.json: 2), or both 0 (linear.json). A head without a
+	 * hidden layer is tcnn's CutlassMLP with one (padded output) x (input) matrix. */
 	uint32_t n_neurons;
 	uint32_t n_hidden_density;
 	uint32_t n_hidden_rgb;
@@ -85,7 +87,8 @@ typedef struct ngp_model_desc {
 	 *                 ignored, params_fp16 holds the two MLPs only)
 	 *   dir_encoding  0: SphericalHarmonics degree 4; 1: Frequency with dir_n_frequencies
 	 *   mlp_alignment 16: FullyFusedMLP, 8: CutlassMLP (0 = 16) -- what encodings, the rgb network's input and its output are padded
-	 *                 to (nerf_network.h:81-100)
+	 *                 to (nerf_network.h:81-100). For the grid architecture it is the RGB network's alignment (:83): 8 makes the rgb
+	 *                 output layer 8 rows (linear.json, base_0layer.json)
 	 * Inference only: ngp_train_* refuse such a model. */
 	uint32_t pos_encoding, pos_n_frequencies;
 	uint32_t dir_encoding, dir_n_frequencies;

@@ -204,7 +204,9 @@ class Oracle:
         de = scene.get("dir_encoding", {})
         if de.get("otype") == "Frequency":
             m.dir_encoding, m.dir_n_frequencies = 1, de["n_frequencies"]
-        m.mlp_alignment = 8 if scene["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+        # the rgb network's alignment (nerf_network.h:83): the rgb input and output are padded to it; Frequency encodings pad the
+        # position encoding to the density network's, and both networks are CutlassMLPs there
+        m.mlp_alignment = 8 if scene["rgb_network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
         m.n_neurons = scene["network"]["n_neurons"]
         m.n_hidden_density = scene["network"]["n_hidden_layers"]
         m.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]

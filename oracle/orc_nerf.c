@@ -176,6 +176,7 @@ int orc_grid_layout(const orc_nerf_model* m, uint32_t* offsets, uint32_t* resolu
 }
 
 static uint64_t mlp_n_params(uint32_t in, uint32_t width, uint32_t n_hidden, uint32_t out_padded) {
+	if (n_hidden == 0) return (uint64_t)out_padded * in; /* tcnn CutlassMLP with no hidden layer: one (padded output) x (input) matrix */
 	return (uint64_t)width * in + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)out_padded * width;
 }
 
@@ -204,7 +205,7 @@ uint64_t orc_n_params(const orc_nerf_model* m) {
 }
 
 int orc_nerf_prepare(orc_nerf_model* m) {
-	if (m->n_hidden_density < 1 || m->n_hidden_rgb < 1) return -2;
+	if (m->n_hidden_density > 8 || m->n_hidden_rgb > 8) return -2;
 	if (m->n_neurons > 256) return -4;
 	prepared_t* p = (prepared_t*)calloc(1, sizeof(prepared_t));
 	if (!p) return -1;
@@ -385,6 +386,10 @@ static void mlp_layer_ideal(const float* w, uint32_t n_out, uint32_t n_in, const
 }
 static void mlp_forward_ideal(const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const double* in, double* out) {
 	double a[256], b[256];
+	if (n_hidden == 0) { /* configs/nerf/linear.json: the output layer alone */
+		mlp_layer_ideal(w, n_out, n_in, in, 0, out);
+		return;
+	}
 	mlp_layer_ideal(w, width, n_in, in, 1, a);
 	w += (size_t)width * n_in;
 	double* cur = a;
@@ -401,6 +406,10 @@ static void mlp_forward_ideal(const float* w, uint32_t n_in, uint32_t width, uin
 static void mlp_forward(uint32_t mode, const float* w, uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out, const float* in, float* out_f, uint16_t* out_h) {
 	void (*layer)(const float*, uint32_t, uint32_t, const float*, int, float*, uint16_t*) = mode == ORC_MLP_ACC_FP16_K16 ? mlp_layer_fp16_k16 : mlp_layer;
 	float a[256], b[256];
+	if (n_hidden == 0) { /* configs/nerf/linear.json: the output layer alone (output_activation None) */
+		layer(w, n_out, n_in, in, 0, out_f, out_h);
+		return;
+	}
 	layer(w, width, n_in, in, 1, a, NULL);
 	w += (size_t)width * n_in;
 	float* cur = a;
@@ -559,7 +568,7 @@ static void density_gradient_one(const orc_nerf_model* m, const prepared_t* p, c
 	const uint32_t F = m->n_features_per_level, W = m->n_neurons, E = p->enc_dims, NH = m->n_hidden_density;
 	uint16_t enc_h[ORC_MAX_LEVELS * 8];
 	grid_encode_one(m, p, x, enc_h);
-	float act[9][256]; /* act[0] = encoding, act[k] = hidden layer k (as floats of the fp16 values) */
+	float act[9][256] = {{0.0f}}; /* act[0] = encoding, act[k] = hidden layer k (as floats of the fp16 values) */
 	for (uint32_t i = 0; i < E; ++i) act[0][i] = orc_half_to_float(enc_h[i]);
 	const float* w = p->density_w;
 	const float* layer_w[9];
@@ -572,11 +581,12 @@ static void density_gradient_one(const orc_nerf_model* m, const prepared_t* p, c
 	}
 	uint16_t out_h[32];
 	float out_f[32];
-	mlp_layer(w, m->density_out_dims, W, act[NH], 0, out_f, out_h);
+	mlp_layer(w, m->density_out_dims, n_in, act[NH], 0, out_f, out_h);
 	if (logit_out) *logit_out = out_h[0];
-	/* backward: d(128 * logit) / d hidden NH = 128 * W_out[0][:], masked by the forward ReLU */
+	/* backward: d(128 * logit) / d hidden NH = 128 * W_out[0][:], masked by the forward ReLU (no mask on the encoding itself when
+	 * there is no hidden layer) */
 	float g[256], g_prev[256];
-	for (uint32_t i = 0; i < W; ++i) g[i] = act[NH][i] > 0.0f ? orc_half_to_float(orc_float_to_half(128.0f * w[i])) : 0.0f;
+	for (uint32_t i = 0; i < n_in; ++i) g[i] = NH == 0 || act[NH][i] > 0.0f ? orc_half_to_float(orc_float_to_half(128.0f * w[i])) : 0.0f;
 	for (uint32_t l = NH; l-- > 0;) {
 		const uint32_t n_prev = l == 0 ? E : W;
 		for (uint32_t i = 0; i < n_prev; ++i) {

@@ -895,8 +895,10 @@ NGP_DEV Sh4 sh4_from_dir(int h, float dx01, float dy01, float dz01) {
 }
 
 // density head alone (NerfNetwork::density, nerf_network.h): the logit of sample c in lanes 0..15
+template <bool DLIN = false>
 NGP_DEV half_t density_pass(const uint4* s_w, int lane, half8 enc) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+	if (DLIN) return (half_t)mfma16(ld_frag(s_w, FRAG_D0, lane), enc, zero)[0]; // configs/nerf/linear.json: the 16 x 32 output layer alone
 	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
 	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
 	floatx4 d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
@@ -908,17 +910,26 @@ NGP_DEV half_t density_pass(const uint4* s_w, int lane, half8 enc) {
 }
 // RGB_MID: the number of 64x64 layers of the rgb head = its n_hidden_layers - 1 (configs/nerf/base.json: 1;
 // base_1layer.json 0, base_3layer.json 2). Their fragments follow FRAG_R1 eight at a time, the output layer's come last.
+// RGB_MID -1 (base_0layer.json): the rgb head is its output layer alone (a CutlassMLP: 8 padded rows, zero rows above them in the
+// fragment); RGB_MID -2 (linear.json): so is the density head. One MFMA each.
 template <int RGB_MID = 1>
 NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-	// density head: 32 -> 64 (ReLU) -> 16
-	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
-	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
-	floatx4 d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
-	floatx4 d3 = mfma16(ld_frag(s_w, FRAG_D0 + 3, lane), enc, zero);
-	half8 b0 = relu_pack(d0, d1), b1 = relu_pack(d2, d3);
-	floatx4 dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
-	dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
+	floatx4 d0, d1, d2, d3, dens;
+	half8 b0, b1;
+	if (RGB_MID == -2) {
+		dens = mfma16(ld_frag(s_w, FRAG_D0, lane), enc, zero);
+	} else {
+		// density head: 32 -> 64 (ReLU) -> 16
+		d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
+		d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);
+		d2 = mfma16(ld_frag(s_w, FRAG_D0 + 2, lane), enc, zero);
+		d3 = mfma16(ld_frag(s_w, FRAG_D0 + 3, lane), enc, zero);
+		b0 = relu_pack(d0, d1);
+		b1 = relu_pack(d2, d3);
+		dens = mfma16(ld_frag(s_w, FRAG_D1 + 0, lane), b0, zero);
+		dens = mfma16(ld_frag(s_w, FRAG_D1 + 1, lane), b1, dens);
+	}
 	// rgb head input: [density out 4h..4h+3 | SH 4h..4h+3]
 	half8 rin;
 #pragma unroll
@@ -928,6 +939,13 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 	}
 	MlpOut out;
 	out.sigma = rin[0];
+	if (RGB_MID < 0) {
+		const floatx4 lin = mfma16(ld_frag(s_w, FRAG_R0, lane), rin, zero);
+		out.rgb[0] = (half_t)lin[0];
+		out.rgb[1] = (half_t)lin[1];
+		out.rgb[2] = (half_t)lin[2];
+		return out;
+	}
 	// rgb head: 32 -> 64 (ReLU) [-> 64 (ReLU)] x RGB_MID -> 16
 	d0 = mfma16(ld_frag(s_w, FRAG_R0 + 0, lane), rin, zero);
 	d1 = mfma16(ld_frag(s_w, FRAG_R0 + 1, lane), rin, zero);
@@ -949,8 +967,9 @@ NGP_DEV MlpOut mlp_pass(const uint4* s_w, int lane, half8 enc, Sh4 shq) {
 		b0 = relu_pack(d0, d1);
 		b1 = relu_pack(d2, d3);
 	}
-	floatx4 rgb = mfma16(ld_frag(s_w, FRAG_R1 + 8 * RGB_MID + 0, lane), b0, zero);
-	rgb = mfma16(ld_frag(s_w, FRAG_R1 + 8 * RGB_MID + 1, lane), b1, rgb);
+	constexpr int f_out = FRAG_R1 + 8 * (RGB_MID < 0 ? 0 : RGB_MID);
+	floatx4 rgb = mfma16(ld_frag(s_w, f_out + 0, lane), b0, zero);
+	rgb = mfma16(ld_frag(s_w, f_out + 1, lane), b1, rgb);
 	out.rgb[0] = (half_t)rgb[0];
 	out.rgb[1] = (half_t)rgb[1];
 	out.rgb[2] = (half_t)rgb[2];
@@ -1003,8 +1022,21 @@ NGP_DEV void encode_gradient(const EncodeInFlight& e, float scale0, float scale1
 		}
 	}
 }
-NGP_DEV DensityGrad density_gradient_pass(const uint4* s_w, const uint4* __restrict__ g_wfrags, int lane, const EncodeInFlight& e, half8 enc, float scale0, float scale1) {
+// linear (wave-uniform): the density head has no hidden layer (configs/nerf/linear.json) -- dL_dy is 128 * W[0][:] itself, unmasked
+NGP_DEV DensityGrad density_gradient_pass(const uint4* s_w, const uint4* __restrict__ g_wfrags, int lane, const EncodeInFlight& e, half8 enc, float scale0, float scale1, bool linear = false) {
 	const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+	if (linear) {
+		// row 0 of the only fragment sits in the lanes with (lane & 15) == 0, in the encoding's K order: element j of lane (h, .) is
+		// W[0][16 (j >> 2) + 4 h + (j & 3)] -- feature j & 3 of level h (j < 4) or h + 4
+		const half8 w = ld_frag(s_w, FRAG_D0, lane & 48);
+		float dLdy[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) dLdy[j] = (float)(half_t)((half_t)128.0f * w[j]);
+		DensityGrad out;
+		encode_gradient(e, scale0, scale1, dLdy, out.g);
+		out.sigma = (half_t)mfma16(ld_frag(s_w, FRAG_D0, lane), enc, zero)[0];
+		return out;
+	}
 	// forward: 32 -> 64 (ReLU) -> 16
 	floatx4 d0 = mfma16(ld_frag(s_w, FRAG_D0 + 0, lane), enc, zero);
 	floatx4 d1 = mfma16(ld_frag(s_w, FRAG_D0 + 1, lane), enc, zero);

@@ -495,7 +495,7 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				EncodeInFlight e;
 				encode_issue(t_grid, t_xgrid, s_lv, hq, ax, ay, az, e);
 				const half8 enc = encode_finish(e);
-				DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale);
+				DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale, M.density_linear != 0);
 #pragma unroll
 				for (int k = 0; k < 3; ++k) { // the four lanes of a sample hold two levels each
 					dg.g[k] += __shfl_xor(dg.g[k], 16, 64);
@@ -676,7 +676,15 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_mid2(const ModelPa
 	ProbeParams P{};
 	fused_body<false, false, false, (int)NERF_CASCADES, true, 2>(M, C, F, P);
 }
-// diagnostic twin with s_memtime stamps between the sections of the loop; its run time is not a benchmark
+// heads without a hidden layer: configs/nerf/base_0layer.json (the rgb head is one matrix) and linear.json (both are)
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_lin_rgb(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, (int)NERF_CASCADES, true, -1>(M, C, F, P);
+}
+__global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_lin(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	fused_body<false, false, false, (int)NERF_CASCADES, true, -2>(M, C, F, P);
+}
 __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, false, false, (int)NERF_CASCADES, true, 1, false, true>(M, C, F, P);
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(BLOCK) void density_gradient_kernel(const ModelPara
 		EncodeInFlight e;
 		encode_issue(t_grid, t_xgrid, s_lv, hq, pos01[3 * sc], pos01[3 * sc + 1], pos01[3 * sc + 2], e);
 		const half8 enc = encode_finish(e);
-		DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale);
+		DensityGrad dg = density_gradient_pass(s_w, M.wfrags, lane, e, enc, s_lv[hq].scale, s_lv[hq + 4].scale, M.density_linear != 0);
 #pragma unroll
 		for (int k = 0; k < 3; ++k) {
 			dg.g[k] += __shfl_xor(dg.g[k], 16, 64);
@@ -874,6 +882,7 @@ __global__ __launch_bounds__(BLOCK) void density_gradient_kernel(const ModelPara
 // splat_grid_samples_nerf_max_nearest_neighbor in one kernel (src/testbed_nerf.cu:185-232, 2812-2852). A wave owns
 // 64 samples: every lane draws its sample (cell, position), then four 16-sample passes run the hash-grid encode and
 // the density head on MFMA exactly like the render kernel, and lanes 0..15 splat their pass's results.
+template <bool DLIN> // DLIN: a density head without a hidden layer (configs/nerf/linear.json)
 __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const ModelParams M, uint32_t n_samples, Pcg32 rng, uint32_t step, uint32_t n_cascades,
                                                                      float thresh, const float* __restrict__ grid_in, float* __restrict__ grid_tmp) {
 	__shared__ uint4 s_w[N_FRAGS * 64];
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(BLOCK) void density_grid_samples_kernel(const Model
 		const uint32_t s_idx = (uint32_t)__shfl((int)idx, src, 64);
 		const int s_valid = __shfl(valid ? 1 : 0, src, 64);
 		half8 enc = encode_level_pair(t_grid, t_xgrid, s_lv, lane >> 4, sx, sy, sz);
-		half_t logit = density_pass(s_w, lane, enc);
+		half_t logit = density_pass<DLIN>(s_w, lane, enc);
 		if (lane < 16 && s_valid) {
 			// optical thickness of the smallest step (level 0, :218); positive floats order like their bit patterns
 			float thickness = network_to_density((float)logit, M.density_act) * stepsize();
@@ -1138,11 +1147,14 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 		hipLaunchKernelGGL(render_nerf_fused_normals, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		return;
 	}
-	if (M.rgb_mid != 1) { // the base_1layer / base_3layer heads: one general kernel each
-		static const int per_cu_mid0 = resident_blocks_per_cu(render_nerf_fused_mid0), per_cu_mid2 = resident_blocks_per_cu(render_nerf_fused_mid2);
-		const int nb = grid_blocks(F, n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : per_cu_mid2));
+	if (M.rgb_mid != 1) { // the base_0layer / base_1layer / base_3layer / linear heads: one general kernel each
+		static const int per_cu_mid0 = resident_blocks_per_cu(render_nerf_fused_mid0), per_cu_mid2 = resident_blocks_per_cu(render_nerf_fused_mid2),
+		                 per_cu_lin_rgb = resident_blocks_per_cu(render_nerf_fused_lin_rgb), per_cu_lin = resident_blocks_per_cu(render_nerf_fused_lin);
+		const int nb = grid_blocks(F, n_cus * (M.rgb_mid == 0 ? per_cu_mid0 : M.rgb_mid == 2 ? per_cu_mid2 : M.density_linear ? per_cu_lin : per_cu_lin_rgb));
 		const FrameParams G = with_grid(F, nb);
 		if (M.rgb_mid == 0) hipLaunchKernelGGL(render_nerf_fused_mid0, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
+		else if (M.rgb_mid < 0 && M.density_linear) hipLaunchKernelGGL(render_nerf_fused_lin, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
+		else if (M.rgb_mid < 0) hipLaunchKernelGGL(render_nerf_fused_lin_rgb, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		else hipLaunchKernelGGL(render_nerf_fused_mid2, dim3(nb), dim3(BLOCK), 0, stream, M, C, G);
 		return;
 	}
@@ -1201,7 +1213,9 @@ void launch_grid_encode(const ModelParams& M, uint32_t n, const float* pos01, ui
 }
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream) {
 	uint32_t n_waves = (n + 63) / 64;
-	if (M.rgb_mid == 0) hipLaunchKernelGGL(network_inference_kernel<0>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	if (M.rgb_mid < 0 && M.density_linear) hipLaunchKernelGGL(network_inference_kernel<-2>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	else if (M.rgb_mid < 0) hipLaunchKernelGGL(network_inference_kernel<-1>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
+	else if (M.rgb_mid == 0) hipLaunchKernelGGL(network_inference_kernel<0>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 	else if (M.rgb_mid == 2) hipLaunchKernelGGL(network_inference_kernel<2>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 	else hipLaunchKernelGGL(network_inference_kernel<1>, dim3((n_waves + 3) / 4), dim3(BLOCK), 0, stream, M, n, pos01, dir01, out);
 }
@@ -1214,7 +1228,9 @@ void launch_density_gradient(const ModelParams& M, uint32_t n, const float* pos0
 }
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,
                                 float* grid_tmp, hipStream_t stream) {
-	if (n_samples) hipLaunchKernelGGL(density_grid_samples_kernel, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, grid_tmp);
+	if (!n_samples) return;
+	if (M.density_linear) hipLaunchKernelGGL(density_grid_samples_kernel<true>, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, grid_tmp);
+	else hipLaunchKernelGGL(density_grid_samples_kernel<false>, dim3((n_samples + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, M, n_samples, rng, step, n_cascades, thresh, grid, grid_tmp);
 }
 void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, int n_cus, hipStream_t stream);
 // scratch: n_samples x (3 floats + 1 cell index + 4 fp16 outputs), owned by the caller

@@ -244,6 +244,7 @@ void build_xor_layout(LevelInfo* lv, uint32_t n_levels, const uint16_t* grid /* 
 }
 
 uint64_t mlp_n_params(uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t n_out) {
+	if (n_hidden == 0) return (uint64_t)n_out * n_in; // tcnn CutlassMLP without a hidden layer: one (padded output) x (input) matrix
 	return (uint64_t)width * n_in + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)n_out * width;
 }
 
@@ -251,15 +252,16 @@ uint64_t mlp_n_params(uint32_t n_in, uint32_t width, uint32_t n_hidden, uint32_t
 // row = l&15), element j: W[16m + row][n(s,h,j)], n(s,h,j) = 32s + 16(j>>2) + 4h + (j&3). The K permutation n() is
 // the order in which the previous layer's accumulator tiles (and the encoder's level pairs) already sit in the
 // B operand's registers, so no activation ever moves between lanes (nerf_device.h mlp_pass).
+// n_out rows are stored (a CutlassMLP's output layer: 8); tiles are filled up with zero rows.
 void emit_fragments(std::vector<uint16_t>& frags, int first_frag, const uint16_t* W, int n_out, int n_in) {
 	int f = first_frag;
-	for (int m = 0; m < n_out / 16; ++m) {
+	for (int m = 0; m < (n_out + 15) / 16; ++m) {
 		for (int s = 0; s < n_in / 32; ++s, ++f) {
 			for (int l = 0; l < 64; ++l) {
 				int h = l >> 4, row = l & 15;
 				for (int j = 0; j < 8; ++j) {
 					int k = 32 * s + 16 * (j >> 2) + 4 * h + (j & 3);
-					frags[((size_t)f * 64 + l) * 8 + j] = W[(size_t)(16 * m + row) * n_in + k];
+					frags[((size_t)f * 64 + l) * 8 + j] = 16 * m + row < n_out ? W[(size_t)(16 * m + row) * n_in + k] : (uint16_t)0;
 				}
 			}
 		}
@@ -334,10 +336,11 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 			                         "neurons with 1 or more hidden layers, a 16-wide density output, up to 40 position and 4 direction frequencies");
 		}
 	} else
-	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density != 1 ||
-	    d.n_hidden_rgb < 1 || d.n_hidden_rgb > 1 + (uint32_t)MAX_RGB_MID || d.density_out_dims != 16) {
-		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json "
-		                         "(HashGrid 8 levels x 4 features, density MLP 64x1 hidden -> 16, rgb MLP 64 wide with 1 to 3 hidden layers)");
+	if (d.n_levels != N_LEVELS || d.n_features_per_level != N_FEATURES || d.n_neurons != MLP_WIDTH || d.n_hidden_density > 1 ||
+	    d.n_hidden_rgb > 1 + (uint32_t)MAX_RGB_MID || d.density_out_dims != 16 || (d.n_hidden_density == 0 && d.n_hidden_rgb != 0)) {
+		throw std::runtime_error("unsupported network architecture: the HIP path is specialised for configs/nerf/base.json and its variants "
+		                         "(HashGrid 8 levels x 4 features; density MLP 64x1 hidden -> 16 with an rgb MLP 64 wide of 0 to 3 hidden layers -- "
+		                         "base, base_0layer .. base_3layer --, or both heads without a hidden layer -- linear.json)");
 	}
 	if (!wide && ((d.log2_hashmap_size > 28 && d.log2_hashmap_size != 31) || d.base_resolution == 0 || !(d.per_level_scale > 0.f))) throw std::runtime_error("invalid hash grid configuration");
 	if (d.aabb_scale == 0 || (d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error("NeRF dataset's `aabb_scale` must be a power of two"); // testbed_nerf.cu:2707
@@ -349,7 +352,8 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	const WideShapes ws = wide_shapes(d);
 	const uint32_t enc_dims = wide ? ws.enc_dims : d.n_levels * d.n_features_per_level;
 	const uint64_t nd = mlp_n_params(enc_dims, d.n_neurons, d.n_hidden_density, d.density_out_dims);
-	const uint64_t nr = wide ? mlp_n_params(ws.rgb_in, d.n_neurons, d.n_hidden_rgb, ws.rgb_out) : mlp_n_params(d.density_out_dims + 16u, d.n_neurons, d.n_hidden_rgb, 16u);
+	// (grid models: the rgb input is 16 + 16 wide under either alignment; the output is padded to the rgb network's -- 8 rows for a CutlassMLP)
+	const uint64_t nr = wide ? mlp_n_params(ws.rgb_in, d.n_neurons, d.n_hidden_rgb, ws.rgb_out) : mlp_n_params(d.density_out_dims + 16u, d.n_neurons, d.n_hidden_rgb, ws.rgb_out);
 	const uint64_t ng = wide ? 0 : (uint64_t)total_entries * d.n_features_per_level;
 	if (d.n_params != nd + nr + ng || !d.params_fp16) {
 		throw std::runtime_error("parameter count mismatch: snapshot has " + std::to_string(d.n_params) + ", network needs " + std::to_string(nd + nr + ng));
@@ -425,14 +429,23 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 	// weight fragments
 	std::vector<uint16_t> frags((size_t)(N_FRAGS_MAX + N_NORMALS_FRAGS) * 64 * 8, 0); // (the Normals mode's four are permuted out of the forward ones on the device, below)
 	const uint16_t* W = ctx->params.data();
-	emit_fragments(frags, FRAG_D0, W, 64, 32);
-	emit_fragments(frags, FRAG_D1, W + 64 * 32, 16, 64);
+	if (d.n_hidden_density == 0) {
+		emit_fragments(frags, FRAG_D0, W, 16, 32); // configs/nerf/linear.json: the 16 x 32 output layer alone
+	} else {
+		emit_fragments(frags, FRAG_D0, W, 64, 32);
+		emit_fragments(frags, FRAG_D1, W + 64 * 32, 16, 64);
+	}
 	const uint16_t* R = W + nd;
-	const int rgb_mid = (int)d.n_hidden_rgb - 1; // 64x64 layers between the first and the output layer of the rgb head
-	emit_fragments(frags, FRAG_R0, R, 64, 32);
-	for (int k = 0; k < rgb_mid; ++k) emit_fragments(frags, FRAG_R1 + 8 * k, R + 64 * 32 + (size_t)k * 64 * 64, 64, 64);
-	emit_fragments(frags, FRAG_R1 + 8 * rgb_mid, R + 64 * 32 + (size_t)rgb_mid * 64 * 64, 16, 64);
-	M.rgb_mid = (uint32_t)rgb_mid;
+	const int rgb_mid = (int)d.n_hidden_rgb - 1; // 64x64 layers between the first and the output layer of the rgb head; -1: the output layer alone
+	if (rgb_mid < 0) {
+		emit_fragments(frags, FRAG_R0, R, (int)ws.rgb_out, 32);
+	} else {
+		emit_fragments(frags, FRAG_R0, R, 64, 32);
+		for (int k = 0; k < rgb_mid; ++k) emit_fragments(frags, FRAG_R1 + 8 * k, R + 64 * 32 + (size_t)k * 64 * 64, 64, 64);
+		emit_fragments(frags, FRAG_R1 + 8 * rgb_mid, R + 64 * 32 + (size_t)rgb_mid * 64 * 64, (int)ws.rgb_out, 64);
+	}
+	M.rgb_mid = rgb_mid;
+	M.density_linear = d.n_hidden_density == 0 ? 1u : 0u;
 	NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
 	NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 	launch_build_normals_fragments(ctx->d_wfrags, ctx->stream);
@@ -711,7 +724,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 			return t == "cutlassmlp";
 		};
 		if (is_cutlass(net) != is_cutlass(rgb) && d.pos_encoding == 1) throw std::runtime_error("unsupported network otype: density and rgb networks of different kinds");
-		d.mlp_alignment = (d.pos_encoding == 1 && is_cutlass(net)) ? 8u : 16u;
+		d.mlp_alignment = is_cutlass(rgb) ? 8u : 16u; // grid models (base_0layer.json mixes the kinds): the rgb network's, nerf_network.h:83
 	}
 	{ // what the kernels hard-wire beyond the shapes: ReLU hidden layers without an output activation, and a direction encoding of
 	  // SphericalHarmonics degree 4 (bare, or first in a Composite whose remainder is Identity: configs/nerf/base.json). A snapshot
@@ -1490,17 +1503,17 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 			if (d.log2_hashmap_size != 31) e["log2_hashmap_size"] = mj::Value::make_uint(d.log2_hashmap_size);
 			e["base_resolution"] = mj::Value::make_uint(d.base_resolution);
 			root["encoding"] = e;
-			auto mlp = [&](uint32_t hidden) {
+			auto mlp = [&](uint32_t hidden, bool cutlass) {
 				mj::Value n = mj::Value::make_object();
-				n["otype"] = mj::Value::make_string("FullyFusedMLP");
+				n["otype"] = mj::Value::make_string(cutlass ? "CutlassMLP" : "FullyFusedMLP");
 				n["activation"] = mj::Value::make_string("ReLU");
 				n["output_activation"] = mj::Value::make_string("None");
 				n["n_neurons"] = mj::Value::make_uint(d.n_neurons);
 				n["n_hidden_layers"] = mj::Value::make_uint(hidden);
 				return n;
 			};
-			root["network"] = mlp(d.n_hidden_density);
-			root["rgb_network"] = mlp(d.n_hidden_rgb);
+			root["network"] = mlp(d.n_hidden_density, d.n_hidden_density == 0);
+			root["rgb_network"] = mlp(d.n_hidden_rgb, d.mlp_alignment == 8);
 			mj::Value de = mj::Value::make_object();
 			de["otype"] = mj::Value::make_string("Composite");
 			mj::Value nested = mj::Value::make_array();

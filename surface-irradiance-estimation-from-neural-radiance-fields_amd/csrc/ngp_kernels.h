@@ -23,7 +23,9 @@ constexpr int FRAG_D0 = 0, FRAG_D1 = 4, FRAG_R0 = 6, FRAG_R1 = 10, FRAG_R2 = 18,
 // other rgb heads (n_hidden_layers 1 or 3, configs/nerf/base_1layer.json / base_3layer.json): 0 or 2 layers of 64x64 at
 // FRAG_R1, the output layer behind them; the fragment buffer always holds N_FRAGS_MAX
 constexpr int MAX_RGB_MID = 2, N_FRAGS_MAX = FRAG_R1 + 8 * MAX_RGB_MID + 2;
-constexpr int n_frags_for(int rgb_mid) { return FRAG_R1 + 8 * rgb_mid + 2; }
+// rgb_mid -1 (configs/nerf/linear.json, base_0layer.json): the rgb head is its output layer alone, one fragment at FRAG_R0; a density
+// head without a hidden layer (linear.json) is one fragment at FRAG_D0
+constexpr int n_frags_for(int rgb_mid) { return rgb_mid < 0 ? FRAG_R0 + 1 : FRAG_R1 + 8 * rgb_mid + 2; }
 // behind them, four fragments of the density head's first layer transposed: the backward pass of ERenderMode::Normals (nerf_device.h)
 constexpr int N_NORMALS_FRAGS = 4, FRAG_NORMALS = N_FRAGS_MAX;
 
@@ -101,7 +103,8 @@ struct ModelParams {
 	uint32_t max_cascade;
 	float cone_angle;
 	uint32_t rgb_act, density_act;
-	uint32_t rgb_mid;      // 64x64 layers of the rgb head (n_hidden_layers - 1): 1 for configs/nerf/base.json
+	int32_t rgb_mid;       // 64x64 layers of the rgb head (n_hidden_layers - 1): 1 for configs/nerf/base.json, -1 for a head without a hidden layer
+	uint32_t density_linear; // the density head has no hidden layer (configs/nerf/linear.json; rgb_mid is -1 then)
 	uint32_t r2l_identity; // render_aabb_to_local is the identity (the usual case): skip the matrix product
 	uint32_t diag_pow2;    // every component of aabb_diag is a power of two: x / diag == x * (1/diag) bit for bit
 	float aabb_inv_diag[3];

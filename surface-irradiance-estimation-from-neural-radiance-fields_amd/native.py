@@ -352,11 +352,14 @@ class Context:
             de = scene.get("dir_encoding", {})
             if de.get("otype") == "Frequency":
                 d.dir_encoding, d.dir_n_frequencies = 1, de["n_frequencies"]
-            d.mlp_alignment = 8 if scene["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+            if scene["network"].get("otype", "FullyFusedMLP") != scene["rgb_network"].get("otype", "FullyFusedMLP"):
+                raise ValueError("Frequency encodings: the density and the rgb network must be of the same otype")
         else:
             d.n_levels, d.n_features_per_level = enc["n_levels"], enc["n_features_per_level"]
             d.log2_hashmap_size, d.base_resolution = enc["log2_hashmap_size"], enc["base_resolution"]
             d.per_level_scale = enc["per_level_scale"]
+        # the rgb network's alignment (nerf_network.h:83): 8 for CutlassMLP (linear.json, base_0layer.json, frequency.json)
+        d.mlp_alignment = 8 if scene["rgb_network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
         d.n_neurons = scene["network"]["n_neurons"]
         d.n_hidden_density = scene["network"]["n_hidden_layers"]
         d.n_hidden_rgb = scene["rgb_network"]["n_hidden_layers"]
@@ -407,8 +410,8 @@ class Context:
         return {
             "encoding": {"otype": "HashGrid", "n_levels": d.n_levels, "n_features_per_level": d.n_features_per_level, "log2_hashmap_size": d.log2_hashmap_size,
                          "base_resolution": d.base_resolution, "per_level_scale": float(d.per_level_scale)},
-            "network": {"otype": "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_density, "n_output_dims": d.density_out_dims},
-            "rgb_network": {"otype": "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_rgb},
+            "network": {"otype": "CutlassMLP" if d.n_hidden_density == 0 else "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_density, "n_output_dims": d.density_out_dims},
+            "rgb_network": {"otype": "CutlassMLP" if d.mlp_alignment == 8 else "FullyFusedMLP", "n_neurons": d.n_neurons, "n_hidden_layers": d.n_hidden_rgb},
             "rgb_activation": d.rgb_activation, "density_activation": d.density_activation,
             "params": params, "density_grid": grid,
             "aabb": (tuple(d.aabb_min), tuple(d.aabb_max)), "render_aabb": (tuple(d.render_aabb_min), tuple(d.render_aabb_max)), "render_aabb_to_local": r2l,

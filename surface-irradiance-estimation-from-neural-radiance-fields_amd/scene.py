@@ -23,6 +23,16 @@ def base_network_config():
     }
 
 
+def linear_network_config(hidden_density=0):
+    """configs/nerf/linear.json (hidden_density 0: both heads a single matrix, CutlassMLP) and configs/nerf/base_0layer.json
+    (hidden_density 1: the base.json density head, the rgb head a single matrix), merged over base.json."""
+    cfg = base_network_config()
+    if hidden_density == 0:
+        cfg["network"].update({"otype": "CutlassMLP", "n_hidden_layers": 0})
+    cfg["rgb_network"].update({"otype": "CutlassMLP", "n_hidden_layers": 0})
+    return cfg
+
+
 def frequency_network_config(n_neurons=256, n_hidden_density=7, n_hidden_rgb=1):
     """configs/nerf/frequency.json merged over base.json: the original NeRF's architecture -- Frequency encodings (16 / 4
     frequencies), CutlassMLPs 256 wide with 7 + 1 hidden layers."""
@@ -36,12 +46,13 @@ def frequency_network_config(n_neurons=256, n_hidden_density=7, n_hidden_rgb=1):
 
 def network_shapes(cfg):
     """(position encoding width, direction encoding width, rgb network input width, rgb network output width) as NerfNetwork derives
-    them (nerf_network.h:81-100): encodings, the rgb input and the rgb output are padded to the MLP's alignment -- 16 for
-    FullyFusedMLP, 8 for CutlassMLP."""
-    al = 8 if cfg["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+    them (nerf_network.h:81-100): the position encoding is padded to the density network's alignment, the direction encoding, the
+    rgb input and the rgb output to the rgb network's -- 16 for FullyFusedMLP, 8 for CutlassMLP."""
+    al_pos = 8 if cfg["network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
+    al = 8 if cfg["rgb_network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
     up = lambda v: (v + al - 1) // al * al
     enc = cfg["encoding"]
-    enc_dims = up(3 * 2 * enc["n_frequencies"]) if enc.get("otype") == "Frequency" else enc["n_levels"] * enc["n_features_per_level"]
+    enc_dims = (3 * 2 * enc["n_frequencies"] + al_pos - 1) // al_pos * al_pos if enc.get("otype") == "Frequency" else enc["n_levels"] * enc["n_features_per_level"]
     de = cfg.get("dir_encoding", {})
     dir_dims = up(3 * 2 * de["n_frequencies"]) if de.get("otype") == "Frequency" else 16
     dens_out = cfg["network"].get("n_output_dims", 16)
@@ -76,6 +87,8 @@ def grid_layout(enc):
 
 
 def mlp_n_params(n_in, width, n_hidden, n_out_padded):
+    if n_hidden == 0:  # tcnn CutlassMLP without a hidden layer: one (padded output) x (input) matrix
+        return n_out_padded * n_in
     return width * n_in + (n_hidden - 1) * width * width + n_out_padded * width
 
 

@@ -121,6 +121,8 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
         return rng.uniform(-s, s, size=(n_out, n_in)).astype(np.float32)
 
     def mlp(n_in, n_hidden, n_out):
+        if n_hidden == 0:  # configs/nerf/linear.json: the output layer alone
+            return [xavier(n_out, n_in)]
         layers = [xavier(width, n_in)]
         for _ in range(n_hidden - 1):
             layers.append(xavier(width, width))
@@ -151,7 +153,10 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
     for W in dens_layers[:-1]:
         h = np.maximum(h @ W.T, 0)
     logit = h @ dens_layers[-1][0]
-    dens_layers[-1][0] *= np.float32(target_logit / max(float(logit.mean()), 1e-6))
+    if len(dens_layers) == 1:  # a linear head over zero-mean features has a zero-mean logit: calibrate its spread instead
+        dens_layers[-1][0] *= np.float32(target_logit / max(float(logit.std()), 1e-6))
+    else:
+        dens_layers[-1][0] *= np.float32(target_logit / max(float(logit.mean()), 1e-6))
 
     params = np.concatenate([W.reshape(-1) for W in dens_layers] + [W.reshape(-1) for W in rgb_layers] + [grid]).astype(np.float16)
     assert params.size == nd + nr + ng

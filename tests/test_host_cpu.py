@@ -320,7 +320,7 @@ def test_snapshot_session_state_roundtrip(tmp_path, native):
     assert np.allclose(c2["matrix"], cam, atol=1e-7) and c2["fov_axis"] == 0 and np.allclose(c2["relative_focal_length"], [1.3, 1.3]) and abs(c2["zoom"] - 1.5) < 1e-7
 
 
-def test_model_validation(native):
+def test_model_validation(native, scene_mod, tmp_path):
     sc = pkg("synthetic").make_scene(aabb_scale=1, seed=5, log2_hashmap_size=12)
     ctx = native.Context(-1)
     for key, val, msg in (("aabb_scale", 3, "power of two"), ("aabb_scale", 256, "aabb_scale <= 128")):
@@ -335,6 +335,23 @@ def test_model_validation(native):
     bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=3)  # base_3layer.json: accepted, but the parameter count must follow
     with pytest.raises(RuntimeError, match="parameter count mismatch"):
         ctx.set_model(bad)
+    bad["rgb_network"] = dict(sc["rgb_network"], n_hidden_layers=2)
+    bad["network"] = dict(sc["network"], n_hidden_layers=0)  # a linear density head comes with a linear rgb head (configs/nerf/linear.json)
+    with pytest.raises(RuntimeError, match="unsupported network architecture"):
+        ctx.set_model(bad)
+    # configs/nerf/linear.json and base_0layer.json: heads without a hidden layer; CutlassMLP pads the rgb output to 8 rows
+    for hidden_density, n_mlp in ((0, 16 * 32 + 8 * 32), (1, 64 * 32 + 16 * 64 + 8 * 32)):
+        lin = pkg("synthetic").make_scene(aabb_scale=1, seed=5, log2_hashmap_size=14, cfg=scene_mod.linear_network_config(hidden_density))
+        assert sum(scene_mod.n_params(lin)[:2]) == n_mlp
+        ctx.set_model(lin)
+        d = ctx.get_model()
+        assert (d.n_hidden_density, d.n_hidden_rgb, d.mlp_alignment, d.n_params) == (hidden_density, 0, 8, lin["params"].size)
+        path = str(tmp_path / f"linear{hidden_density}.ingp")
+        ctx.save_snapshot_file(path)
+        ctx.load_snapshot_file(path)
+        d = ctx.get_model()
+        assert (d.n_hidden_density, d.n_hidden_rgb, d.mlp_alignment, d.n_params) == (hidden_density, 0, 8, lin["params"].size)
+        assert np.array_equal(ctx.get_scene()["params"], lin["params"])
     ctx.close()
 
 

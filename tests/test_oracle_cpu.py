@@ -284,6 +284,47 @@ def test_network_against_numpy_float64(oracle, scene_mod, scene_unit):
     oracle.release(m)
 
 
+@pytest.mark.parametrize("hidden_density", [0, 1])
+def test_heads_without_a_hidden_layer_against_numpy(hidden_density, oracle, scene_mod):
+    """configs/nerf/linear.json / base_0layer.json: tcnn's CutlassMLP with n_hidden_layers 0 is one (padded output) x (input) matrix
+    (rgb: 8 x 32), output_activation None. Both accumulation modes against numpy, bit for bit."""
+    from conftest import _with_bitfield, pkg
+
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=9, log2_hashmap_size=12, cfg=scene_mod.linear_network_config(hidden_density)))
+    rng = np.random.default_rng(4)
+    pos = rng.uniform(0.1, 0.9, (512, 3)).astype(np.float32)
+    d = rng.normal(size=(512, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dir01 = ((d + 1) * 0.5).astype(np.float32)
+    p = sc["params"].view(np.float16).astype(np.float64)
+    nd, nr, _ = scene_mod.n_params(sc)
+    assert nr == 8 * 32
+    R = p[nd:nd + nr].reshape(8, 32)
+
+    def layer(x, W, relu, k_block):
+        acc = np.zeros((x.shape[0], W.shape[0]), np.float16)
+        for k0 in range(0, W.shape[1], k_block):  # k_block = the whole row: one exact sum, rounded to fp32 and then to fp16
+            acc = (acc.astype(np.float64) + x[:, k0:k0 + k_block] @ W[:, k0:k0 + k_block].T).astype(np.float32).astype(np.float16) if k_block == W.shape[1] else \
+                  (acc.astype(np.float64) + x[:, k0:k0 + k_block] @ W[:, k0:k0 + k_block].T).astype(np.float16)
+        a = acc.astype(np.float64)
+        return np.maximum(a, 0) if relu else a
+
+    for mode, kb in (("exact", None), ("fp16_k16", 16)):
+        sc["mlp_accumulate"] = mode
+        m = oracle.make_model(sc)
+        enc = oracle.grid_encode(m, pos).astype(np.float64)
+        sh = oracle.sh4(dir01).astype(np.float64)
+        if hidden_density == 0:
+            dens = layer(enc, p[:512].reshape(16, 32), False, kb or 32)
+        else:
+            dens = layer(layer(enc, p[:2048].reshape(64, 32), True, kb or 32), p[2048:3072].reshape(16, 64), False, kb or 64)
+        rgb = layer(np.concatenate([dens, sh], axis=1), R, False, kb or 32)
+        ref = np.concatenate([rgb[:, :3], dens[:, :1]], axis=1)
+        got = oracle.network(m, pos, dir01).astype(np.float64)
+        oracle.release(m)
+        assert np.array_equal(got, ref), (mode, np.abs(got - ref).max())
+
+
 def test_mlp_accumulation_modes_against_numpy(oracle, scene_mod, scene_unit):
     """The two modes that bracket / measure the reference's fp16-accumulating FullyFusedMLP (oracle.h, orc_nerf_model::mlp_accumulate):
     "fp16_k16" (the running sum rounded to fp16 after every 16-wide block of the inner dimension) against an independent numpy

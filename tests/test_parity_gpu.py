@@ -164,6 +164,78 @@ def test_rgb_heads_with_one_and_three_hidden_layers(n_hidden, gpu_ctx, oracle, n
         gpu_ctx.train(1, 1 << 14)
 
 
+@pytest.mark.parametrize("hidden_density", [0, 1])
+def test_heads_without_a_hidden_layer(hidden_density, gpu_ctx, oracle, native, scene_mod, tmp_path):
+    """configs/nerf/linear.json (both heads a single matrix) and base_0layer.json (the rgb head is; a CutlassMLP, so its output is
+    padded to 8 rows rather than 16): network outputs, the rendered image, the Normals gradient, the snapshot round trip."""
+    from conftest import _with_bitfield
+
+    cfg = scene_mod.linear_network_config(hidden_density)
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=51 + hidden_density, log2_hashmap_size=15, cfg=cfg))
+    assert scene_mod.n_params(sc)[:2] == ((512, 256) if hidden_density == 0 else (3072, 256))
+    gpu_ctx.set_model(sc)
+    d = gpu_ctx.get_model()
+    assert (d.n_hidden_density, d.n_hidden_rgb, d.mlp_alignment) == (hidden_density, 0, 8)
+    m = oracle.make_model(sc)
+    rng = np.random.default_rng(13)
+    pos = rng.uniform(0, 1, (4096 + 21, 3)).astype(np.float32)
+    dr = rng.normal(size=(pos.shape[0], 3)).astype(np.float32)
+    dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    dir01 = ((dr + 1) * 0.5).astype(np.float32)
+    got = gpu_ctx.network(pos, dir01).astype(np.float32)
+    ref = oracle.network(m, pos, dir01).astype(np.float32)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)
+    err = np.abs(got - ref)
+    # one or two dot products of 32 terms: the MFMA's fp32 sum against the oracle's exact one, a last-place flip at most
+    assert err.max() <= 3e-2 and (err <= ulp).mean() > 0.97 and (err == 0).mean() > 0.7
+    g = gpu_ctx.density_gradient(pos[:2048])
+    gr = oracle.density_gradient(m, pos[:2048])
+    scale = np.abs(gr).max()
+    assert np.abs(g - gr).max() <= 2e-3 * scale
+    oracle.release(m)
+    img, depth, st, refimg, db, ost = _render_both(gpu_ctx, oracle, native, scene_mod, sc, 160, 90, 70.0)
+    assert st["n_rays_hit"] > 1000 and abs(int(st["n_rays_hit"]) - int(ost["n_rays_hit"])) <= 3
+    assert_image_close(img, refimg, 50.0)
+    # ERenderMode::Normals through the linear density head (its input gradient is 128 W[0][:], unmasked)
+    m = oracle.make_model(sc)
+    cam, ocam = _cam_pair(native, oracle, scene_mod, 96, 54, az=70.0)
+    nimg = gpu_ctx.render(cam, native.make_opts(render_mode=native.RENDER_NORMALS))
+    nfb, _, _ = oracle.render_nerf(m, ocam, oracle.make_opts(render_mode=7))
+    nref = oracle.tonemap(oracle.accumulate(nfb.reshape(-1, 4), np.zeros((96 * 54, 4), np.float32), 0)).reshape(54, 96, 4)
+    oracle.release(m)
+    assert_image_close(nimg, nref, 38.0, tol=5e-2, frac=0.99, hard=1.01)
+    # density grid refresh through the linear density head (update_density_grid_nerf, src/testbed_nerf.cu:2772-2861)
+    if hidden_density == 0:
+        c = native.Context(0)  # (a context of its own: the refresh advances the context's grid rng)
+        try:
+            c.set_model(sc)
+            mc = sc["max_cascade"]
+            grid0 = c.density_grid(mc)
+            c.update_density_grid(0.95, 40000, 20000, 1)
+            gotg = c.density_grid(mc)
+        finally:
+            c.close()
+        m = oracle.make_model(sc)
+        refg, _ = oracle.update_density_grid(m, grid0, mc, oracle.grid_rng(), 0, 0.95, 40000, 20000)
+        oracle.release(m)
+        decayed = np.float32(0.95) * grid0
+        touched = refg != decayed
+        assert np.array_equal(gotg != decayed, touched) and touched.sum() > 20000
+        rel = np.abs(gotg[touched] - refg[touched]) / np.maximum(refg[touched], 1e-12)
+        assert np.median(rel) < 5e-3 and (rel < 0.1).mean() > 0.995
+    path = str(tmp_path / "linear.ingp")
+    gpu_ctx.save_snapshot_file(path)
+    gpu_ctx.load_snapshot_file(path)
+    d2 = gpu_ctx.get_model()
+    assert (d2.n_hidden_density, d2.n_hidden_rgb, d2.mlp_alignment, d2.n_params) == (hidden_density, 0, 8, d.n_params)
+    if hidden_density == 1:
+        assert np.array_equal(gpu_ctx.network(pos, dir01).astype(np.float32), got)
+    with pytest.raises(RuntimeError, match="irradiance probes are built for"):
+        gpu_ctx.compute_envmap(n_theta=8, n_phi=4)
+    with pytest.raises(RuntimeError, match="training is built for"):
+        gpu_ctx.train(1, 1 << 14)
+
+
 def test_grid_encode_ragged_sizes(gpu_ctx, oracle, scene_unit):
     gpu_ctx.set_model(scene_unit)
     m = oracle.make_model(scene_unit)
