@@ -1177,8 +1177,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	F.prof = nullptr;
 	memcpy(F.tune, ctx->tune, sizeof(F.tune));
 	if (getenv("NGP_PROFILE_SECTIONS")) { // diagnostic: per-section cycle sums of the fused kernel, printed by ngp_get_render_stats
-		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 512));
-		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 512, stream));
+		if (!ctx->d_prof) NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_prof, 1024));
+		NGP_HIP_CHECK(hipMemsetAsync(ctx->d_prof, 0, 1024, stream));
 		F.prof = ctx->d_prof;
 		F.prof_level = atoi(getenv("NGP_PROFILE_SECTIONS"));
 		if (const char* e = getenv("NGP_PROFILE_TRACE")) { // timelines of every stride-th working wave (tools/wave_trace.py)
@@ -1839,7 +1839,7 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 			NGP_HIP_CHECK(hipSetDevice(ctx->device));
 		}
 		if (ctx->d_prof && getenv("NGP_PROFILE_SECTIONS")) {
-			unsigned long long p[64];
+			unsigned long long p[128];
 			NGP_HIP_CHECK(hipMemcpy(p, ctx->d_prof, sizeof(p), hipMemcpyDeviceToHost));
 			{ // wave timeline on the 100 MHz chip clock: when the tile queue ran dry, when the last wave left
 				const double us = 0.01, t_first = (double)(~p[8]);
@@ -1851,6 +1851,9 @@ int ngp_get_render_stats(ngp_ctx* ctx, ngp_render_stats* out) {
 			double tot = (double)(p[0] + p[1] + p[2] + p[3]);
 			fprintf(stderr, "[ngp profile] refill %.1f%% march %.1f%% network %.1f%% composite %.1f%% | wave-iterations %llu passes %llu | cycles/iter %.0f cycles/pass(network) %.0f | skip rounds %llu lane-steps %llu (%.1f lanes/round) cycles/round %.0f\n",
 			        100.0 * p[0] / tot, 100.0 * p[1] / tot, 100.0 * p[2] / tot, 100.0 * p[3] / tot, p[4], p[5], tot / (double)p[4], (double)p[2] / (double)p[5], p[6], p[7], (double)p[7] / (double)p[6], (double)p[1] / (double)p[6]);
+			if (ctx->M.wide.width && p[5]) // the wide kernel's finer sections (wide_kernels.hip), cycles per network round of one workgroup
+				fprintf(stderr, "[ngp wide profile] per network round: hidden layers %.0f (-) %.0f output layers %.0f | march loop %.0f decision %.0f rows+prefetch %.0f encode %.0f composite %.0f | rounds %llu network rounds %llu\n",
+				        (double)p[64] / p[5], (double)p[65] / p[5], (double)p[71] / p[5], (double)p[66] / p[5], (double)p[67] / p[5], (double)p[68] / p[5], (double)p[69] / p[5], (double)p[70] / p[5], p[4], p[5]);
 		}
 	});
 }

@@ -45,7 +45,7 @@ struct WideShared {
 	uint16_t owner[ROWS];                  // the slot whose sample a row carries this round
 	uint32_t cnt[8];                       // per wave: waiting / new samples (the round's selection)
 	uint32_t coarse16[NERF_CASCADES * 16]; // per cascade: which 16^3-cell blocks of the occupancy grid hold anything (ModelParams::coarse, tail)
-	unsigned long long prof[8];            // diagnostic (NGP_PROFILE_SECTIONS=1): the workgroup's section sums, kept here rather than in registers
+	unsigned long long prof[16];           // diagnostic (NGP_PROFILE_SECTIONS=1): the workgroup's section sums, kept here rather than in registers
 };
 // the 16 bytes behind a row's 256 activations: before the network the sample's position (x, y, z, 1; w = 0: the row is empty), after
 // it the sample's rgb outputs
@@ -83,8 +83,7 @@ NGP_DEV floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_
 // pieces (fma: the products are exact), then the odd Taylor polynomial of degree 11 on [-pi/2, pi/2]. Absolute error < 2e-7 (measured
 // 1.7e-7 over 6.4e6 arguments), i.e. the fp16 rounding of the feature differs from the exactly rounded one in < 1e-4 of the cases;
 // 17 instructions where libm's general sinf takes ~55. Arguments beyond 2^20 go to sinf.
-NGP_DEV float encoder_sin(float t) {
-	if (!(__builtin_fabsf(t) < 1048576.0f)) return sinf(t);
+NGP_DEV float encoder_sin_reduced(float t) { // |t| < 2^20
 	const float k = __builtin_rintf(t * 0.318309886183790672f);
 	float r = __builtin_fmaf(-k, 3.14159274101257324f, t);
 	r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);
@@ -99,23 +98,42 @@ NGP_DEV float encoder_sin(float t) {
 	const uint32_t flip = (uint32_t)(int)k << 31; // sin(r + k pi) = (-1)^k sin(r)
 	return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) ^ flip);
 }
+NGP_DEV float encoder_sin(float t) {
+	if (!(__builtin_fabsf(t) < 1048576.0f)) return sinf(t);
+	return encoder_sin_reduced(t);
+}
 
 // tcnn FrequencyEncoding (encodings/frequency.h): feature j of input x is
 //   sin(fma(scalbn(x[j / (2 F)], (j / 2) % F), pi, (j % 2) pi / 2))
 // rounded to fp16; inputs beyond 3 * 2 F up to `padded` are ones. This call writes the features of frequencies [f_begin, f_end) of
 // the three inputs (4-byte aligned pairs); with `tail` also the ones up to `padded` and zeros from there to k_end (the MFMA K the row
 // is read in: the weights' columns there are zeros, which does not make 0 x stale-NaN a zero; 16-byte aligned).
+// The usual case -- up to 16 frequencies of inputs around the unit cube: every argument stays below 2^20 -- runs without the per-sine
+// range check, frequency by frequency with the six sines of a frequency (three inputs, sine and cosine) as independent chains.
 NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y, float z, half_t* out, uint32_t f_begin, uint32_t f_end, bool tail, uint32_t k_end = 0) {
 	const float PI = 3.14159265358979323846f;
 	const float in[3] = {x, y, z};
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
+	if (n_freq <= 16u && __builtin_fabsf(x) <= 8.0f && __builtin_fabsf(y) <= 8.0f && __builtin_fabsf(z) <= 8.0f) { // |2^15 * 8 * pi| < 2^20
 		for (uint32_t f = f_begin; f < f_end; ++f) {
-			const float v = __builtin_ldexpf(in[d], (int)f);
-			half2_t sc;
-			sc[0] = (half_t)encoder_sin(__builtin_fmaf(v, PI, 0.0f));
-			sc[1] = (half_t)encoder_sin(__builtin_fmaf(v, PI, PI / 2.0f));
-			*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const float v = __builtin_ldexpf(in[d], (int)f);
+				half2_t sc;
+				sc[0] = (half_t)encoder_sin_reduced(__builtin_fmaf(v, PI, 0.0f));
+				sc[1] = (half_t)encoder_sin_reduced(__builtin_fmaf(v, PI, PI / 2.0f));
+				*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			for (uint32_t f = f_begin; f < f_end; ++f) {
+				const float v = __builtin_ldexpf(in[d], (int)f);
+				half2_t sc;
+				sc[0] = (half_t)encoder_sin(__builtin_fmaf(v, PI, 0.0f));
+				sc[1] = (half_t)encoder_sin(__builtin_fmaf(v, PI, PI / 2.0f));
+				*(half2_t*)(out + (uint32_t)d * 2u * n_freq + 2u * f) = sc;
+			}
 		}
 	}
 	if (tail) {
@@ -250,8 +268,10 @@ NGP_DEV OutTiles wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const ui
 #else
 // One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)); ring stages 0..2 hold (or await) K-blocks 0..2.
 template <int MT, int NKB>
-NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
+NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next, unsigned long long* pr = nullptr) {
 	const int n = lane & 31, h = lane >> 5;
+	unsigned long long ts0 = 0;
+	if (pr) ts0 = stamp();
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	floatx16 acc[MT][4];
 	const half_t* col = X + n * XS + 8 * h;
@@ -269,50 +289,49 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __
 			for (int t = 0; t < 4; ++t) b[(kb + 1) & 1][t] = *(const half8*)(col + 32 * t * XS + 16 * (kb + 1));
 		}
 		__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use, one block late)
+		// The last block's operands are in registers: every wave is done reading the layer's input once it gets here, so the barrier that
+		// guards the in-place write sits in front of the last 4 MT MFMAs instead of behind the packing -- the tiles are then packed and
+		// written one by one as their accumulators complete, under the MFMAs of the tiles behind them.
+		if (kb == NKB - 1) lds_barrier();
 #pragma unroll
 		for (int t = 0; t < 4; ++t)
 #pragma unroll
 			for (int m = 0; m < MT; ++m) acc[m][t] = mfma32(as_half8(ar[kb % RING][m]), b[kb & 1][t], kb == 0 ? zero : acc[m][t]);
-		__builtin_amdgcn_sched_barrier(0);
+		if (kb < NKB - 1) __builtin_amdgcn_sched_barrier(0);
 	}
 	ring_preload<MT>(ar, next);
-	uint2 packed[MT][4][4];
-#pragma unroll
-	for (int m = 0; m < MT; ++m)
-#pragma unroll
-		for (int t = 0; t < 4; ++t)
-#pragma unroll
-			for (int q = 0; q < 4; ++q) packed[m][t][q] = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
-	lds_barrier(); // every wave has read the layer's input
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
 		half_t* row = X + (32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
 #pragma unroll
 		for (int m = 0; m < MT; ++m)
 #pragma unroll
-			for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = packed[m][t][q];
+			for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
 	}
 	lds_barrier();
+	if (pr) pr[8] += stamp() - ts0; // (K loop and epilogue together: a stamp between them would keep the packing out of the last MFMAs' shadow)
 }
 
-// An output layer (at most 32 neurons, no activation): wave w computes its own sample tile w; fragments in ar[.][0]
+// An output layer (at most 32 neurons, no activation): wave w computes its own sample tile w; fragments in ar[.][0].
+// One MFMA per K block: a ring that runs AHEAD blocks ahead would be 64 MFMA cycles ahead of an L2 round trip, i.e. every block would wait
+// for one (measured: the two output layers cost 10 k cycles of a 96 k round). The accumulator tiles are free here, so ALL of the layer's
+// fragments and operands are requested at once: one round trip for the layer.
 template <int MT, int NKB>
 NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next) {
 	const int n = lane & 31, h = lane >> 5;
 	const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	floatx16 acc = zero;
 	const half_t* col = X + (32 * wave + n) * XS + 8 * h;
-	half8 b[2];
-	b[0] = *(const half8*)col;
+	u32x4 a[NKB];
+	half8 b[NKB];
 #pragma unroll
-	for (int kb = 0; kb < NKB; ++kb) {
-		if (kb + AHEAD < NKB) ar[(kb + AHEAD) % RING][0] = *(const u32x4*)(wf + (size_t)(kb + AHEAD) * 64);
-		if (kb + 1 < NKB) b[(kb + 1) & 1] = *(const half8*)(col + 16 * (kb + 1));
-		__builtin_amdgcn_sched_barrier(0);
-		acc = mfma32(as_half8(ar[kb % RING][0]), b[kb & 1], acc);
-		__builtin_amdgcn_sched_barrier(0);
-	}
-	ring_preload<MT>(ar, next);
+	for (int kb = 0; kb < NKB; ++kb) a[kb] = kb < AHEAD ? ar[kb][0] : *(const u32x4*)(wf + (size_t)kb * 64);
+#pragma unroll
+	for (int kb = 0; kb < NKB; ++kb) b[kb] = *(const half8*)(col + 16 * kb);
+	ring_preload<MT>(ar, next); // (the ring's stages have been copied out: the next layer's first blocks travel behind this layer's)
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int kb = 0; kb < NKB; ++kb) acc = mfma32(as_half8(a[kb]), b[kb], acc);
 	return acc;
 }
 
@@ -347,7 +366,7 @@ NGP_DEV void wide_network_prefetch(const WideModel& W, u32x4 (&ar)[RING][MT], in
 // encoding, both visible (the caller has passed a barrier), and the first layer's fragments have been requested
 // (wide_network_prefetch); on exit the thread that owns row `my_row` (-1: none) has its outputs and X may be overwritten.
 template <int MT>
-NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[RING][MT], int my_row) {
+NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (&ar)[RING][MT], int my_row, unsigned long long* pr = nullptr) {
 	const int wave = tid >> 6, lane = tid & 63;
 	const int n = lane & 31, h = lane >> 5;
 	(void)n; (void)h;
@@ -359,14 +378,22 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 		const bool density_out = l == W.n_hidden_density, rgb_out = l + 1u == n_layers;
 		const LayerFrags cur = layer_frags<MT>(W, l, wave, lane), next = layer_frags<MT>(W, l + 1u, wave, lane);
 		if (!density_out && !rgb_out) {
+#if WIDE_MFMA16
 			if (cur.nkb == K256) wide_hidden_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next);
 			else wide_hidden_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
+#else
+			if (cur.nkb == K256) wide_hidden_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next, pr);
+			else wide_hidden_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next, pr);
+#endif
 			continue;
 		}
 #if WIDE_MFMA16
 		const OutTiles acc = cur.nkb == K256 ? wide_out_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
 #else
+		unsigned long long ts0 = 0;
+		if (pr) ts0 = stamp();
 		const floatx16 acc = cur.nkb == K256 ? wide_out_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
+		if (pr) { asm volatile("" :: "v"(acc[0])); pr[15] += stamp() - ts0; }
 #endif
 		if (density_out) {
 			// the 16 density outputs become columns 0..15 of the rgb network's input (rows of this wave's own tile: no other wave reads them now)
@@ -469,7 +496,14 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 	// diagnostic (NGP_PROFILE_SECTIONS=1: FrameParams::prof): cycle sums per section, taken by one lane per workgroup
 	const bool prof = F.prof != nullptr && tid == 0;
 	unsigned long long t0 = 0;
-	if (tid < 8) S.prof[tid] = 0ull;
+	if (tid < 16) S.prof[tid] = 0ull;
+	__syncthreads();
+	unsigned long long t2 = 0;
+	auto lap2 = [&](int k) { // finer: [10] march loop, [11] decision, [12] rows + prefetch, [13] encode, [14] composite; [8] K loops, [9] epilogues (wide_hidden_layer)
+		const unsigned long long t1 = stamp();
+		S.prof[k] += t1 - t2;
+		t2 = t1;
+	};
 	auto lap = [&](int section) { // [0] refill, [1] march + decision, [2] network, [3] encode + composite
 		const unsigned long long t1 = stamp();
 		S.prof[section] += t1 - t0;
@@ -558,7 +592,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 
-		if (prof) lap(0);
+		if (prof) { lap(0); t2 = t0; }
 		// ---- K4 / K2: if_unoccupied_advance_to_next_occupied_voxel (nerf_device.cuh:461-494): every marching slot walks to its next
 		// sample (or out of the box), at most 64 voxels per round so that one long empty stretch does not hold up the workgroup
 		bool newly_counted = false;
@@ -614,6 +648,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 		n_alive_init += (uint32_t)__popcll(__ballot(newly_counted));
+		if (prof) lap2(10);
 
 		// ---- workgroup decision: run the network once (nearly) a round's worth of samples waits or nothing else can add to them
 		const int wave_id = tid >> 6;
@@ -632,7 +667,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			new_total += nc;
 		}
 		const int n_ready = (int)(held_total + new_total);
-		if (prof) lap(1);
+		if (prof) { lap(1); lap2(11); }
 		if (n_ready == 0) {
 			if (n_progress == 0) break;
 			__syncthreads(); // (S.cnt is rewritten next round)
@@ -662,11 +697,13 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		u32x4 ar[RING][MT];
 		wide_network_prefetch<MT>(W, ar, tid); // the first layer's weights travel while the sines are computed
 		lds_barrier();
+		if (prof) lap2(12);
 		encode_positions(W, S, tid);
 		lds_barrier();
+		if (prof) lap2(13);
 		if (prof) { lap(3); S.prof[5] += 1ull; S.prof[7] += (unsigned long long)(n_ready < ROWS ? n_ready : ROWS); }
-		const WideOut o = wide_network<MT>(W, S, tid, ar, my_row);
-		if (prof) lap(2);
+		const WideOut o = wide_network<MT>(W, S, tid, ar, my_row, prof ? S.prof : nullptr);
+		if (prof) { lap(2); t2 = t0; }
 
 		// ---- K6: composite_kernel_nerf (:569-726)
 		if (run) {
@@ -705,7 +742,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			}
 		}
 		n_samples += (uint32_t)__popcll(__ballot(run));
-		if (prof) lap(3);
+		if (prof) { lap(3); lap2(14); }
 	}
 	if (prof) { // [refill, march + decision, network, encode + composite] cycles, rounds, network rounds (twice: the host divides by both), samples
 		for (int k = 0; k < 4; ++k) atomicAdd(&F.prof[k], S.prof[k]);
@@ -713,6 +750,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		atomicAdd(&F.prof[5], S.prof[5]);
 		atomicAdd(&F.prof[6], S.prof[5]);
 		atomicAdd(&F.prof[7], S.prof[7]);
+		for (int k = 8; k < 16; ++k) atomicAdd(&F.prof[56 + k], S.prof[k]); // [64..71]
 	}
 	finish_launch(F, lane, n_alive_init, n_hit, n_samples);
 }
