@@ -212,25 +212,21 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __
 				b[(q + 1) & 1][1] = *(const half8*)(col + 16 * (2 * nq + 1) * XS + 32 * nkb);
 			}
 			__builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads next to their use)
+			const bool last = kb == NKB - 1 && q == 3;
+			if (last) lds_barrier(); // every wave has read the layer's input: the in-place writes may start under the last MFMAs (see the 32x32x16 form)
 #pragma unroll
 			for (int t = 0; t < 2; ++t)
 #pragma unroll
 				for (int m = 0; m < MT; ++m) acc[m][2 * q + t] = mfma16w(as_half8(ar[kb % RING][m]), b[q & 1][t], kb == 0 ? zero : acc[m][2 * q + t]);
-			__builtin_amdgcn_sched_barrier(0);
+			if (!last) __builtin_amdgcn_sched_barrier(0);
 		}
 	}
 	ring_preload<MT>(ar, next);
-	uint2 packed[MT][8];
-#pragma unroll
-	for (int m = 0; m < MT; ++m)
-#pragma unroll
-		for (int t = 0; t < 8; ++t) packed[m][t] = pack4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3], true);
-	lds_barrier(); // every wave has read the layer's input
 #pragma unroll
 	for (int t = 0; t < 8; ++t) {
 		half_t* row = X + (16 * t + c) * XS + 16 * (wave * MT) + 4 * h;
 #pragma unroll
-		for (int m = 0; m < MT; ++m) *(uint2*)(row + 16 * m) = packed[m][t];
+		for (int m = 0; m < MT; ++m) *(uint2*)(row + 16 * m) = pack4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3], true);
 	}
 	lds_barrier();
 }
