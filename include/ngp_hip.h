@@ -84,8 +84,9 @@ typedef struct ngp_model_desc {
 	/* The second architecture the renderer implements: configs/nerf/frequency.json, the original NeRF's network (tcnn Frequency
 	 * encodings, CutlassMLPs 128 or 256 wide with any number of hidden layers). All zero = the grid architecture above.
 	 *   pos_encoding  0: the grid encoding described by the fields above; 1: Frequency with pos_n_frequencies (the grid fields are
-	 *                 ignored, params_fp16 holds the two MLPs only)
-	 *   dir_encoding  0: SphericalHarmonics degree 4; 1: Frequency with dir_n_frequencies
+	 *                 ignored, params_fp16 holds the two MLPs only); 2: Identity (configs/nerf/none.json: the position itself, padded
+	 *                 with ones to mlp_alignment)
+	 *   dir_encoding  0: SphericalHarmonics degree 4; 1: Frequency with dir_n_frequencies; 2: Identity (with pos_encoding 1 or 2)
 	 *   mlp_alignment 16: FullyFusedMLP, 8: CutlassMLP (0 = 16) -- what encodings, the rgb network's input and its output are padded
 	 *                 to (nerf_network.h:81-100). For the grid architecture it is the RGB network's alignment (:83): 8 makes the rgb
 	 *                 output layer 8 rows (linear.json, base_0layer.json)

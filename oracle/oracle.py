@@ -191,8 +191,11 @@ class Oracle:
         """scene: dict produced by the package's synthetic/snapshot loaders (plain numpy + scalars)."""
         m = NerfModel()
         enc = scene["encoding"]
-        if enc.get("otype", "HashGrid") == "Frequency":  # configs/nerf/frequency.json: no grid at all
-            m.pos_encoding, m.pos_n_frequencies = 1, enc["n_frequencies"]
+        if enc.get("otype", "HashGrid") in ("Frequency", "Identity"):  # configs/nerf/frequency.json, none.json: no grid at all
+            if enc["otype"] == "Identity":
+                m.pos_encoding = 2
+            else:
+                m.pos_encoding, m.pos_n_frequencies = 1, enc["n_frequencies"]
             m.n_levels = m.n_features_per_level = m.log2_hashmap_size = m.base_resolution = 0
             m.per_level_scale = 1.0
         else:
@@ -204,6 +207,8 @@ class Oracle:
         de = scene.get("dir_encoding", {})
         if de.get("otype") == "Frequency":
             m.dir_encoding, m.dir_n_frequencies = 1, de["n_frequencies"]
+        elif de.get("otype") == "Identity":
+            m.dir_encoding = 2
         # the rgb network's alignment (nerf_network.h:83): the rgb input and output are padded to it; Frequency encodings pad the
         # position encoding to the density network's, and both networks are CutlassMLPs there
         m.mlp_alignment = 8 if scene["rgb_network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16

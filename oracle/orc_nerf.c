@@ -183,8 +183,8 @@ static uint64_t mlp_n_params(uint32_t in, uint32_t width, uint32_t n_hidden, uin
 static uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 static void network_shapes(const orc_nerf_model* m, uint32_t* enc_dims, uint32_t* dir_dims, uint32_t* rgb_in, uint32_t* rgb_out) {
 	const uint32_t al = m->mlp_alignment ? m->mlp_alignment : 16u;
-	*enc_dims = m->pos_encoding == 1 ? align_up(3u * 2u * m->pos_n_frequencies, al) : m->n_levels * m->n_features_per_level;
-	*dir_dims = m->dir_encoding == 1 ? align_up(3u * 2u * m->dir_n_frequencies, al) : 16u;
+	*enc_dims = m->pos_encoding == 1 ? align_up(3u * 2u * m->pos_n_frequencies, al) : m->pos_encoding == 2 ? align_up(3u, al) : m->n_levels * m->n_features_per_level;
+	*dir_dims = m->dir_encoding == 1 ? align_up(3u * 2u * m->dir_n_frequencies, al) : m->dir_encoding == 2 ? align_up(3u, al) : 16u;
 	*rgb_in = align_up(m->density_out_dims + *dir_dims, al);
 	*rgb_out = align_up(3u, al);
 }
@@ -195,7 +195,7 @@ uint64_t orc_n_params(const orc_nerf_model* m) {
 	uint32_t enc, dir, rgb_in, rgb_out;
 	network_shapes(m, &enc, &dir, &rgb_in, &rgb_out);
 	uint64_t ng = 0;
-	if (m->pos_encoding != 1) {
+	if (m->pos_encoding == 0) {
 		if (orc_grid_layout(m, offsets, res, scales)) return 0;
 		ng = (uint64_t)offsets[m->n_levels] * m->n_features_per_level;
 	}
@@ -209,11 +209,11 @@ int orc_nerf_prepare(orc_nerf_model* m) {
 	if (m->n_neurons > 256) return -4;
 	prepared_t* p = (prepared_t*)calloc(1, sizeof(prepared_t));
 	if (!p) return -1;
-	if (m->pos_encoding != 1 && orc_grid_layout(m, p->offsets, p->resolutions, p->scales)) { free(p); return -1; }
+	if (m->pos_encoding == 0 && orc_grid_layout(m, p->offsets, p->resolutions, p->scales)) { free(p); return -1; }
 	network_shapes(m, &p->enc_dims, &p->dir_dims, &p->rgb_in, &p->rgb_out);
 	p->n_density_w = mlp_n_params(p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims);
 	p->n_rgb_w = mlp_n_params(p->rgb_in, m->n_neurons, m->n_hidden_rgb, p->rgb_out);
-	uint64_t need = p->n_density_w + p->n_rgb_w + (m->pos_encoding == 1 ? 0 : (uint64_t)p->offsets[m->n_levels] * m->n_features_per_level);
+	uint64_t need = p->n_density_w + p->n_rgb_w + (m->pos_encoding != 0 ? 0 : (uint64_t)p->offsets[m->n_levels] * m->n_features_per_level);
 	if (m->n_params != need) { free(p); return -3; }
 	p->density_w = (float*)malloc(sizeof(float) * p->n_density_w);
 	p->rgb_w = (float*)malloc(sizeof(float) * p->n_rgb_w);
@@ -426,6 +426,11 @@ static void mlp_forward(uint32_t mode, const float* w, uint32_t n_in, uint32_t w
  * + (j % 2) * pi / 2), cast to half; padded outputs are 1 (tcnn pads encodings with ones). The argument is one fma (what nvcc makes
  * of the expression); the sine is libm's -- tcnn calls the hardware approximation __sinf, whose error at these arguments (up to
  * 2^15 pi) is not specified closely enough to restate: PARITY UNPINNED like the rest of tcnn's arithmetic. */
+/* tcnn IdentityEncoding (encodings/identity.h; configs/nerf/none.json): out[j] = in[j] * scale + offset (1 and 0: the defaults) cast to half,
+ * padded outputs are 1. PARITY UNPINNED like the rest of tcnn's arithmetic. */
+static void identity_encode_one(uint32_t n_dims, uint32_t padded, const float* x, uint16_t* out) {
+	for (uint32_t j = 0; j < padded; ++j) out[j] = orc_float_to_half(j < n_dims ? x[j] * 1.0f + 0.0f : 1.0f);
+}
 static void frequency_encode_one(uint32_t n_dims, uint32_t n_freq, uint32_t padded, const float* x, uint16_t* out) {
 	const float PI = 3.14159265358979323846f;
 	const uint32_t n = n_dims * 2u * n_freq;
@@ -451,6 +456,8 @@ static void nerf_network_one_ideal(const orc_nerf_model* m, const prepared_t* p,
 		const uint32_t nf = m->pos_n_frequencies, n = 3u * 2u * nf;
 		for (uint32_t j = 0; j < n; ++j) enc[j] = sin(ldexp((double)pos01[j / (nf * 2u)], (int)((j / 2u) % nf)) * PI + (double)(j % 2u) * (PI / 2.0));
 		for (uint32_t j = n; j < p->enc_dims; ++j) enc[j] = 1.0;
+	} else if (m->pos_encoding == 2) {
+		for (uint32_t j = 0; j < p->enc_dims; ++j) enc[j] = j < 3u ? (double)pos01[j] : 1.0;
 	} else {
 		const uint32_t F = m->n_features_per_level;
 		for (uint32_t l = 0; l < m->n_levels; ++l) {
@@ -485,6 +492,8 @@ static void nerf_network_one_ideal(const orc_nerf_model* m, const prepared_t* p,
 		const uint32_t nf = m->dir_n_frequencies, n = 3u * 2u * nf;
 		for (uint32_t j = 0; j < n; ++j) dir[j] = sin(ldexp((double)dir01[j / (nf * 2u)], (int)((j / 2u) % nf)) * PI + (double)(j % 2u) * (PI / 2.0));
 		for (uint32_t j = n; j < p->dir_dims; ++j) dir[j] = 1.0;
+	} else if (m->dir_encoding == 2) {
+		for (uint32_t j = 0; j < p->dir_dims; ++j) dir[j] = j < 3u ? (double)dir01[j] : 1.0;
 	} else {
 		const double x = (double)dir01[0] * 2.0 - 1.0, y = (double)dir01[1] * 2.0 - 1.0, z = (double)dir01[2] * 2.0 - 1.0;
 		const double xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
@@ -525,6 +534,7 @@ static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const
 	uint16_t enc_h[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
 	float enc[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
 	if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h);
+	else if (m->pos_encoding == 2) identity_encode_one(3, p->enc_dims, pos01, enc_h);
 	else grid_encode_one(m, p, pos01, enc_h);
 	for (uint32_t i = 0; i < p->enc_dims; ++i) enc[i] = orc_half_to_float(enc_h[i]);
 	float rgb_in[128];
@@ -532,6 +542,7 @@ static void nerf_network_one(const orc_nerf_model* m, const prepared_t* p, const
 	mlp_forward(m->mlp_accumulate, p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, rgb_in, dens_h);
 	uint16_t dir_h[64];
 	if (m->dir_encoding == 1) frequency_encode_one(3, m->dir_n_frequencies, p->dir_dims, dir01, dir_h);
+	else if (m->dir_encoding == 2) identity_encode_one(3, p->dir_dims, dir01, dir_h);
 	else sh4_one(dir01, dir_h);
 	for (uint32_t i = 0; i < p->dir_dims; ++i) rgb_in[m->density_out_dims + i] = orc_half_to_float(dir_h[i]);
 	for (uint32_t i = m->density_out_dims + p->dir_dims; i < p->rgb_in; ++i) rgb_in[i] = 1.0f; /* alignment padding of the rgb network's input */
@@ -1338,7 +1349,8 @@ static void grid_samples_splat(const orc_nerf_model* m, const prepared_t* p, uin
 		uint16_t enc_h[ORC_MAX_LEVELS * 8];
 		float enc[ORC_MAX_LEVELS * 8], dens_f[64];
 		uint16_t dens_h[32];
-		if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h); /* any NerfNetwork: NerfNetwork::density, nerf_network.h */
+		if (m->pos_encoding == 2) identity_encode_one(3, p->enc_dims, pos01, enc_h);
+		else if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, pos01, enc_h); /* any NerfNetwork: NerfNetwork::density, nerf_network.h */
 		else grid_encode_one(m, p, pos01, enc_h);
 		for (uint32_t k = 0; k < p->enc_dims; ++k) enc[k] = orc_half_to_float(enc_h[k]);
 		mlp_forward(m->mlp_accumulate == ORC_MLP_ACC_FP16_K16 ? ORC_MLP_ACC_FP16_K16 : ORC_MLP_ACC_EXACT, p->density_w, p->enc_dims, m->n_neurons, m->n_hidden_density, m->density_out_dims, enc, dens_f, dens_h);

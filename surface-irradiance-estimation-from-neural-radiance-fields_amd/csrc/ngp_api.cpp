@@ -295,8 +295,8 @@ WideShapes wide_shapes(const ngp_model_desc& d) {
 	WideShapes w{};
 	w.alignment = d.mlp_alignment ? d.mlp_alignment : 16u;
 	auto up = [&](uint32_t v) { return (v + w.alignment - 1) / w.alignment * w.alignment; };
-	w.enc_dims = up(6u * d.pos_n_frequencies);
-	w.dir_dims = d.dir_encoding == 1 ? up(6u * d.dir_n_frequencies) : 16u;
+	w.enc_dims = d.pos_encoding == 2 ? up(3u) : up(6u * d.pos_n_frequencies);
+	w.dir_dims = d.dir_encoding == 1 ? up(6u * d.dir_n_frequencies) : d.dir_encoding == 2 ? up(3u) : 16u;
 	w.rgb_in = up(d.density_out_dims + w.dir_dims);
 	w.rgb_out = up(3u);
 	return w;
@@ -326,12 +326,12 @@ void free_model(ngp_ctx* ctx) {
 }
 
 void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
-	const bool wide = d.pos_encoding == 1;
-	if (d.pos_encoding > 1 || d.dir_encoding > 1 || (d.mlp_alignment != 0 && d.mlp_alignment != 8 && d.mlp_alignment != 16)) throw std::runtime_error("invalid model descriptor (encoding kinds / mlp_alignment)");
-	if (!wide && d.dir_encoding != 0) throw std::runtime_error("unsupported network architecture: a Frequency direction encoding is implemented together with a Frequency position encoding (configs/nerf/frequency.json)");
+	const bool wide = d.pos_encoding >= 1; // Frequency (1) or Identity (2) position encoding: no grid, the wide-MLP kernels
+	if (d.pos_encoding > 2 || d.dir_encoding > 2 || (d.mlp_alignment != 0 && d.mlp_alignment != 8 && d.mlp_alignment != 16)) throw std::runtime_error("invalid model descriptor (encoding kinds / mlp_alignment)");
+	if (!wide && d.dir_encoding != 0) throw std::runtime_error("unsupported network architecture: a Frequency / Identity direction encoding is implemented together with a Frequency / Identity position encoding (configs/nerf/frequency.json, none.json)");
 	if (wide) {
 		if ((d.n_neurons != 128 && d.n_neurons != 256) || d.n_hidden_density < 1 || d.n_hidden_rgb < 1 || d.n_hidden_density + d.n_hidden_rgb + 2 > (uint32_t)WIDE_MAX_LAYERS ||
-		    d.density_out_dims != 16 || d.pos_n_frequencies < 1 || d.pos_n_frequencies > 40 || (d.dir_encoding == 1 && (d.dir_n_frequencies < 1 || d.dir_n_frequencies > 4))) {
+		    d.density_out_dims != 16 || (d.pos_encoding == 1 && (d.pos_n_frequencies < 1 || d.pos_n_frequencies > 40)) || (d.dir_encoding == 1 && (d.dir_n_frequencies < 1 || d.dir_n_frequencies > 4))) {
 			throw std::runtime_error("unsupported network architecture: with a Frequency position encoding (configs/nerf/frequency.json) the HIP path implements MLPs of 128 or 256 "
 			                         "neurons with 1 or more hidden layers, a 16-wide density output, up to 40 position and 4 direction frequencies");
 		}
@@ -389,8 +389,10 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		std::vector<uint16_t> frags;
 		WideModel& WM = M.wide;
 		WM.width = d.n_neurons;
-		WM.pos_freqs = d.pos_n_frequencies;
+		WM.pos_freqs = d.pos_encoding == 1 ? d.pos_n_frequencies : 0u;
 		WM.dir_freqs = d.dir_encoding == 1 ? d.dir_n_frequencies : 0u;
+		WM.pos_identity = d.pos_encoding == 2 ? 1u : 0u;
+		WM.dir_identity = d.dir_encoding == 2 ? 1u : 0u;
 		WM.enc_dims = ws.enc_dims;
 		WM.dir_dims = ws.dir_dims;
 		WM.rgb_in = ws.rgb_in;
@@ -686,8 +688,11 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 	} else if (otype == "frequency") { // configs/nerf/frequency.json
 		d.pos_encoding = 1;
 		d.pos_n_frequencies = (uint32_t)enc.value("n_frequencies", 12.0);
+	} else if (otype == "identity") { // configs/nerf/none.json: the position itself (tcnn Identity: in * scale + offset, padded with ones)
+		if (enc.value("scale", 1.0) != 1.0 || enc.value("offset", 0.0) != 0.0) throw std::runtime_error("unsupported Identity encoding (scale 1, offset 0 are implemented)");
+		d.pos_encoding = 2;
 	} else if (otype != "hashgrid") {
-		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid, DenseGrid and Frequency are implemented)");
+		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid, DenseGrid, Frequency and Identity are implemented)");
 	}
 	d.n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2.0);
 	d.n_levels = enc.contains("n_features") && enc.at("n_features").num() > 0 ? (uint32_t)enc.at("n_features").num() / d.n_features_per_level
@@ -703,7 +708,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 	d.aabb_scale = (uint32_t)ds.aabb_scale;
 
 	d.per_level_scale = (float)enc.value("per_level_scale", 0.0);
-	if (d.pos_encoding == 1) {
+	if (d.pos_encoding >= 1) {
 		d.n_levels = d.n_features_per_level = d.log2_hashmap_size = d.base_resolution = 0;
 		d.per_level_scale = 0.0f;
 	} else if (!(d.per_level_scale > 0.0f) && d.n_levels > 1) {
@@ -723,7 +728,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 			for (auto& ch : t) ch = (char)tolower(ch);
 			return t == "cutlassmlp";
 		};
-		if (is_cutlass(net) != is_cutlass(rgb) && d.pos_encoding == 1) throw std::runtime_error("unsupported network otype: density and rgb networks of different kinds");
+		if (is_cutlass(net) != is_cutlass(rgb) && d.pos_encoding >= 1) throw std::runtime_error("unsupported network otype: density and rgb networks of different kinds");
 		d.mlp_alignment = is_cutlass(rgb) ? 8u : 16u; // grid models (base_0layer.json mixes the kinds): the rgb network's, nerf_network.h:83
 	}
 	{ // what the kernels hard-wire beyond the shapes: ReLU hidden layers without an output activation, and a direction encoding of
@@ -737,9 +742,10 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		if (root.contains("dir_encoding")) {
 			const mj::Value& de = root.at("dir_encoding");
 			auto is_sh4 = [&](const mj::Value& e) { return lower(e.value("otype", "")) == "sphericalharmonics" && (int)e.value("degree", 4.0) == 4; };
-			auto is_freq = [&](const mj::Value& e) { return d.pos_encoding == 1 && lower(e.value("otype", "")) == "frequency"; };
+			auto is_freq = [&](const mj::Value& e) { return d.pos_encoding >= 1 && lower(e.value("otype", "")) == "frequency"; };
+			auto is_ident = [&](const mj::Value& e) { return d.pos_encoding >= 1 && lower(e.value("otype", "")) == "identity" && e.value("scale", 1.0) == 1.0 && e.value("offset", 0.0) == 0.0; };
 			const mj::Value* first = &de;
-			bool ok = is_sh4(de) || is_freq(de);
+			bool ok = is_sh4(de) || is_freq(de) || is_ident(de);
 			if (!ok && lower(de.value("otype", "")) == "composite" && de.contains("nested") && de.at("nested").is_array() && de.at("nested").size() >= 1) {
 				const mj::Value& nested = de.at("nested");
 				first = &nested.at(0);
@@ -750,6 +756,8 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 			if (is_freq(*first)) {
 				d.dir_encoding = 1;
 				d.dir_n_frequencies = (uint32_t)first->value("n_frequencies", 12.0);
+			} else if (first == &de && is_ident(de)) {
+				d.dir_encoding = 2;
 			}
 		}
 	}
@@ -1469,10 +1477,10 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 		ngp::refresh_density_grid_host(ctx);
 		const ngp_model_desc& d = ctx->desc;
 		mj::Value root = ctx->config.is_object() ? ctx->config : mj::Value::make_object();
-		if (!root.contains("encoding") && d.pos_encoding == 1) { // configs/nerf/frequency.json
+		if (!root.contains("encoding") && d.pos_encoding >= 1) { // configs/nerf/frequency.json, none.json
 			mj::Value e = mj::Value::make_object();
-			e["otype"] = mj::Value::make_string("Frequency");
-			e["n_frequencies"] = mj::Value::make_uint(d.pos_n_frequencies);
+			e["otype"] = mj::Value::make_string(d.pos_encoding == 2 ? "Identity" : "Frequency");
+			if (d.pos_encoding == 1) e["n_frequencies"] = mj::Value::make_uint(d.pos_n_frequencies);
 			root["encoding"] = e;
 			auto mlp = [&](uint32_t hidden) {
 				mj::Value n = mj::Value::make_object();
@@ -1489,6 +1497,8 @@ int ngp_save_snapshot_file(ngp_ctx* ctx, const char* path, int compress) {
 			if (d.dir_encoding == 1) {
 				de["otype"] = mj::Value::make_string("Frequency");
 				de["n_frequencies"] = mj::Value::make_uint(d.dir_n_frequencies);
+			} else if (d.dir_encoding == 2) {
+				de["otype"] = mj::Value::make_string("Identity");
 			} else {
 				de["otype"] = mj::Value::make_string("SphericalHarmonics");
 				de["degree"] = mj::Value::make_uint(4);

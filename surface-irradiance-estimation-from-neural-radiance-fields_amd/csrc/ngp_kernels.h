@@ -83,7 +83,8 @@ struct WideLayer {
 struct WideModel {
 	const uint4* frags;
 	uint32_t width;                        // n_neurons: 128 or 256; 0 = the model is not of this architecture
-	uint32_t pos_freqs, dir_freqs;         // n_frequencies of the position / direction encodings; dir_freqs 0 = SphericalHarmonics degree 4
+	uint32_t pos_freqs, dir_freqs;         // n_frequencies of the position / direction encodings; dir_freqs 0 = SphericalHarmonics degree 4 ...
+	uint32_t pos_identity, dir_identity;   // ... unless the encoding is tcnn's Identity (configs/nerf/none.json): the inputs themselves, padded with ones
 	uint32_t enc_dims, dir_dims, rgb_in;   // padded widths (nerf_network.h:81-100): position encoding, direction encoding, rgb network input
 	uint32_t n_hidden_density, n_hidden_rgb;
 	// density: layers [0, n_hidden_density] (the last one is the 16-wide output layer); rgb: the n_hidden_rgb + 1 layers behind them

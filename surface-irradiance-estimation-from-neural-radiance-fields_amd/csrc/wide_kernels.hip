@@ -144,6 +144,17 @@ NGP_DEV void frequency_encode(uint32_t n_freq, uint32_t padded, float x, float y
 	}
 }
 
+// tcnn Identity encoding (encodings/identity.h; configs/nerf/none.json): out[j] = in[j] * scale + offset (1, 0 here) rounded to fp16, ones up to
+// `padded`; zeros from there to k_end as above
+NGP_DEV void identity_encode(uint32_t padded, float x, float y, float z, half_t* out, uint32_t k_end = 0) {
+	half8 v = {(half_t)x, (half_t)y, (half_t)z, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+	*(half8*)out = v; // (padded is a multiple of 8: next_multiple(3, alignment))
+	const half8 ones = {(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+	for (uint32_t j = 8u; j < padded; j += 8u) *(half8*)(out + j) = ones;
+	const half8 zeros = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (uint32_t j = padded; j < k_end; j += 8u) *(half8*)(out + j) = zeros;
+}
+
 NGP_DEV uint2 pack4(float a, float b, float c, float d, bool relu) {
 	half2_t lo = {(half_t)a, (half_t)b}, hi = {(half_t)c, (half_t)d}; // v_cvt_pk_f16_f32
 	if (relu) { // max(round(x), 0) == round(max(x, 0)): v_pk_max_f16
@@ -440,7 +451,8 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int slot, f3 d) {
 	const float dx = (d.x + 1.0f) * 0.5f, dy = (d.y + 1.0f) * 0.5f, dz = (d.z + 1.0f) * 0.5f;
 	half_t* out = S.dir + slot * DIR_STRIDE;
-	if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dx, dy, dz, out, 0u, W.dir_freqs, true);
+	if (W.dir_identity) identity_encode(W.dir_dims, dx, dy, dz, out);
+	else if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dx, dy, dz, out, 0u, W.dir_freqs, true);
 	else sh4_all(dx, dy, dz, out);
 }
 
@@ -449,6 +461,10 @@ NGP_DEV void encode_positions(const WideModel& W, WideShared& S, int tid) {
 	const int row = tid & (ROWS - 1), part = tid >> 7;
 	const float4 p = *row_meta(S, row);
 	if (p.w == 0.0f) return;
+	if (W.pos_identity) {
+		if (part == 0) identity_encode(W.enc_dims, p.x, p.y, p.z, S.x + row * XS, (uint32_t)WIDE_TILE_K * W.layers[0].n_kblocks);
+		return;
+	}
 	const uint32_t split = (W.pos_freqs + 1u) / 2u;
 	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, (uint32_t)WIDE_TILE_K * W.layers[0].n_kblocks);
 }
@@ -786,7 +802,8 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 			S.owner[row] = (uint16_t)row;
 		} else if (run) {
 			half_t* d = S.dir + row * DIR_STRIDE;
-			if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d, 0u, W.dir_freqs, true);
+			if (W.dir_identity) identity_encode(W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
+			else if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d, 0u, W.dir_freqs, true);
 			else sh4_all(dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
 		}
 		lds_barrier();
@@ -811,7 +828,9 @@ NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, 
 __global__ void frequency_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	frequency_encode(M.wide.pos_freqs, M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], (half_t*)out + (size_t)M.wide.enc_dims * i, 0u, M.wide.pos_freqs, true);
+	half_t* o = (half_t*)out + (size_t)M.wide.enc_dims * i;
+	if (M.wide.pos_identity) identity_encode(M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], o);
+	else frequency_encode(M.wide.pos_freqs, M.wide.enc_dims, pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], o, 0u, M.wide.pos_freqs, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------

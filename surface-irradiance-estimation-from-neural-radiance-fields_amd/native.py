@@ -347,11 +347,16 @@ class Context:
     def set_model(self, scene):
         d = ModelDesc()
         enc = scene["encoding"]
-        if enc.get("otype") == "Frequency":  # configs/nerf/frequency.json
-            d.pos_encoding, d.pos_n_frequencies = 1, enc["n_frequencies"]
+        if enc.get("otype") in ("Frequency", "Identity"):  # configs/nerf/frequency.json, none.json
+            if enc["otype"] == "Identity":
+                d.pos_encoding = 2
+            else:
+                d.pos_encoding, d.pos_n_frequencies = 1, enc["n_frequencies"]
             de = scene.get("dir_encoding", {})
             if de.get("otype") == "Frequency":
                 d.dir_encoding, d.dir_n_frequencies = 1, de["n_frequencies"]
+            elif de.get("otype") == "Identity":
+                d.dir_encoding = 2
             if scene["network"].get("otype", "FullyFusedMLP") != scene["rgb_network"].get("otype", "FullyFusedMLP"):
                 raise ValueError("Frequency encodings: the density and the rgb network must be of the same otype")
         else:
@@ -589,7 +594,7 @@ class Context:
         pos01 = np.ascontiguousarray(pos01, np.float32)
         d = self.get_model()  # a Frequency position encoding (pos_encoding 1) is as wide as its padded 3 * 2 * n_frequencies
         al = d.mlp_alignment or 16
-        width = (6 * d.pos_n_frequencies + al - 1) // al * al if d.pos_encoding == 1 else 32
+        width = (6 * d.pos_n_frequencies + al - 1) // al * al if d.pos_encoding == 1 else (3 + al - 1) // al * al if d.pos_encoding == 2 else 32
         out = np.zeros((pos01.shape[0], width), np.uint16)
         self._check(self.L.ngp_grid_encode(self.h, pos01.shape[0], _p(pos01), _p(out)))
         return out.view(np.float16)

@@ -44,6 +44,15 @@ def frequency_network_config(n_neurons=256, n_hidden_density=7, n_hidden_rgb=1):
     }
 
 
+def identity_network_config(n_neurons=256, n_hidden_density=7, n_hidden_rgb=1):
+    """configs/nerf/none.json merged over frequency.json: Identity encodings (the position and the direction themselves, padded with ones to the
+    CutlassMLPs' alignment of 8) in front of the same MLPs."""
+    cfg = frequency_network_config(n_neurons, n_hidden_density, n_hidden_rgb)
+    cfg["encoding"] = {"otype": "Identity"}
+    cfg["dir_encoding"] = {"otype": "Identity"}
+    return cfg
+
+
 def network_shapes(cfg):
     """(position encoding width, direction encoding width, rgb network input width, rgb network output width) as NerfNetwork derives
     them (nerf_network.h:81-100): the position encoding is padded to the density network's alignment, the direction encoding, the
@@ -52,9 +61,10 @@ def network_shapes(cfg):
     al = 8 if cfg["rgb_network"].get("otype", "FullyFusedMLP") == "CutlassMLP" else 16
     up = lambda v: (v + al - 1) // al * al
     enc = cfg["encoding"]
-    enc_dims = (3 * 2 * enc["n_frequencies"] + al_pos - 1) // al_pos * al_pos if enc.get("otype") == "Frequency" else enc["n_levels"] * enc["n_features_per_level"]
+    up_pos = lambda v: (v + al_pos - 1) // al_pos * al_pos
+    enc_dims = up_pos(3 * 2 * enc["n_frequencies"]) if enc.get("otype") == "Frequency" else up_pos(3) if enc.get("otype") == "Identity" else enc["n_levels"] * enc["n_features_per_level"]
     de = cfg.get("dir_encoding", {})
-    dir_dims = up(3 * 2 * de["n_frequencies"]) if de.get("otype") == "Frequency" else 16
+    dir_dims = up(3 * 2 * de["n_frequencies"]) if de.get("otype") == "Frequency" else up(3) if de.get("otype") == "Identity" else 16
     dens_out = cfg["network"].get("n_output_dims", 16)
     return enc_dims, dir_dims, up(dens_out + dir_dims), up(3)
 
@@ -98,7 +108,7 @@ def n_params(cfg):
     dens_out = cfg["network"].get("n_output_dims", 16)
     nd = mlp_n_params(enc_dims, cfg["network"]["n_neurons"], cfg["network"]["n_hidden_layers"], dens_out)
     nr = mlp_n_params(rgb_in, cfg["rgb_network"]["n_neurons"], cfg["rgb_network"]["n_hidden_layers"], rgb_out)
-    if enc.get("otype") == "Frequency":
+    if enc.get("otype") in ("Frequency", "Identity"):
         return nd, nr, 0
     offsets, _, _ = grid_layout(enc)
     return nd, nr, offsets[-1] * enc["n_features_per_level"]

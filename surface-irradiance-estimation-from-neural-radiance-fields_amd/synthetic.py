@@ -106,7 +106,8 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
     cfg = {k: dict(v) if isinstance(v, dict) else v for k, v in cfg.items()}
     enc = cfg["encoding"]
     frequency = enc.get("otype") == "Frequency"
-    if not frequency:
+    identity = enc.get("otype") == "Identity"
+    if not frequency and not identity:
         enc["log2_hashmap_size"] = log2_hashmap_size
         if "per_level_scale" not in enc:
             enc["per_level_scale"] = S.per_level_scale(aabb_scale, enc["n_levels"], enc["base_resolution"], pls_rule)
@@ -148,6 +149,8 @@ def make_scene(aabb_scale=1, seed=1234, log2_hashmap_size=19, pls_rule="fork", t
         h = np.stack([np.sin(arg), np.sin(arg + np.float32(np.pi / 2))], -1).reshape(pts.shape[0], -1).astype(np.float32)
         if h.shape[1] < enc_dims:
             h = np.concatenate([h, np.ones((pts.shape[0], enc_dims - h.shape[1]), np.float32)], 1)
+    elif identity:  # tcnn IdentityEncoding: the inputs, padded with ones
+        h = np.concatenate([pts, np.ones((pts.shape[0], enc_dims - 3), np.float32)], 1)
     else:
         h = _grid_encode_np(grid.astype(np.float16).astype(np.float32), cfg, pts)
     for W in dens_layers[:-1]:

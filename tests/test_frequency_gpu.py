@@ -147,6 +147,45 @@ def test_snapshot_round_trip_and_modes(ctx, native, scene_mod, scene_freq, tmp_p
         other.close()
 
 
+def test_identity_encodings(ctx, oracle, native, scene_mod, tmp_path):
+    """configs/nerf/none.json: tcnn Identity encodings -- the warped position and the direction themselves, padded with ones to the
+    CutlassMLPs' alignment (3 -> 8) -- in front of frequency.json's MLPs: encoding bit for bit, network, a frame, the snapshot round trip."""
+    sc = _with_bitfield(oracle, pkg("synthetic").make_scene(aabb_scale=1, seed=17, cfg=scene_mod.identity_network_config()))
+    assert scene_mod.network_shapes(sc) == (8, 8, 24, 8) and scene_mod.n_params(sc) == (8 * 256 + 6 * 256 * 256 + 16 * 256, 24 * 256 + 8 * 256, 0)
+    ctx.set_model(sc)
+    d = ctx.get_model()
+    assert (d.pos_encoding, d.dir_encoding, d.mlp_alignment) == (2, 2, 8)
+    pos, dir01 = _rays(5000, 3)
+    enc = ctx.grid_encode(pos)
+    assert enc.shape == (5000, 8) and np.array_equal(enc[:, :3], pos.astype(np.float16)) and (enc[:, 3:] == 1).all()
+    m = oracle.make_model(sc)
+    got = ctx.network(pos, dir01).astype(np.float32)
+    ref = oracle.network(m, pos, dir01).astype(np.float32)
+    err = np.abs(got - ref)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)
+    assert np.isfinite(got).all() and err.max() <= 6e-2 and (err <= 2 * ulp).mean() > 0.9, (err.max(), (err <= 2 * ulp).mean())
+    w, h = 96, 54
+    mat = scene_mod.orbit_camera(40.0, 25.0, 3.2)
+    focal = scene_mod.focal_from_fov_x(w, 0.6911)
+    img = ctx.render(native.make_camera(mat, w, h, focal), native.make_opts())
+    st = ctx.render_stats()
+    fb, db, ost = oracle.render_nerf(m, oracle.make_camera(mat, w, h, focal))
+    ref_img = oracle.tonemap(oracle.accumulate(fb.reshape(-1, 4), np.zeros((w * h, 4), np.float32), 0)).reshape(h, w, 4)
+    oracle.release(m)
+    assert abs(int(st["n_samples"]) - int(ost["n_samples"])) <= max(4, ost["n_samples"] // 2000) and ost["n_samples"] > 10000
+    assert psnr(img[..., :3], ref_img[..., :3]) >= 50.0
+    path = str(tmp_path / "none.ingp")
+    ctx.save_snapshot_file(path)
+    other = native.Context(0)
+    try:
+        other.load_snapshot_file(path)
+        d2 = other.get_model()
+        assert (d2.pos_encoding, d2.dir_encoding, d2.mlp_alignment, d2.n_params) == (2, 2, 8, d.n_params)
+        assert np.array_equal(other.network(pos, dir01).astype(np.float32), got)
+    finally:
+        other.close()
+
+
 def test_density_grid_refresh(native, oracle, scene_freq):
     """update_density_grid_nerf works for any NerfNetwork (src/testbed_nerf.cu:2772-2861): for the Frequency architecture the sampled
     cells and positions are the grid model's (same pcg32 stream), the density comes from the wide-MLP kernel; against the oracle."""

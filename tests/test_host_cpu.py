@@ -281,6 +281,18 @@ def test_frequency_architecture_snapshot(tmp_path, native, scene_mod):
         ctx2.load_snapshot_bytes(msgpack.packb(dict(root, encoding={"otype": "Frequency", "n_frequencies": 12}), use_bin_type=True))
     with pytest.raises(RuntimeError, match="unsupported network architecture"):
         ctx2.load_snapshot_bytes(msgpack.packb(dict(root, network=dict(root["network"], n_neurons=64), rgb_network=dict(root["rgb_network"], n_neurons=64)), use_bin_type=True))
+    # configs/nerf/none.json: Identity encodings in front of the same MLPs (3 -> 8 inputs each, rgb input 16 + 8)
+    ident = scene_mod.identity_network_config()
+    assert scene_mod.network_shapes(ident) == (8, 8, 24, 8)
+    ctx.set_model(pkg("synthetic").make_scene(aabb_scale=1, seed=4, cfg=ident))
+    ctx.save_snapshot_file(p, compress=False)
+    root = msgpack.unpackb(open(p, "rb").read(), raw=False)
+    assert root["encoding"] == {"otype": "Identity"} and root["dir_encoding"] == {"otype": "Identity"} and root["snapshot"]["n_params"] == 399360 + 8192
+    ctx2.load_snapshot_file(p)
+    d = ctx2.get_model()
+    assert (d.pos_encoding, d.dir_encoding, d.mlp_alignment, d.n_params) == (2, 2, 8, 399360 + 8192)
+    with pytest.raises(RuntimeError, match="unsupported Identity encoding"):
+        ctx2.load_snapshot_bytes(msgpack.packb(dict(root, encoding={"otype": "Identity", "scale": 2.0}), use_bin_type=True))
     ctx2.close()
     ctx.close()
 
