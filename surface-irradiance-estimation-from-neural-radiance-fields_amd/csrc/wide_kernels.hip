@@ -307,13 +307,23 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __
 		if (kb < NKB - 1) __builtin_amdgcn_sched_barrier(0);
 	}
 	ring_preload<MT>(ar, next);
+	// Lane (n, h) holds neurons 8 q + 4 h .. + 3 of its sample: 8 bytes per q. Written like that, the 32 lanes of a half wave hit every second
+	// bank pair twice (row stride 132 dwords: lanes n and n + 16 share banks -- the stride is the one the 16-byte operand READS need). The two
+	// halves of the wave trade one q each instead (v_permlane32_swap: the low half ends up with neurons 16 j .. + 7, the high half with
+	// 16 j + 8 .. + 15) and write 16 bytes per lane: half as many LDS instructions, conflict-free like the reads.
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
-		half_t* row = X + (32 * t + n) * XS + 32 * (wave * MT) + 4 * h;
+		half_t* row = X + (32 * t + n) * XS + 32 * (wave * MT) + 8 * h;
 #pragma unroll
 		for (int m = 0; m < MT; ++m)
 #pragma unroll
-			for (int q = 0; q < 4; ++q) *(uint2*)(row + 32 * m + 8 * q) = pack4(acc[m][t][4 * q], acc[m][t][4 * q + 1], acc[m][t][4 * q + 2], acc[m][t][4 * q + 3], true);
+			for (int j = 0; j < 2; ++j) {
+				const uint2 p0 = pack4(acc[m][t][8 * j], acc[m][t][8 * j + 1], acc[m][t][8 * j + 2], acc[m][t][8 * j + 3], true);
+				const uint2 p1 = pack4(acc[m][t][8 * j + 4], acc[m][t][8 * j + 5], acc[m][t][8 * j + 6], acc[m][t][8 * j + 7], true);
+				const auto sx = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
+				const auto sy = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
+				*(uint4*)(row + 32 * m + 16 * j) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+			}
 	}
 	lds_barrier();
 	if (pr) pr[8] += stamp() - ts0; // (K loop and epilogue together: a stamp between them would keep the packing out of the last MFMAs' shadow)
