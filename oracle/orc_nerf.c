@@ -574,11 +574,16 @@ static void nerf_network_one_f(const orc_nerf_model* m, const prepared_t* p, con
  * GridEncoding::backward's input path (kernel_grid_backward_input: dL_dx[d] = sum_k (float)dL_dy[k] * dy_dx[d][k] in fp32, with the
  * dy_dx that kernel_grid forms for linear interpolation: scale * sum over the 4 corner pairs of w_other * (val_right - val_left)),
  * and a division by the scale. tcnn is not in the mount (PARITY UNPINNED): its fused backward's rounding points are restated as
- * "exact sum, rounded to fp32, then to fp16" like the forward pass. HashGrid models only. */
+ * "exact sum, rounded to fp32, then to fp16" like the forward pass.
+ * Frequency encodings (configs/nerf/frequency.json): tcnn's forward pass stores dy_dx[j] = scalbnf(1, log2_frequency) * PI * __cosf(input) in
+ * fp32 beside each feature, and frequency_encoding_backward sums dL_dx[d] = sum_k (float)dL_dy[d 2F + k] * dy_dx[d 2F + k] in fp32, k ascending
+ * (encodings/frequency.h). Identity encodings: dL_dx[d] = dL_dy[d] * scale (1). */
 static void density_gradient_one(const orc_nerf_model* m, const prepared_t* p, const float* x, float* grad3, uint16_t* logit_out) {
 	const uint32_t F = m->n_features_per_level, W = m->n_neurons, E = p->enc_dims, NH = m->n_hidden_density;
-	uint16_t enc_h[ORC_MAX_LEVELS * 8];
-	grid_encode_one(m, p, x, enc_h);
+	uint16_t enc_h[ORC_MAX_LEVELS * 8 > 256 ? ORC_MAX_LEVELS * 8 : 256];
+	if (m->pos_encoding == 1) frequency_encode_one(3, m->pos_n_frequencies, p->enc_dims, x, enc_h);
+	else if (m->pos_encoding == 2) identity_encode_one(3, p->enc_dims, x, enc_h);
+	else grid_encode_one(m, p, x, enc_h);
 	float act[9][256] = {{0.0f}}; /* act[0] = encoding, act[k] = hidden layer k (as floats of the fp16 values) */
 	for (uint32_t i = 0; i < E; ++i) act[0][i] = orc_half_to_float(enc_h[i]);
 	const float* w = p->density_w;
@@ -611,6 +616,24 @@ static void density_gradient_one(const orc_nerf_model* m, const prepared_t* p, c
 	}
 	/* g = dL_dy over the encoding (fp16 values). dy_dx and the sum over features, level by level */
 	float result[3] = {0.0f, 0.0f, 0.0f};
+	if (m->pos_encoding == 1) {
+		const float PI = 3.14159265358979323846f;
+		const uint32_t nf = m->pos_n_frequencies;
+		for (uint32_t d = 0; d < 3; ++d) {
+			for (uint32_t k = 0; k < 2u * nf; ++k) {
+				const uint32_t log2_frequency = k / 2u;
+				const float input = fmaf(scalbnf(x[d], (int)log2_frequency), PI, (float)(k % 2u) * (PI / 2.0f));
+				const float dy_dx = scalbnf(1.0f, (int)log2_frequency) * PI * cosf(input);
+				result[d] += g[d * 2u * nf + k] * dy_dx;
+			}
+		}
+		for (int d = 0; d < 3; ++d) grad3[d] = result[d] * (1.0f / 128.0f);
+		return;
+	}
+	if (m->pos_encoding == 2) {
+		for (int d = 0; d < 3; ++d) grad3[d] = g[d] * (1.0f / 128.0f);
+		return;
+	}
 	for (uint32_t l = 0; l < m->n_levels; ++l) {
 		const uint32_t size = p->offsets[l + 1] - p->offsets[l];
 		const uint16_t* level = p->grid + (uint64_t)p->offsets[l] * F;

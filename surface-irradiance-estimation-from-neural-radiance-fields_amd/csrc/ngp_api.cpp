@@ -412,6 +412,23 @@ void set_model_impl(ngp_ctx* ctx, const ngp_model_desc& d) {
 		};
 		emit_mlp(ws.enc_dims, d.n_hidden_density, d.density_out_dims);
 		emit_mlp(ws.rgb_in, d.n_hidden_rgb, ws.rgb_out);
+		if (d.n_hidden_density <= (uint32_t)WIDE_MAX_NORMALS_LAYERS) {
+			// ERenderMode::Normals: the density network's hidden layers transposed (the backward pass of tcnn's input_gradient runs the same GEMM
+			// kernels on them), zero rows beyond the encoding's width in layer 0, and row 0 of the output layer (the one-hot loss gradient's only row)
+			const uint16_t* D = ctx->params.data();
+			std::vector<uint16_t> wt((size_t)d.n_neurons * d.n_neurons);
+			uint32_t n_in = ws.enc_dims;
+			for (uint32_t k = 0; k < d.n_hidden_density; ++k) {
+				std::fill(wt.begin(), wt.end(), (uint16_t)0);
+				for (uint32_t o = 0; o < d.n_neurons; ++o)
+					for (uint32_t i = 0; i < n_in && i < d.n_neurons; ++i) wt[(size_t)i * d.n_neurons + o] = D[(size_t)o * n_in + i];
+				WM.layers_t[k] = emit_wide_fragments(frags, wt.data(), d.n_neurons, d.n_neurons);
+				D += (size_t)d.n_neurons * n_in;
+				n_in = d.n_neurons;
+			}
+			WM.out_row0_offset = (uint32_t)(frags.size() / 8);
+			frags.insert(frags.end(), D, D + d.n_neurons); // (D now points at the output layer: row 0 = the density logit's weights)
+		}
 		NGP_HIP_CHECK(hipMalloc((void**)&ctx->d_wfrags, frags.size() * sizeof(uint16_t)));
 		NGP_HIP_CHECK(hipMemcpy(ctx->d_wfrags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		WM.frags = ctx->d_wfrags;
@@ -1152,7 +1169,8 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_NORMALS) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Normals, Positions, Depth, Cost");
 	const bool gbuffer_mode = (opts.render_mode >= NGP_RENDER_AO && opts.render_mode <= NGP_RENDER_COST) || opts.render_mode == NGP_RENDER_NORMALS;
 	if (gbuffer_mode && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Normals, Positions, Depth, Cost) apply to NeRF mode");
-	if (opts.render_mode == NGP_RENDER_NORMALS && ctx->model_loaded && ctx->M.wide.width) throw std::runtime_error("render_mode Normals is built for the grid encodings (configs/nerf/base.json); not for a Frequency-encoding model");
+	if (opts.render_mode == NGP_RENDER_NORMALS && ctx->model_loaded && ctx->M.wide.width && (!ctx->M.wide.layers_t[0].n_mtiles || ctx->M.wide.enc_dims > ctx->M.wide.width))
+		throw std::runtime_error("render_mode Normals on a Frequency / Identity-encoding model: implemented for up to 8 hidden density layers and an encoding no wider than the network");
 	const uint32_t shard_count = opts.shard_count ? opts.shard_count : 1u;
 	if (opts.shard_index >= shard_count) throw std::runtime_error("shard_index out of range");
 	const uint32_t tiles_total = (uint32_t)((cam.width + 7) / 8) * (uint32_t)((cam.height + 7) / 8);
@@ -1926,7 +1944,8 @@ int ngp_density_gradient(ngp_ctx* ctx, uint32_t n, const float* pos01, float* ou
 	return guarded(ctx, [&] {
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); there is no CPU fallback");
 		if (!ctx->model_loaded) throw std::runtime_error("No network available.");
-		if (ctx->M.wide.width) throw std::runtime_error("the density gradient is built for the grid encodings (configs/nerf/base.json)");
+		if (ctx->M.wide.width && (!ctx->M.wide.layers_t[0].n_mtiles || ctx->M.wide.enc_dims > ctx->M.wide.width))
+			throw std::runtime_error("the density gradient of a Frequency / Identity-encoding model: implemented for up to 8 hidden density layers and an encoding no wider than the network");
 		ngp::sync_inference_model(ctx);
 		if (n == 0) return;
 		if (!pos01 || !out_grad) throw std::runtime_error("null argument");
@@ -1934,7 +1953,8 @@ int ngp_density_gradient(ngp_ctx* ctx, uint32_t n, const float* pos01, float* ou
 		NGP_HIP_CHECK(hipMalloc((void**)&d_pos, (size_t)n * 3 * sizeof(float)));
 		NGP_HIP_CHECK(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)));
 		NGP_HIP_CHECK(hipMemcpy(d_pos, pos01, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-		launch_density_gradient(ctx->M, n, d_pos, d_out, ctx->stream);
+		if (ctx->M.wide.width) launch_density_gradient_wide(ctx->M, n, d_pos, d_out, ctx->n_cus, ctx->stream);
+		else launch_density_gradient(ctx->M, n, d_pos, d_out, ctx->stream);
 		NGP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		NGP_HIP_CHECK(hipMemcpy(out_grad, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
 		(void)hipFree(d_pos);

@@ -35,6 +35,7 @@ void launch_density_gradient(const ModelParams& M, uint32_t n, const float* pos0
 void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream);
 void launch_trace_probe_wide(const ModelParams& M, const FrameParams& F, const ProbeParams& P, int n_cus, hipStream_t stream);
 void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, int n_cus, hipStream_t stream);
+void launch_density_gradient_wide(const ModelParams& M, uint32_t n, const float* pos01, float* out, int n_cus, hipStream_t stream);
 void launch_frequency_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream);
 void launch_network_inference(const ModelParams& M, uint32_t n, const float* pos01, const float* dir01, uint16_t* out, hipStream_t stream);
 void launch_density_grid_update(const ModelParams& M, uint32_t n_samples, const Pcg32& rng, uint32_t step, uint32_t n_cascades, float thresh, const float* grid,

@@ -89,7 +89,13 @@ struct WideModel {
 	uint32_t n_hidden_density, n_hidden_rgb;
 	// density: layers [0, n_hidden_density] (the last one is the 16-wide output layer); rgb: the n_hidden_rgb + 1 layers behind them
 	WideLayer layers[WIDE_MAX_LAYERS];
+	// ERenderMode::Normals (the density network's input gradient): its hidden layers TRANSPOSED -- layers_t[l] maps the gradient at layer l's
+	// neurons to layer l's inputs (width x width fragments; layer 0's rows beyond the encoding are zeros) -- for up to WIDE_MAX_NORMALS_LAYERS
+	// hidden layers (0 tiles in layers_t[0]: not prepared), and row 0 of the density output layer (`width` halves at frags + out_row0_offset)
+	WideLayer layers_t[8];
+	uint32_t out_row0_offset;
 };
+constexpr int WIDE_MAX_NORMALS_LAYERS = 8;
 
 struct ModelParams {
 	const uint2* grid;       // fp16 x4 per entry, tcnn order (level-major, entry-major)

@@ -102,6 +102,24 @@ NGP_DEV float encoder_sin(float t) {
 	if (!(__builtin_fabsf(t) < 1048576.0f)) return sinf(t);
 	return encoder_sin_reduced(t);
 }
+// cos(t) the same way (the encoding's derivative, ERenderMode::Normals): even Taylor polynomial of degree 12 on [-pi/2, pi/2], |error| < 1e-7
+NGP_DEV float encoder_cos(float t) {
+	if (!(__builtin_fabsf(t) < 1048576.0f)) return cosf(t);
+	const float k = __builtin_rintf(t * 0.318309886183790672f);
+	float r = __builtin_fmaf(-k, 3.14159274101257324f, t);
+	r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);
+	r = __builtin_fmaf(-k, -3.55271367880050093e-15f, r);
+	const float r2 = r * r;
+	float p = 2.08767569878680990e-09f;
+	p = __builtin_fmaf(p, r2, -2.75573192239858907e-07f);
+	p = __builtin_fmaf(p, r2, 2.48015873015873016e-05f);
+	p = __builtin_fmaf(p, r2, -1.38888888888888889e-03f);
+	p = __builtin_fmaf(p, r2, 4.16666666666666667e-02f);
+	p = __builtin_fmaf(p, r2, -0.5f);
+	const float c = __builtin_fmaf(p, r2, 1.0f);
+	const uint32_t flip = (uint32_t)(int)k << 31; // cos(r + k pi) = (-1)^k cos(r)
+	return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c) ^ flip);
+}
 
 // tcnn FrequencyEncoding (encodings/frequency.h): feature j of input x is
 //   sin(fma(scalbn(x[j / (2 F)], (j / 2) % F), pi, (j % 2) pi / 2))
@@ -274,8 +292,11 @@ NGP_DEV OutTiles wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const ui
 }
 #else
 // One hidden layer, in place: X[:, 0 .. 128 MT) <- ReLU(W X[:, 0 .. 16 NKB)); ring stages 0..2 hold (or await) K-blocks 0..2.
-template <int MT, int NKB>
-NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next, unsigned long long* pr = nullptr) {
+// MODE (ERenderMode::Normals, the density network's backward pass on the same GEMM): 0 = forward; 1 = forward, and bit (row, neuron) of `mask`
+// (ROWS x 32 bytes) records which outputs are positive; 2 = a TRANSPOSED layer of the backward pass: no ReLU, outputs whose mask bit is
+// clear become zero (the ReLU's derivative at the forward activation); 3 = transposed, no mask (the first layer: its inputs are the encoding)
+template <int MT, int NKB, int MODE = 0>
+NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __restrict__ wf, int wave, int lane, LayerFrags next, unsigned long long* pr = nullptr, uint8_t* mask = nullptr) {
 	const int n = lane & 31, h = lane >> 5;
 	unsigned long long ts0 = 0;
 	if (pr) ts0 = stamp();
@@ -318,11 +339,28 @@ NGP_DEV void wide_hidden_layer(half_t* X, u32x4 (&ar)[RING][MT], const uint4* __
 		for (int m = 0; m < MT; ++m)
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
-				const uint2 p0 = pack4(acc[m][t][8 * j], acc[m][t][8 * j + 1], acc[m][t][8 * j + 2], acc[m][t][8 * j + 3], true);
-				const uint2 p1 = pack4(acc[m][t][8 * j + 4], acc[m][t][8 * j + 5], acc[m][t][8 * j + 6], acc[m][t][8 * j + 7], true);
+				const uint2 p0 = pack4(acc[m][t][8 * j], acc[m][t][8 * j + 1], acc[m][t][8 * j + 2], acc[m][t][8 * j + 3], MODE < 2);
+				const uint2 p1 = pack4(acc[m][t][8 * j + 4], acc[m][t][8 * j + 5], acc[m][t][8 * j + 6], acc[m][t][8 * j + 7], MODE < 2);
 				const auto sx = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
 				const auto sy = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
-				*(uint4*)(row + 32 * m + 16 * j) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+				uint4 v = make_uint4(sx[0], sy[0], sx[1], sy[1]); // neurons c0 .. c0 + 7 of row 32 t + n, c0 = 32 (wave MT + m) + 16 j + 8 h
+				if (MODE == 1 || MODE == 2) {
+					uint8_t* mb = mask + (32 * t + n) * 32 + 4 * (wave * MT + m) + 2 * j + h;
+					const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+					if (MODE == 1) { // (after the ReLU a value is positive iff it is not a zero of either sign)
+						uint32_t bits = 0;
+#pragma unroll
+						for (int k = 0; k < 4; ++k) bits |= ((w4[k] & 0x7fffu) ? 1u : 0u) << (2 * k) | ((w4[k] & 0x7fff0000u) ? 1u : 0u) << (2 * k + 1);
+						*mb = (uint8_t)bits;
+					} else {
+						const uint32_t bits = *mb;
+						uint32_t o4[4];
+#pragma unroll
+						for (int k = 0; k < 4; ++k) o4[k] = w4[k] & (((bits >> (2 * k)) & 1u ? 0xffffu : 0u) | ((bits >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u));
+						v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+					}
+				}
+				*(uint4*)(row + 32 * m + 16 * j) = v;
 			}
 	}
 	lds_barrier();
@@ -356,6 +394,7 @@ NGP_DEV floatx16 wide_out_layer(const half_t* X, u32x4 (&ar)[RING][MT], const ui
 
 struct WideOut {
 	half_t r, g, b, sigma;
+	float gx, gy, gz; // ERenderMode::Normals only: d logit / d warped position
 };
 constexpr int K256 = 256 / WIDE_TILE_K, K128 = 128 / WIDE_TILE_K; // K blocks of the two layer shapes the kernels are instantiated for
 
@@ -458,6 +497,108 @@ NGP_DEV WideOut wide_network(const WideModel& W, WideShared& S, int tid, u32x4 (
 	return o;
 }
 
+#if !WIDE_MFMA16
+template <int MT>
+NGP_DEV LayerFrags layer_frags_t(const WideModel& W, int l, int wave, int lane) {
+	LayerFrags L;
+	if (l < 0) {
+		L.base = nullptr; L.nkb = 0; L.mt = 0;
+		return L;
+	}
+	L.nkb = (int)W.layers_t[l].n_kblocks;
+	L.mt = MT;
+	L.base = W.frags + W.layers_t[l].frag_offset + (size_t)(wave * MT) * L.nkb * 64 + lane;
+	return L;
+}
+// ERenderMode::Normals for this architecture: what tcnn's DifferentiableObject::input_gradient(stream, 3, ...) computes for the workgroup's 128 rows
+// (src/testbed_nerf.cu:2106-2107; restated in oracle/orc_nerf.c density_gradient_one). NerfNetwork::backward_impl routes the one-hot loss gradient
+// (backprop_scale 128 at output 3) to the density network's output 0 only -- the rgb network does not see it --, so: the density network forward
+// with every hidden layer's ReLU mask kept as bits (`mask`: n_hidden_density x ROWS x 32 bytes), g = 128 W_out[0][:] under the last mask, the hidden
+// layers TRANSPOSED on the same GEMM kernel (fp16 gradients between layers, each masked by the layer below), and the encoding's own derivative:
+// Frequency: dL_dx[d] = sum_k (float)dL_dy[d 2F + k] * (2^f pi cos(input_k)) in fp32 (tcnn encodings/frequency.h); Identity: dL_dy[d].
+// Entry and exit as wide_network; the returned sigma is the density logit, (gx, gy, gz) the gradient / 128.
+template <int MT>
+NGP_DEV WideOut wide_density_gradient(const WideModel& W, WideShared& S, uint8_t* mask, int tid, u32x4 (&ar)[RING][MT], int my_row) {
+	const int wave = tid >> 6, lane = tid & 63;
+	const int n = lane & 31, h = lane >> 5;
+	const int row_id = tid & (ROWS - 1), part = tid >> 7;
+	const int NH = (int)W.n_hidden_density;
+	WideOut o;
+	o.r = o.g = o.b = o.sigma = (half_t)0.0f;
+	o.gx = o.gy = o.gz = 0.0f;
+	for (int l = 0; l < NH; ++l) {
+		const LayerFrags cur = layer_frags<MT>(W, (uint32_t)l, wave, lane), next = layer_frags<MT>(W, (uint32_t)l + 1u, wave, lane);
+		if (cur.nkb == K256) wide_hidden_layer<MT, K256, 1>(S.x, ar, cur.base, wave, lane, next, nullptr, mask + (size_t)l * ROWS * 32);
+		else wide_hidden_layer<MT, K128, 1>(S.x, ar, cur.base, wave, lane, next, nullptr, mask + (size_t)l * ROWS * 32);
+	}
+	{ // the density output layer: only the logit is needed (and kept: column 0 of the wave's own rows)
+		const LayerFrags cur = layer_frags<MT>(W, (uint32_t)NH, wave, lane), next = layer_frags_t<MT>(W, NH - 1, wave, lane);
+		const floatx16 acc = cur.nkb == K256 ? wide_out_layer<MT, K256>(S.x, ar, cur.base, wave, lane, next) : wide_out_layer<MT, K128>(S.x, ar, cur.base, wave, lane, next);
+		if (h == 0) *(uint2*)(S.x + (32 * wave + n) * XS) = pack4(acc[0], acc[1], acc[2], acc[3], false);
+	}
+	lds_barrier();
+	if (my_row >= 0) o.sigma = S.x[my_row * XS];
+	lds_barrier(); // (the logits have been read: the rows may be overwritten)
+	{ // the loss gradient at the last hidden layer: 128 * W_out[0][:] where that layer's activation is positive; two threads per row
+		const half_t* w0 = (const half_t*)(W.frags + W.out_row0_offset);
+		const uint8_t* mrow = mask + (size_t)(NH - 1) * ROWS * 32 + row_id * 32;
+		half_t* xrow = S.x + row_id * XS;
+		const uint32_t half_w = W.width / 2u;
+		for (uint32_t c = (uint32_t)part * half_w; c < (uint32_t)(part + 1) * half_w; c += 8u) {
+			const half8 wv = *(const half8*)(w0 + c);
+			const uint32_t bits = mrow[c >> 3];
+			half8 g;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) g[i] = (bits >> i) & 1u ? (half_t)((half_t)128.0f * wv[i]) : (half_t)0.0f;
+			*(half8*)(xrow + c) = g;
+		}
+	}
+	lds_barrier();
+	for (int l = NH - 1; l >= 1; --l) {
+		const LayerFrags cur = layer_frags_t<MT>(W, l, wave, lane), next = layer_frags_t<MT>(W, l - 1, wave, lane);
+		if (cur.nkb == K256) wide_hidden_layer<MT, K256, 2>(S.x, ar, cur.base, wave, lane, next, nullptr, mask + (size_t)(l - 1) * ROWS * 32);
+		else wide_hidden_layer<MT, K128, 2>(S.x, ar, cur.base, wave, lane, next, nullptr, mask + (size_t)(l - 1) * ROWS * 32);
+	}
+	{
+		const LayerFrags cur = layer_frags_t<MT>(W, 0, wave, lane), next = layer_frags_t<MT>(W, -1, wave, lane);
+		if (cur.nkb == K256) wide_hidden_layer<MT, K256, 3>(S.x, ar, cur.base, wave, lane, next);
+		else wide_hidden_layer<MT, K128, 3>(S.x, ar, cur.base, wave, lane, next);
+	}
+	// columns [0, enc_dims) of a row now hold dL/d(encoding) in fp16; the encoding's derivative by the row's two threads (the masks are dead:
+	// their memory carries the second thread's partial sums)
+	const float4 p = *row_meta(S, row_id);
+	const half_t* g = S.x + row_id * XS;
+	float gs[3] = {0.f, 0.f, 0.f};
+	if (W.pos_identity) {
+		if (part == 0) { gs[0] = (float)g[0]; gs[1] = (float)g[1]; gs[2] = (float)g[2]; }
+	} else {
+		const float PI = 3.14159265358979323846f;
+		const uint32_t F = W.pos_freqs, split = (F + 1u) / 2u;
+		const float in[3] = {p.x, p.y, p.z};
+		for (uint32_t f = part ? split : 0u; f < (part ? F : split); ++f) {
+			const float scale = __builtin_ldexpf(PI, (int)f);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const float v = __builtin_ldexpf(in[d], (int)f);
+				const half2_t gg = *(const half2_t*)(g + (uint32_t)d * 2u * F + 2u * f);
+				gs[d] += (float)gg[0] * (scale * encoder_cos(__builtin_fmaf(v, PI, 0.0f)));
+				gs[d] += (float)gg[1] * (scale * encoder_cos(__builtin_fmaf(v, PI, PI / 2.0f)));
+			}
+		}
+	}
+	float* partial = (float*)mask;
+	if (part == 1) { partial[row_id * 4 + 0] = gs[0]; partial[row_id * 4 + 1] = gs[1]; partial[row_id * 4 + 2] = gs[2]; }
+	lds_barrier();
+	if (part == 0) *row_meta(S, row_id) = make_float4((gs[0] + partial[row_id * 4 + 0]) * (1.0f / 128.0f), (gs[1] + partial[row_id * 4 + 1]) * (1.0f / 128.0f), (gs[2] + partial[row_id * 4 + 2]) * (1.0f / 128.0f), 0.0f);
+	lds_barrier();
+	if (my_row >= 0) {
+		const float4 gq = *row_meta(S, my_row);
+		o.gx = gq.x; o.gy = gq.y; o.gz = gq.z;
+	}
+	return o;
+}
+#endif
+
 NGP_DEV void encode_direction(const WideModel& W, WideShared& S, int slot, f3 d) {
 	const float dx = (d.x + 1.0f) * 0.5f, dy = (d.y + 1.0f) * 0.5f, dz = (d.z + 1.0f) * 0.5f;
 	half_t* out = S.dir + slot * DIR_STRIDE;
@@ -479,9 +620,10 @@ NGP_DEV void encode_positions(const WideModel& W, WideShared& S, int tid) {
 	frequency_encode(W.pos_freqs, W.enc_dims, p.x, p.y, p.z, S.x + row * XS, part ? split : 0u, part ? W.pos_freqs : split, part != 0, (uint32_t)WIDE_TILE_K * W.layers[0].n_kblocks);
 }
 
-template <bool PROBE, int MT>
+template <bool PROBE, int MT, bool NORMALS = false>
 NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameParams& F, const ProbeParams& P) {
 	__shared__ WideShared S;
+	__shared__ __attribute__((aligned(16))) uint8_t s_mask[NORMALS ? WIDE_MAX_NORMALS_LAYERS * ROWS * 32 : 16]; // Normals: the hidden layers' ReLU masks (one workgroup per CU then)
 	const WideModel& W = M.wide;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const uint32_t max_cascade = M.max_cascade;
@@ -540,7 +682,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		if (__any(finished)) {
 			bool hit = false;
 			if (finished) {
-				hit = shade_ray<PROBE, false>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d);
+				hit = shade_ray<PROBE, false, NORMALS>(F, P, bg_linear, ray.out, acc, step - 1u, ray.d);
 				finished = false;
 			}
 			n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -724,7 +866,11 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 		lds_barrier();
 		if (prof) lap2(13);
 		if (prof) { lap(3); S.prof[5] += 1ull; S.prof[7] += (unsigned long long)(n_ready < ROWS ? n_ready : ROWS); }
+#if WIDE_MFMA16
 		const WideOut o = wide_network<MT>(W, S, tid, ar, my_row, prof ? S.prof : nullptr);
+#else
+		const WideOut o = NORMALS ? wide_density_gradient<MT>(W, S, s_mask, tid, ar, my_row) : wide_network<MT>(W, S, tid, ar, my_row, prof ? S.prof : nullptr);
+#endif
 		if (prof) { lap(2); t2 = t0; }
 
 		// ---- K6: composite_kernel_nerf (:569-726)
@@ -738,7 +884,11 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 			const float weight = alpha * T;
 			float cr = network_to_rgb((float)o.r, M.rgb_act), cg = network_to_rgb((float)o.g, M.rgb_act), cb = network_to_rgb((float)o.b, M.rgb_act);
 			if (!PROBE && F.render_mode > 1) {
-				if (F.render_mode == 2) {
+				if (NORMALS) { // src/testbed_nerf.cu:688-693: opposite to the density gradient
+					const float dd = network_to_density_derivative((float)o.sigma, M.density_act);
+					const f3 nrm = normalize3(mk3(-dd * o.gx, -dd * o.gy, -dd * o.gz));
+					cr = nrm.x; cg = nrm.y; cb = nrm.z;
+				} else if (F.render_mode == 2) {
 					cr = cg = cb = alpha;
 				} else if (F.render_mode == 3) {
 					cr = (pos.x - 0.5f) / 2.0f + 0.5f; cg = (pos.y - 0.5f) / 2.0f + 0.5f; cb = (pos.z - 0.5f) / 2.0f + 0.5f;
@@ -796,10 +946,24 @@ NGP_WIDE_KERNEL void trace_probe_wide128(const ModelParams M, const FrameParams 
 	wide_body<true, 32 / WIDE_TILE_M>(M, C, F, P);
 }
 
-// NerfNetwork::inference on explicit inputs (ngp_network_inference): 128 samples per workgroup round
-template <int MT>
+#if !WIDE_MFMA16
+// ERenderMode::Normals: the density network's backward pass per round; 32 KB of masks beside the activations = one workgroup per CU
+NGP_WIDE_KERNEL void render_nerf_wide256_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	wide_body<false, 64 / WIDE_TILE_M, true>(M, C, F, P);
+}
+NGP_WIDE_KERNEL void render_nerf_wide128_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
+	ProbeParams P{};
+	wide_body<false, 32 / WIDE_TILE_M, true>(M, C, F, P);
+}
+#endif
+
+// NerfNetwork::inference on explicit inputs (ngp_network_inference): 128 samples per workgroup round; GRADIENT: the density logit's input
+// gradient instead (ngp_density_gradient: 3 floats per sample into `out`)
+template <int MT, bool GRADIENT = false>
 NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
 	__shared__ WideShared S;
+	__shared__ __attribute__((aligned(16))) uint8_t s_mask[GRADIENT ? WIDE_MAX_NORMALS_LAYERS * ROWS * 32 : 16];
 	const WideModel& W = M.wide;
 	const int tid = threadIdx.x, row = tid & (ROWS - 1), part = tid >> 7;
 	for (uint32_t base = blockIdx.x * ROWS; base < n; base += gridDim.x * ROWS) { // (workgroup-uniform trip count)
@@ -810,7 +974,7 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 		if (part == 0) { // row r carries sample base + r; its direction sits in slot r
 			*row_meta(S, row) = run ? make_float4(pos01[3 * (size_t)i], pos01[3 * (size_t)i + 1], pos01[3 * (size_t)i + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
 			S.owner[row] = (uint16_t)row;
-		} else if (run) {
+		} else if (run && !GRADIENT) {
 			half_t* d = S.dir + row * DIR_STRIDE;
 			if (W.dir_identity) identity_encode(W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d);
 			else if (W.dir_freqs) frequency_encode(W.dir_freqs, W.dir_dims, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], d, 0u, W.dir_freqs, true);
@@ -819,11 +983,20 @@ NGP_DEV void wide_inference_body(const ModelParams& M, uint32_t n, const float* 
 		lds_barrier();
 		encode_positions(W, S, tid);
 		lds_barrier();
+#if WIDE_MFMA16
 		const WideOut o = wide_network<MT>(W, S, tid, ar, (run && part == 0) ? row : -1);
+#else
+		const WideOut o = GRADIENT ? wide_density_gradient<MT>(W, S, s_mask, tid, ar, (run && part == 0) ? row : -1) : wide_network<MT>(W, S, tid, ar, (run && part == 0) ? row : -1);
+#endif
 		if (run && part == 0) {
-			union { half_t h[4]; uint2 u; } p;
-			p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
-			*(uint2*)(out + 4 * (size_t)i) = p.u;
+			if (GRADIENT) {
+				float* og = (float*)out + 3 * (size_t)i;
+				og[0] = o.gx; og[1] = o.gy; og[2] = o.gz;
+			} else {
+				union { half_t h[4]; uint2 u; } p;
+				p.h[0] = o.r; p.h[1] = o.g; p.h[2] = o.b; p.h[3] = o.sigma;
+				*(uint2*)(out + 4 * (size_t)i) = p.u;
+			}
 		}
 		lds_barrier(); // (the next round's positions overwrite what this round's threads may still read)
 	}
@@ -834,6 +1007,14 @@ NGP_WIDE_KERNEL void network_inference_wide256(const ModelParams M, uint32_t n, 
 NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, const float* __restrict__ dir01, uint16_t* __restrict__ out) {
 	wide_inference_body<32 / WIDE_TILE_M>(M, n, pos01, dir01, out);
 }
+#if !WIDE_MFMA16
+NGP_WIDE_KERNEL void density_gradient_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
+	wide_inference_body<64 / WIDE_TILE_M, true>(M, n, pos01, pos01, (uint16_t*)out);
+}
+NGP_WIDE_KERNEL void density_gradient_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
+	wide_inference_body<32 / WIDE_TILE_M, true>(M, n, pos01, pos01, (uint16_t*)out);
+}
+#endif
 // the position encoding alone (ngp_grid_encode's counterpart for this architecture): n x enc_dims halves
 __global__ void frequency_encode_kernel(const ModelParams M, uint32_t n, const float* __restrict__ pos01, uint16_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -875,6 +1056,18 @@ static int wide_blocks(const FrameParams& F, int n_cus, int per_cu) {
 	return n_blocks;
 }
 void launch_render_nerf_wide(const ModelParams& M, const CameraParams& C, const FrameParams& F, int n_cus, hipStream_t stream) {
+#if !WIDE_MFMA16
+	if (F.render_mode == 7) { // ERenderMode::Normals
+		static const int per_cu256n = wide_blocks_per_cu(render_nerf_wide256_normals), per_cu128n = wide_blocks_per_cu(render_nerf_wide128_normals);
+		const int nb = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256n : per_cu128n);
+		FrameParams G = F;
+		G.n_waves = (uint32_t)nb * (WBLOCK / 64);
+		wide_schedule(G);
+		if (M.wide.width == 256) hipLaunchKernelGGL(render_nerf_wide256_normals, dim3(nb), dim3(WBLOCK), 0, stream, M, C, G);
+		else hipLaunchKernelGGL(render_nerf_wide128_normals, dim3(nb), dim3(WBLOCK), 0, stream, M, C, G);
+		return;
+	}
+#endif
 	static const int per_cu256 = wide_blocks_per_cu(render_nerf_wide256), per_cu128 = wide_blocks_per_cu(render_nerf_wide128);
 	const int n_blocks = wide_blocks(F, n_cus, M.wide.width == 256 ? per_cu256 : per_cu128);
 	FrameParams G = F;
@@ -898,6 +1091,17 @@ void launch_network_inference_wide(const ModelParams& M, uint32_t n, const float
 	if (n_blocks > 2 * n_cus) n_blocks = 2 * n_cus;
 	if (M.wide.width == 256) hipLaunchKernelGGL(network_inference_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
 	else hipLaunchKernelGGL(network_inference_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, dir01, out);
+}
+void launch_density_gradient_wide(const ModelParams& M, uint32_t n, const float* pos01, float* out, int n_cus, hipStream_t stream) {
+	if (n == 0) return;
+#if !WIDE_MFMA16
+	int n_blocks = (int)((n + ROWS - 1) / ROWS);
+	if (n_blocks > n_cus) n_blocks = n_cus;
+	if (M.wide.width == 256) hipLaunchKernelGGL(density_gradient_wide256, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, out);
+	else hipLaunchKernelGGL(density_gradient_wide128, dim3(n_blocks), dim3(WBLOCK), 0, stream, M, n, pos01, out);
+#else
+	fprintf(stderr, "[ngp] the density gradient of the wide architecture is not built in the WIDE_MFMA16 experiment\n");
+#endif
 }
 void launch_frequency_encode(const ModelParams& M, uint32_t n, const float* pos01, uint16_t* out, hipStream_t stream) {
 	if (n == 0) return;
