@@ -511,7 +511,7 @@ NGP_DEV LayerFrags layer_frags_t(const WideModel& W, int l, int wave, int lane) 
 	return L;
 }
 // ERenderMode::Normals for this architecture: what tcnn's DifferentiableObject::input_gradient(stream, 3, ...) computes for the workgroup's 128 rows
-// (src/testbed_nerf.cu:2106-2107; restated in oracle/orc_nerf.c density_gradient_one). NerfNetwork::backward_impl routes the one-hot loss gradient
+// (src/testbed_nerf.cu:2106-2107; the CPU checker restates it for the tests). NerfNetwork::backward_impl routes the one-hot loss gradient
 // (backprop_scale 128 at output 3) to the density network's output 0 only -- the rgb network does not see it --, so: the density network forward
 // with every hidden layer's ReLU mask kept as bits (`mask`: n_hidden_density x ROWS x 32 bytes), g = 128 W_out[0][:] under the last mask, the hidden
 // layers TRANSPOSED on the same GEMM kernel (fp16 gradients between layers, each masked by the layer below), and the encoding's own derivative:
