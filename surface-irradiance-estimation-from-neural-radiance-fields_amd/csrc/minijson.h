@@ -53,7 +53,9 @@ struct Value {
 		switch (type) {
 			case Int: return i;
 			case UInt: return (int64_t)u;
-			case Float: return (int64_t)f;
+			case Float:
+				if (!(f > -9.2e18 && f < 9.2e18)) throw std::runtime_error("json: number out of range for an integer"); // (NaN included; the cast would be undefined)
+				return (int64_t)f;
 			case Bool: return b ? 1 : 0;
 			default: throw std::runtime_error("json: value is not an integer");
 		}
@@ -131,6 +133,12 @@ public:
 private:
 	const char* m_p;
 	const char* m_end;
+	int m_depth = 0; // arrays / objects open around the cursor: the parser recurses, and these files are untrusted input
+	struct Nest {
+		int& d;
+		explicit Nest(int& depth) : d(depth) { if (++d > 256) throw std::runtime_error("json parse error: nesting too deep"); }
+		~Nest() { --d; }
+	};
 	[[noreturn]] void fail(const char* msg) { throw std::runtime_error(std::string("json parse error: ") + msg); }
 	void ws() {
 		for (;;) {
@@ -219,6 +227,7 @@ private:
 		return out;
 	}
 	Value array() {
+		Nest nest(m_depth);
 		++m_p;
 		Value v = Value::make_array();
 		ws();
@@ -233,6 +242,7 @@ private:
 		}
 	}
 	Value object() {
+		Nest nest(m_depth);
 		++m_p;
 		Value v = Value::make_object();
 		ws();

@@ -139,6 +139,7 @@ void build_levels(const ngp_model_desc& d, LevelInfo* lv, uint32_t* total_entrie
 	uint32_t offset = 0;
 	for (uint32_t l = 0; l < d.n_levels; ++l) {
 		float scale = exp2f((float)l * log2_pls) * (float)d.base_resolution - 1.0f;
+		if (!(scale >= 0.0f && scale < 1073741824.0f)) throw std::runtime_error("invalid hash grid configuration (a level's resolution is out of range)");
 		uint32_t res = (uint32_t)ceilf(scale) + 1u;
 		uint32_t max_params = 0xFFFFFFFFu / 2u;
 		uint32_t n = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
@@ -593,8 +594,15 @@ mj::Value lens_to_json(const TrainingView& v) {
 	return j;
 }
 
+// numbers out of untrusted files: a double that does not fit the integer type must not reach the cast (undefined behaviour); out-of-range values
+// become ones that every later validation refuses
+uint32_t to_u32(double v) { return v >= 0.0 && v < 4294967296.0 ? (uint32_t)v : 0xffffffffu; }
+int to_int(double v) { return v > -2147483648.0 && v < 2147483648.0 ? (int)v : (v < 0.0 ? -2147483647 - 1 : 2147483647); }
+
 void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-183
-	size_t n = (size_t)j.at("n_images").integer();
+	const int64_t n_images = j.at("n_images").integer();
+	if (n_images < 0 || !j.at("xforms").is_array() || (uint64_t)n_images != j.at("xforms").size()) throw std::runtime_error("snapshot dataset: n_images does not match the list of camera transforms");
+	size_t n = (size_t)n_images;
 	ds.views.assign(n, TrainingView{});
 	for (size_t i = 0; i < n; ++i) {
 		TrainingView& v = ds.views[i];
@@ -603,14 +611,14 @@ void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-
 		v.resolution[0] = v.resolution[1] = 0;
 		if (j.contains("principal_point")) read_vec(j.at("principal_point"), v.principal_point, 2);
 		if (j.contains("focal_length")) read_vec(j.at("focal_length"), v.focal_length, 2);
-		if (j.contains("image_resolution")) { float r[2]; read_vec(j.at("image_resolution"), r, 2); v.resolution[0] = (int)r[0]; v.resolution[1] = (int)r[1]; }
+		if (j.contains("image_resolution")) { float r[2]; read_vec(j.at("image_resolution"), r, 2); v.resolution[0] = to_int(r[0]); v.resolution[1] = to_int(r[1]); }
 		read_mat(j.at("xforms").at(i).at("start"), v.xform.data(), 4, 3);
 		if (j.contains("metadata")) {
 			const mj::Value& ji = j.at("metadata").at(i);
 			float r[2];
 			read_vec(ji.at("resolution"), r, 2);
-			v.resolution[0] = (int)r[0];
-			v.resolution[1] = (int)r[1];
+			v.resolution[0] = to_int(r[0]);
+			v.resolution[1] = to_int(r[1]);
 			read_vec(ji.at("focal_length"), v.focal_length, 2);
 			read_vec(ji.at("principal_point"), v.principal_point, 2);
 			if (ji.contains("lens")) lens_from_json(ji.at("lens"), v);
@@ -628,7 +636,7 @@ void dataset_from_json(const mj::Value& j, Dataset& ds) { // json_binding.h:121-
 	ds.aabb_scale = (int)j.at("aabb_scale").integer();
 	ds.from_mitsuba = j.at("from_mitsuba").boolean();
 	ds.is_hdr = j.value("is_hdr", false);
-	ds.n_extra_learnable_dims = (int)j.value("n_extra_learnable_dims", 0.0);
+	ds.n_extra_learnable_dims = to_int(j.value("n_extra_learnable_dims", 0.0));
 }
 
 mj::Value dataset_to_json(const Dataset& ds) { // json_binding.h:94-119
@@ -704,19 +712,19 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		else if (gt != "hash") throw std::runtime_error("unsupported grid type '" + gt + "' (Hash and Dense are implemented)");
 	} else if (otype == "frequency") { // configs/nerf/frequency.json
 		d.pos_encoding = 1;
-		d.pos_n_frequencies = (uint32_t)enc.value("n_frequencies", 12.0);
+		d.pos_n_frequencies = to_u32(enc.value("n_frequencies", 12.0));
 	} else if (otype == "identity") { // configs/nerf/none.json: the position itself (tcnn Identity: in * scale + offset, padded with ones)
 		if (enc.value("scale", 1.0) != 1.0 || enc.value("offset", 0.0) != 0.0) throw std::runtime_error("unsupported Identity encoding (scale 1, offset 0 are implemented)");
 		d.pos_encoding = 2;
 	} else if (otype != "hashgrid") {
 		throw std::runtime_error("unsupported encoding '" + otype + "' (HashGrid, DenseGrid, Frequency and Identity are implemented)");
 	}
-	d.n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2.0);
-	d.n_levels = enc.contains("n_features") && enc.at("n_features").num() > 0 ? (uint32_t)enc.at("n_features").num() / d.n_features_per_level
-	                                                                           : (uint32_t)enc.value("n_levels", 16.0);
-	d.log2_hashmap_size = dense_grid ? 31u : (uint32_t)enc.value("log2_hashmap_size", 15.0);
-	d.base_resolution = (uint32_t)enc.value("base_resolution", 0.0);
-	if (!d.base_resolution) d.base_resolution = 1u << (d.log2_hashmap_size / 3); // testbed.cu:3945-3949
+	d.n_features_per_level = to_u32(enc.value("n_features_per_level", 2.0));
+	d.n_levels = enc.contains("n_features") && enc.at("n_features").is_number() && enc.at("n_features").num() > 0 && d.n_features_per_level ? to_u32(enc.at("n_features").num()) / d.n_features_per_level
+	                                                                                                                                       : to_u32(enc.value("n_levels", 16.0));
+	d.log2_hashmap_size = dense_grid ? 31u : to_u32(enc.value("log2_hashmap_size", 15.0));
+	d.base_resolution = to_u32(enc.value("base_resolution", 0.0));
+	if (!d.base_resolution) d.base_resolution = d.log2_hashmap_size < 96u ? 1u << (d.log2_hashmap_size / 3) : 0u; // testbed.cu:3945-3949 (a larger value fails the validation below)
 
 	const mj::Value& nerf = snap.at("nerf");
 	Dataset ds;
@@ -758,7 +766,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 		}
 		if (root.contains("dir_encoding")) {
 			const mj::Value& de = root.at("dir_encoding");
-			auto is_sh4 = [&](const mj::Value& e) { return lower(e.value("otype", "")) == "sphericalharmonics" && (int)e.value("degree", 4.0) == 4; };
+			auto is_sh4 = [&](const mj::Value& e) { return lower(e.value("otype", "")) == "sphericalharmonics" && to_int(e.value("degree", 4.0)) == 4; };
 			auto is_freq = [&](const mj::Value& e) { return d.pos_encoding >= 1 && lower(e.value("otype", "")) == "frequency"; };
 			auto is_ident = [&](const mj::Value& e) { return d.pos_encoding >= 1 && lower(e.value("otype", "")) == "identity" && e.value("scale", 1.0) == 1.0 && e.value("offset", 0.0) == 0.0; };
 			const mj::Value* first = &de;
@@ -772,7 +780,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 			if (!ok) throw std::runtime_error("unsupported dir_encoding (SphericalHarmonics of degree 4 -- or Frequency beside a Frequency position encoding --, bare or first in a Composite with Identity for the extra dimensions, is implemented)");
 			if (is_freq(*first)) {
 				d.dir_encoding = 1;
-				d.dir_n_frequencies = (uint32_t)first->value("n_frequencies", 12.0);
+				d.dir_n_frequencies = to_u32(first->value("n_frequencies", 12.0));
 			} else if (first == &de && is_ident(de)) {
 				d.dir_encoding = 2;
 			}
@@ -782,7 +790,7 @@ void load_snapshot_value(ngp_ctx* ctx, mj::Value root) {
 	if ((uint32_t)rgb.at("n_neurons").integer() != d.n_neurons) throw std::runtime_error("density and rgb networks must have the same width");
 	d.n_hidden_density = (uint32_t)net.at("n_hidden_layers").integer();
 	d.n_hidden_rgb = (uint32_t)rgb.at("n_hidden_layers").integer();
-	d.density_out_dims = (uint32_t)net.value("n_output_dims", 16.0);
+	d.density_out_dims = to_u32(net.value("n_output_dims", 16.0));
 	d.rgb_activation = ds.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC; // testbed_nerf.cu:2653
 	d.density_activation = NGP_ACT_EXPONENTIAL;                           // nerf.h:151-152
 
@@ -1059,8 +1067,8 @@ void load_training_data_impl(ngp_ctx* ctx, const std::string& path) {
 			v.abs_path = resolve(v.path);
 			v.white_transparent = json.value("white_transparent", false);
 			v.black_transparent = json.value("black_transparent", false);
-			v.resolution[0] = (int)(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
-			v.resolution[1] = (int)(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
+			v.resolution[0] = to_int(frame.contains("w") ? frame.at("w").num() : json.value("w", 0.0));
+			v.resolution[1] = to_int(frame.contains("h") ? frame.at("h").num() : json.value("h", 0.0));
 			if ((v.resolution[0] <= 0 || v.resolution[1] <= 0) && !probe_image_size(v.abs_path, v.resolution[0], v.resolution[1]))
 				throw std::runtime_error("transforms.json gives no 'w' / 'h' and the resolution of '" + v.abs_path + "' cannot be read (PNG or JPEG expected)");
 			v.focal_length[0] = v.focal_length[1] = 1000.f;

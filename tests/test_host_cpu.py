@@ -593,6 +593,145 @@ def test_resolution_comes_from_the_image_when_the_json_has_none(tmp_path, native
     ctx.close()
 
 
+def test_parsers_survive_mutated_files(tmp_path, native):
+    """tests/aux/parse_fuzz.cpp under AddressSanitizer + UBSan: the JSON and msgpack parsers (csrc/minijson.h) on truncations, byte flips,
+    insertions and deep nesting of a transforms.json and of a snapshot -- parsed or refused, no crash (2 M nested brackets used to overflow the stack)."""
+    import subprocess
+
+    exe = str(tmp_path / "pfuzz")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "parse_fuzz.cpp")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all", src, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    frames = [{"file_path": f"./images/{i:04d}.jpg", "sharpness": 30.5 + i, "transform_matrix": np.eye(4).tolist()} for i in range(6)]
+    (tmp_path / "seed.json").write_text(json.dumps({"camera_angle_x": 0.6911, "fl_x": 1375.5, "k1": 0.03, "aabb_scale": 4, "w": 1080.0, "h": 1920.0, "frames": frames}, indent=2))
+    ctx = native.Context(-1)
+    ctx.set_model(pkg("synthetic").make_scene(aabb_scale=1, seed=5, log2_hashmap_size=8))
+    ctx.save_snapshot_file(str(tmp_path / "seed.msgpack"), compress=False)
+    ctx.close()
+    (tmp_path / "deep.json").write_text("[" * 2000000)
+    (tmp_path / "deep.msgpack").write_bytes(b"\x91" * 2000000)
+    for seed, n in (("seed.json", 2000), ("seed.msgpack", 120), ("deep.json", 1), ("deep.msgpack", 1)):
+        r = subprocess.run([exe, str(tmp_path / seed), str(n)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "parsed" in r.stdout, (seed, r.stdout[-300:], r.stderr[-800:])
+
+
+def test_snapshot_loader_survives_mutated_snapshots(tmp_path, native):
+    """Testbed::load_snapshot's counterpart on hostile files: every field of a valid snapshot replaced by values of other types and sizes, keys
+    removed, binary blobs shortened, the byte stream truncated and flipped -- the loader either loads the file or throws; the context stays usable."""
+    import msgpack
+
+    ctx = native.Context(-1)
+    sc = pkg("synthetic").make_scene(aabb_scale=2, seed=5, log2_hashmap_size=8)
+    ctx.set_model(sc)
+    p = str(tmp_path / "seed.msgpack")
+    ctx.save_snapshot_file(p, compress=False)
+    blob = open(p, "rb").read()
+    root = msgpack.unpackb(blob, raw=False)
+    weird = [None, True, -1, 0, 1, 3, 2 ** 31, 2 ** 40, -2 ** 40, 1e30, float("nan"), float("inf"), "", "x" * 70000, b"", b"\x00" * 7, [], [1, 2, 3], {}, {"a": {"b": [None]}}]
+
+    def paths(node, prefix=()):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                yield prefix + (k,)
+                yield from paths(v, prefix + (k,))
+        elif isinstance(node, list) and len(node) <= 16:
+            for i, v in enumerate(node):
+                yield prefix + (i,)
+                yield from paths(v, prefix + (i,))
+
+    def mutated(path, value, delete=False):
+        import copy
+
+        r = copy.copy(root)
+        node = r
+        for k in path[:-1]:
+            child = copy.copy(node[k])
+            node[k] = child
+            node = child
+        if delete:
+            if isinstance(node, dict):
+                del node[path[-1]]
+            else:
+                node.pop(path[-1])
+        else:
+            node[path[-1]] = value
+        return msgpack.packb(r, use_bin_type=True)
+
+    rng = np.random.default_rng(3)
+    all_paths = list(paths(root))
+    assert len(all_paths) > 60
+    n_ok = n_refused = 0
+    for path in all_paths:
+        variants = [mutated(path, None, delete=True)] + [mutated(path, weird[int(i)]) for i in rng.choice(len(weird), 5, replace=False)]
+        leaf = root
+        for k in path:
+            leaf = leaf[k]
+        if isinstance(leaf, (bytes, str)) and len(leaf) > 4:  # a blob one element short, and one element long
+            variants += [mutated(path, leaf[:-2]), mutated(path, leaf + leaf[:2])]
+        for data in variants:
+            try:
+                ctx.load_snapshot_bytes(data)
+                n_ok += 1
+            except RuntimeError:
+                n_refused += 1
+    for _ in range(150):  # the raw stream: truncations and flips in the header region
+        b = bytearray(blob)
+        if rng.random() < 0.4:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            for _k in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, min(len(b), 3000)))] = int(rng.integers(0, 256))
+        try:
+            ctx.load_snapshot_bytes(bytes(b))
+            n_ok += 1
+        except RuntimeError:
+            n_refused += 1
+    assert n_refused > 100 and n_ok > 20, (n_ok, n_refused)
+    ctx.load_snapshot_bytes(blob)  # and the context still takes the intact file
+    assert ctx.get_model().n_params == sc["params"].size
+    ctx.close()
+
+
+def test_dataset_loader_survives_mutated_transforms(tmp_path, native):
+    """Testbed::load_training_data's counterpart on hostile transforms.json files: every field replaced by values of other types and ranges
+    (negative / huge / NaN resolutions and intrinsics, matrices of the wrong shape, missing keys): loaded or refused, the context stays usable."""
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "images")
+    for i in range(2):
+        Image.fromarray(np.full((12, 16, 3), 40 * i + 20, np.uint8)).save(tmp_path / "images" / f"{i:04d}.png")
+    good = {"camera_angle_x": 0.69, "fl_x": 20.0, "fl_y": 20.0, "cx": 8.0, "cy": 6.0, "w": 16, "h": 12, "k1": 0.01, "k2": 0.0, "p1": 0.0, "p2": 0.0, "aabb_scale": 2, "scale": 0.33,
+            "offset": [0.5, 0.5, 0.5], "enable_depth_loading": False, "white_transparent": False, "rolling_shutter": [0, 0, 0, 0],
+            "frames": [{"file_path": f"./images/{i:04d}.png", "sharpness": 10.0, "transform_matrix": np.eye(4).tolist()} for i in range(2)]}
+    weird = [None, True, -1, 0, 3, 2 ** 31, 2 ** 40, -2 ** 40, 1e30, -1e30, 1e-30, "", "x", [], [1, 2, 3], [[1, 2], [3]], {}, {"a": 1}]
+    ctx = native.Context(-1)
+    path = str(tmp_path / "transforms.json")
+    n_ok = n_refused = 0
+
+    def attempt(obj, raw=None):
+        nonlocal n_ok, n_refused
+        open(path, "w").write(raw if raw is not None else json.dumps(obj))
+        try:
+            ctx.load_training_data(path)
+            n_ok += 1
+        except RuntimeError:
+            n_refused += 1
+
+    for key in list(good):
+        for v in weird:
+            attempt(dict(good, **{key: v}))
+        attempt({k: val for k, val in good.items() if k != key})
+    for key in list(good["frames"][0]):
+        for v in weird:
+            fr = [dict(good["frames"][0], **{key: v}), good["frames"][1]]
+            attempt(dict(good, frames=fr))
+    for raw in ("", "{", "[]", "null", json.dumps(good)[:-20], json.dumps(good).replace("0.69", "NaN"), json.dumps(good).replace("16", "1e400"), "{\"frames\": " + "[" * 100000):
+        attempt(None, raw)
+    assert n_refused > 40 and n_ok > 40, (n_ok, n_refused)
+    attempt(good)
+    assert ctx.training_view(1)["resolution"].tolist() == [16, 12]
+    ctx.close()
+
+
 def test_image_decoders_survive_mutated_files(tmp_path):
     """tests/aux/decode_fuzz.cpp under AddressSanitizer + UBSan: truncations, byte flips, 0xFF runs and insertions of
     PNG / JPEG seeds either decode or are refused -- no crash, no hang (dataset images are untrusted input)."""
