@@ -1173,7 +1173,7 @@ void render_frames(ngp_ctx* ctx, const ngp_camera& cam, const ngp_render_opts& o
 	if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 	if (!ctx->model_loaded && !(opts.testbed_mode == NGP_MODE_GEOMETRY && !ctx->meshes.empty())) throw std::runtime_error("No network available."); // testbed.cu:4735-4738
 	ngp::sync_inference_model(ctx);
-	if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("invalid render resolution");
+	if (cam.width <= 0 || cam.height <= 0 || cam.width > 65536 || cam.height > 65536) throw std::runtime_error("invalid render resolution"); // (tile counts stay inside 32 bits)
 	if (opts.render_mode < NGP_RENDER_SHADE || opts.render_mode > NGP_RENDER_NORMALS) throw std::runtime_error("render modes implemented: Shade, ShadeEnvMap, ShadeGridEnvMap, AO, Normals, Positions, Depth, Cost");
 	const bool gbuffer_mode = (opts.render_mode >= NGP_RENDER_AO && opts.render_mode <= NGP_RENDER_COST) || opts.render_mode == NGP_RENDER_NORMALS;
 	if (gbuffer_mode && opts.testbed_mode == NGP_MODE_GEOMETRY) throw std::runtime_error("the G-buffer render modes (AO, Normals, Positions, Depth, Cost) apply to NeRF mode");
@@ -1744,7 +1744,9 @@ void* pinned_device_alias(const void* host, size_t bytes); // below, with the po
 
 int ngp_render(ngp_ctx* ctx, const ngp_camera* cam, const ngp_render_opts* opts, float* rgba_out, float* depth_out) {
 	return guarded(ctx, [&] {
-		if (!cam || !opts || !rgba_out) throw std::runtime_error("null argument");
+		if (!cam || !opts) throw std::runtime_error("null argument");
+		if (cam->width <= 0 || cam->height <= 0 || cam->width > 65536 || cam->height > 65536) throw std::runtime_error("invalid render resolution");
+		if (!rgba_out) throw std::runtime_error("null argument");
 		if (opts->packed_output) throw std::runtime_error("packed_output is for ngp_render_device (GPU-resident tiles); ngp_render returns images");
 		if (ctx->device < 0) throw std::runtime_error("this context has no HIP device (host-only); rendering needs an MI355X -- there is no CPU fallback");
 		const size_t n_pixels = (size_t)cam->width * cam->height;

@@ -463,6 +463,8 @@ class Context:
     # ---------------------------------------------------------------- render
     def render(self, cam, opts=None, want_depth=False):
         opts = opts or make_opts()
+        if not (0 < cam.width <= 65536 and 0 < cam.height <= 65536):  # (the library refuses it: no image to allocate for the call)
+            self._check(self.L.ngp_render(self.h, C.byref(cam), C.byref(opts), None, None))
         rgba = np.zeros((cam.height, cam.width, 4), np.float32)
         depth = np.zeros((cam.height, cam.width), np.float32) if want_depth else None
         self._check(self.L.ngp_render(self.h, C.byref(cam), C.byref(opts), _p(rgba), _p(depth) if want_depth else None))

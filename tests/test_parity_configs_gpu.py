@@ -319,6 +319,29 @@ def test_schedule_knobs_are_validated(native):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_render_arguments_are_validated_before_any_launch(native, scene_mod, scene_unit, gpu_ctx):
+    """A frame's arguments come from a caller, not from the library: resolutions, shard coordinates and modes that the kernels' indexing does
+    not cover are refused with a message; a camera of NaNs renders an empty frame (every ray invalid) and leaves the context usable."""
+    gpu_ctx.set_model(scene_unit)
+    focal = scene_mod.focal_from_fov_x(64, 0.6911)
+    good = native.make_camera(scene_mod.orbit_camera(45.0), 64, 36, focal)
+    ref = gpu_ctx.render(good, native.make_opts())
+    for w, h in ((0, 36), (64, 0), (-8, 36), (70000, 36), (64, 70000)):
+        with pytest.raises(RuntimeError, match="invalid render resolution"):
+            gpu_ctx.render(native.make_camera(scene_mod.orbit_camera(45.0), w, h, focal), native.make_opts())
+    with pytest.raises(RuntimeError, match="shard_index out of range"):
+        gpu_ctx.render(good, native.make_opts(shard_index=3, shard_count=2))
+    with pytest.raises(RuntimeError, match="render modes implemented"):
+        gpu_ctx.render(good, native.make_opts(render_mode=99))
+    nan_cam = native.make_camera(np.full((3, 4), np.nan, np.float32), 64, 36, focal)
+    img = gpu_ctx.render(nan_cam, native.make_opts())
+    assert img.shape == (36, 64, 4) and np.isfinite(img).all() and (img == img[0, 0]).all()  # (the background, everywhere)
+    nan_focal = native.make_camera(scene_mod.orbit_camera(45.0), 64, 36, (float("nan"), float("nan")))
+    gpu_ctx.render(nan_focal, native.make_opts())
+    assert np.array_equal(gpu_ctx.render(good, native.make_opts()), ref)
+
+
 # ---------------------------------------------------------------------------------------- several devices behind one context
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_dev", [2, 3])
