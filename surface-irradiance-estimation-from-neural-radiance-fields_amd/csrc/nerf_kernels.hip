@@ -1168,6 +1168,9 @@ void launch_render_nerf(const ModelParams& M, const CameraParams& C, const Frame
 	// (measured on one GPU with two frames in flight: 2 per CU is as fast as 3 from N = 2 on, tools/shard_probe.py)
 	static const int shard_per_cu = []() { const char* e = getenv("NGP_SHARD_BLOCKS_PER_CU"); int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }(); // experiments: tools/shard_probe.py
 	if (F.shard_count > 1 && per_cu > shard_per_cu) per_cu = shard_per_cu;
+	// a frame of fewer than ~2 tiles per resident wave (below ~800 x 450) is faster on two workgroups per CU as well, alone (512 x 288: 0.81 -> 0.72 ms,
+	// 800 x 450: 0.89 -> 0.84) and with frames in flight (-1..6 %); from 960 x 540 on the third workgroup pays (profiles/r3_small_frame.txt)
+	if (F.shard_count <= 1 && F.n_local_tiles <= 6144u && per_cu > 2) per_cu = 2;
 	if (const char* e = getenv("NGP_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; } // experiments only
 	const int threads = (!F.prof && unit && plain) ? FB_UNIT_PLAIN : BLOCK;
 	if (F.shard_count > 1 && threads != BLOCK) per_cu = per_cu * threads > 2 * BLOCK ? ((2 * BLOCK) / threads > 0 ? (2 * BLOCK) / threads : 1) : per_cu; // (a rank's share: two thirds of the CU, as above)

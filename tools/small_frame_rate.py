@@ -11,7 +11,8 @@ ctx = native.Context(0)
 ctx.set_model(sc)
 k = int(os.environ.get("K", 6))
 streams = [torch.cuda.Stream() for _ in range(k)]
-for (w, h, shards) in ((256, 256, 1), (680, 382, 1), (1920, 1080, 8), (1920, 1080, 1)):
+SIZES = [tuple(int(v) for v in t.split("x")) for t in os.environ["SIZES"].split(",")] if os.environ.get("SIZES") else None  # e.g. SIZES=800x450x1,960x540x1 (width x height x shards)
+for (w, h, shards) in (SIZES or ((256, 256, 1), (680, 382, 1), (1920, 1080, 8), (1920, 1080, 1))):
     cams = [native.make_camera(scene.orbit_camera(az), w, h, scene.focal_from_fov_x(w, 0.6911)) for az in (0, 45, 90, 135, 180, 225, 270, 315)]
     bufs = [(torch.zeros((h, w, 4), device="cuda"), torch.zeros((h, w), device="cuda")) for _ in range(k)]
     opts = native.make_opts(shard_index=0, shard_count=shards, packed_output=shards > 1)
