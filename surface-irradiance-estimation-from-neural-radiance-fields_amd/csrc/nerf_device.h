@@ -762,6 +762,13 @@ NGP_DEV void encode_issue(GridRsrc grid, GridRsrc xgrid, const LevelInfo* lv, in
 		for (int c = 0; c < 8; ++c) e.v[c] = gather8(xgrid, c0.index[c]);
 #pragma unroll
 		for (int c = 0; c < 8; ++c) e.v[8 + c] = gather8(xgrid, c1.index[c]);
+#if defined(NGP_EXPERIMENT_EXTRA_GATHERS) // timing experiment only (profiles/r3_extra_gathers.txt): N more lane-loads per lane and pass, of lines the loads above have just touched; results unchanged
+#pragma unroll
+		for (int c = 0; c < NGP_EXPERIMENT_EXTRA_GATHERS; ++c) {
+			const uint2 d = gather8(xgrid, c & 1 ? c1.index[c & 7] : c0.index[c & 7]);
+			asm volatile("" ::"v"(d.x), "v"(d.y));
+		}
+#endif
 	} else {
 		level_corners(L0, p0, c0);
 		level_corners(L1, p1, c1);
