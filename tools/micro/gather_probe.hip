@@ -45,6 +45,43 @@ __global__ __launch_bounds__(256) void gather(const T* __restrict__ table, uint3
 	if (acc == 0x12345678u) out[0] = acc;
 }
 
+// 16-byte loads whose address is 8 modulo 16 (every load straddles two aligned 16-byte slots; one in eight also straddles a 64-byte boundary)
+// against aligned ones: what the pair gathers of tools/experiments would issue for dense levels with odd x
+template <int UNROLL, int MISALIGN>
+__global__ __launch_bounds__(256) void gather16_at(const char* __restrict__ table, uint32_t mask, int iters, uint32_t* out) {
+	uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+	uint32_t acc = 0;
+	for (int it = 0; it < iters; ++it) {
+		uint4 v[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; ++u) {
+			s = s * 1664525u + 1013904223u;
+			const uint32_t r = (s >> 4) & mask;
+			v[u] = *(const uint4*)(table + (size_t)r * 16u + MISALIGN);
+		}
+#pragma unroll
+		for (int u = 0; u < UNROLL; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+template <int MISALIGN>
+void run16(void* d_table, size_t table_bytes, uint32_t* d_out) {
+	const uint32_t mask = (uint32_t)(table_bytes / 16) - 2u; // (leave the last slot: the misaligned load reads 8 bytes past its own)
+	const int blocks = 2048, iters = 500;
+	hipEvent_t a, b;
+	CHECK(hipEventCreate(&a));
+	CHECK(hipEventCreate(&b));
+	gather16_at<16, MISALIGN><<<blocks, 256>>>((const char*)d_table, mask & ~1u, iters / 4, d_out);
+	CHECK(hipEventRecord(a));
+	gather16_at<16, MISALIGN><<<blocks, 256>>>((const char*)d_table, mask & ~1u, iters, d_out);
+	CHECK(hipEventRecord(b));
+	CHECK(hipEventSynchronize(b));
+	float ms = 0;
+	CHECK(hipEventElapsedTime(&ms, a, b));
+	const double loads = (double)blocks * 256.0 * iters * 16;
+	printf("16 B random at offset %d mod 16      table %10.4f MB blocks %4d: %8.3f ms  %5.2f lane-loads/clk/CU (2.4 GHz)\n", MISALIGN, table_bytes / 1048576.0, blocks, ms, loads / (ms * 1e-3 * 2.4e9 * 256.0));
+}
+
 template <typename T, int UNROLL, int MODE>
 void run(const char* name, void* d_table, size_t table_bytes, int blocks, uint32_t* d_out, uint32_t lanes_on = 64u, uint32_t stride_sel = 0u) {
 	uint32_t n = (uint32_t)(table_bytes / sizeof(T));
@@ -74,6 +111,13 @@ int main(int argc, char** argv) {
 	CHECK(hipMalloc(&d_table, max_bytes));
 	CHECK(hipMemset(d_table, 1, max_bytes));
 	CHECK(hipMalloc(&d_out, 4));
+	if (argc > 1 && argv[1][0] == 'u') { // "unaligned": 16-byte loads at 8 modulo 16
+		for (size_t sz : {8ull << 10, 16ull << 10, 1ull << 20, 32ull << 20}) {
+			run16<0>(d_table, sz, d_out);
+			run16<8>(d_table, sz, d_out);
+		}
+		return 0;
+	}
 	if (argc > 1) { // "masked": the same scattered 8-byte gather with 64 / 32 / 16 / 8 lanes of a wave switched on
 		for (size_t sz : {8ull << 10, 1ull << 20, 32ull << 20}) {
 			run<uint2, 16, 0>("8 B random, 16 in flight", d_table, sz, 2048, d_out);
