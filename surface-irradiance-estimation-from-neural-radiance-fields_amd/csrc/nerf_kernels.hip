@@ -644,7 +644,10 @@ __global__ __launch_bounds__(BLOCK, 2) void render_nerf_fused(const ModelParams 
 	ProbeParams P{};
 	fused_body<false>(M, C, F, P);
 }
-__global__ __launch_bounds__(BLOCK, 3) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
+#ifndef NGP_UNIT_NONPLAIN_WAVES
+#define NGP_UNIT_NONPLAIN_WAVES 3
+#endif
+__global__ __launch_bounds__(BLOCK, NGP_UNIT_NONPLAIN_WAVES) void render_nerf_fused_unit(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	fused_body<false, false, true>(M, C, F, P);
 }
