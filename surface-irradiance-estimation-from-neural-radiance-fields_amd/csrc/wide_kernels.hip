@@ -928,6 +928,7 @@ NGP_DEV void wide_body(const ModelParams& M, const CameraParams& C, const FrameP
 }
 
 #define NGP_WIDE_KERNEL __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define NGP_WIDE_KERNEL_1 __global__ __launch_bounds__(WBLOCK) // (the Normals kernels: 113 KB of LDS, one workgroup per CU, one wave per SIMD)
 
 NGP_WIDE_KERNEL void render_nerf_wide256(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
@@ -948,11 +949,11 @@ NGP_WIDE_KERNEL void trace_probe_wide128(const ModelParams M, const FrameParams 
 
 #if !WIDE_MFMA16
 // ERenderMode::Normals: the density network's backward pass per round; 32 KB of masks beside the activations = one workgroup per CU
-NGP_WIDE_KERNEL void render_nerf_wide256_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
+NGP_WIDE_KERNEL_1 void render_nerf_wide256_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	wide_body<false, 64 / WIDE_TILE_M, true>(M, C, F, P);
 }
-NGP_WIDE_KERNEL void render_nerf_wide128_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
+NGP_WIDE_KERNEL_1 void render_nerf_wide128_normals(const ModelParams M, const CameraParams C, const FrameParams F) {
 	ProbeParams P{};
 	wide_body<false, 32 / WIDE_TILE_M, true>(M, C, F, P);
 }
@@ -1008,10 +1009,10 @@ NGP_WIDE_KERNEL void network_inference_wide128(const ModelParams M, uint32_t n, 
 	wide_inference_body<32 / WIDE_TILE_M>(M, n, pos01, dir01, out);
 }
 #if !WIDE_MFMA16
-NGP_WIDE_KERNEL void density_gradient_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
+NGP_WIDE_KERNEL_1 void density_gradient_wide256(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
 	wide_inference_body<64 / WIDE_TILE_M, true>(M, n, pos01, pos01, (uint16_t*)out);
 }
-NGP_WIDE_KERNEL void density_gradient_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
+NGP_WIDE_KERNEL_1 void density_gradient_wide128(const ModelParams M, uint32_t n, const float* __restrict__ pos01, float* __restrict__ out) {
 	wide_inference_body<32 / WIDE_TILE_M, true>(M, n, pos01, pos01, (uint16_t*)out);
 }
 #endif
