@@ -82,31 +82,48 @@ NGP_DEV float div_max_cone_stepsize(float x) { return div_const(x, max_cone_step
 
 // The piecewise map's constants depend on the cone angle alone -- five logf / expf and two divisions that the reference's inline
 // functions form on every call. A persistent kernel forms them once (make_stepping) and carries them; same expressions, same values.
+// The middle branch (exponential steps, t between at and bt) is log(t) / log(1 + c) one way and exp(n log(1 + c)) back. The reference is built with
+// --use_fast_math: its logf / expf there are lg2.approx / ex2.approx with a multiply and its division is approximate; v_log_f32 / v_exp_f32 are the
+// gfx950 counterparts (1 ulp), so each direction is ONE transcendental and one multiply -- glibc-grade logf / expf and an IEEE division cost ~95
+// VALU instructions per empty-space step and ~55 per sample of a scene with aabb_scale > 1, where the march is more than half of the frame
+// (profiles/r3_sections_configs.txt). The difference to the oracle's libm is ~1e-5 of a step in n: a ray in ~1e4 lands on the other side of a lattice
+// point, as it already did by an ulp of the precise functions (tests: the cascaded scenes' sample counts within 5e-3). -DNGP_PRECISE_STEPPING restores them.
 struct Stepping {
 	float cone_angle, log1p_c, a, b, at, bt;
+	float to_scale, from_scale; // ln 2 / log(1 + c), log(1 + c) / ln 2
 };
 NGP_DEV Stepping make_stepping(float cone_angle) {
 	Stepping s;
 	s.cone_angle = cone_angle;
-	s.log1p_c = s.a = s.b = s.at = s.bt = 0.0f;
+	s.log1p_c = s.a = s.b = s.at = s.bt = s.to_scale = s.from_scale = 0.0f;
 	if (cone_angle <= 1e-5f) return s;
 	s.log1p_c = logf(1.0f + cone_angle);
 	s.a = (logf(stepsize()) - logf(s.log1p_c)) / s.log1p_c;
 	s.b = (logf(max_cone_stepsize()) - logf(s.log1p_c)) / s.log1p_c;
 	s.at = expf(s.a * s.log1p_c);
 	s.bt = expf(s.b * s.log1p_c);
+	s.to_scale = 0.6931471805599453f / s.log1p_c;
+	s.from_scale = s.log1p_c * 1.4426950408889634f;
 	return s;
 }
 NGP_DEV float to_stepping_space(float t, const Stepping& s) {
 	if (s.cone_angle <= 1e-5f) return div_stepsize(t);
 	if (t <= s.at) return div_stepsize(t - s.at) + s.a;
+#ifdef NGP_PRECISE_STEPPING
 	else if (t <= s.bt) return logf(t) / s.log1p_c;
+#else
+	else if (t <= s.bt) return __builtin_amdgcn_logf(t) * s.to_scale;
+#endif
 	else return div_max_cone_stepsize(t - s.bt) + s.b;
 }
 NGP_DEV float from_stepping_space(float n, const Stepping& s) {
 	if (s.cone_angle <= 1e-5f) return n * stepsize();
 	if (n <= s.a) return (n - s.a) * stepsize() + s.at;
+#ifdef NGP_PRECISE_STEPPING
 	else if (n <= s.b) return expf(n * s.log1p_c);
+#else
+	else if (n <= s.b) return __builtin_amdgcn_exp2f(n * s.from_scale);
+#endif
 	else return (n - s.b) * max_cone_stepsize() + s.bt;
 }
 NGP_DEV float advance_n_steps(float t, const Stepping& s, float n) { return from_stepping_space(to_stepping_space(t, s) + n, s); }
@@ -225,7 +242,7 @@ NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield
 	const uint32_t key = (x >> 2) | ((y >> 2) << 5) | ((z >> 2) << 10) | (mip << 15);
 	if (cache.key != key) {
 		const uint32_t b4 = morton3D(x >> 2, y >> 2, z >> 2), b16 = b4 >> 6; // == morton3D(x, y, z) >> 6, >> 12
-		if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
+		if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u; // (32^3 / 64^3 blocks, tried: hardly ever empty where a 16^3 one is)
 		const uint32_t cw = mip < lds_mips ? s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] : g_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)];
 		if (!((cw >> (b4 & 31u)) & 1u)) return 4u;
 		cache.bits = *(const uint2*)(bitfield + (size_t)b4 * 8 + (size_t)(NERF_GRID_N_CELLS / 8) * mip);
@@ -235,6 +252,22 @@ NGP_DEV uint32_t occupancy_state_at(f3 pos, const uint8_t* __restrict__ bitfield
 	const uint32_t bit = (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2) | ((x & 2u) << 2) | ((y & 2u) << 3) | ((z & 2u) << 4);
 	const uint32_t word = (bit & 32u) ? cache.bits.y : cache.bits.x;
 	return ((word >> (bit & 31u)) & 1u) ? 0u : 1u;
+}
+
+// The climb to coarser cascades (nerf_device.cuh:488-490) through the block summaries alone: 16 / 4 = the aligned 16^3 / 4^3 block of cells of cascade
+// `mip` around pos is empty, 0 = it is not (or pos lies outside that cascade's grid). No bitfield word is read and the lane's block cache is left
+// alone: with block jumps on, one empty CELL of the next cascade (two cells of this one) reaches no further than the 4^3 block the march
+// already holds, so only whole empty blocks of coarser cascades can lengthen the step.
+NGP_DEV uint32_t empty_block_summary_at(f3 pos, const uint32_t* s_coarse, const uint32_t* s_coarse16, uint32_t mip, uint32_t lds_mips = NERF_CASCADES,
+                                        const uint32_t* __restrict__ g_coarse = nullptr) {
+	float mip_scale = __builtin_ldexpf(1.0f, -(int)mip);
+	pos = adds3(scale3(adds3(pos, -0.5f), mip_scale), 0.5f);
+	const int ix = (int)(pos.x * (float)(NERF_GRIDSIZE / 4)), iy = (int)(pos.y * (float)(NERF_GRIDSIZE / 4)), iz = (int)(pos.z * (float)(NERF_GRIDSIZE / 4));
+	if (((uint32_t)ix | (uint32_t)iy | (uint32_t)iz) >= NERF_GRIDSIZE / 4 || pos.x < 0.0f || pos.y < 0.0f || pos.z < 0.0f) return 0u;
+	const uint32_t b4 = morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz), b16 = b4 >> 6;
+	if (!((s_coarse16[mip * 16u + (b16 >> 5)] >> (b16 & 31u)) & 1u)) return 16u;
+	const uint32_t cw = mip < lds_mips ? s_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)] : g_coarse[mip * COARSE_WORDS_PER_MIP + (b4 >> 5)];
+	return ((cw >> (b4 & 31u)) & 1u) ? 0u : 4u;
 }
 
 // res is a power of two, so t / res == t * (1/res) bit for bit; inv_res spares the IEEE division sequence

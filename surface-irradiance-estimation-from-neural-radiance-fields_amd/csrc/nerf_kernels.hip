@@ -346,11 +346,24 @@ NGP_DEV void fused_body(const ModelParams& M, const CameraParams& C, const Frame
 				// climb to the largest empty cascade cell around pos (nerf_device.cuh:488-490); each level doubles
 				// the cell, so the block summary of the final level is looked up again
 				if (!UNIT) {
-					while (mip < max_cascade) {
-						uint32_t e = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache, MIPS, M.coarse);
-						if (e == 0u) break;
-						++mip;
-						empty = e;
+					// (with block jumps the step is `empty` cells of cascade `mip`: a 4^3 block of this cascade reaches further than one cell of the
+					// next -- keep the pair that spans most, not simply the coarsest empty cell)
+					if (PROBE || !F.tune[6]) { // the reference's walk: the coarsest cascade whose cell around pos is empty, one cell at a time
+						while (mip < max_cascade) {
+							uint32_t e = occupancy_state_at(pos, M.bitfield, s_coarse, s_coarse16, mip + 1, occ_cache, MIPS, M.coarse);
+							if (e == 0u) break;
+							++mip;
+							empty = e;
+						}
+					} else { // whole empty blocks of coarser cascades, from their summaries (no bitfield word, the block cache keeps this cascade's block)
+						uint32_t best_mip = mip, best_empty = empty;
+						for (uint32_t m = mip + 1u; m <= max_cascade; ++m) {
+							const uint32_t e = empty_block_summary_at(pos, s_coarse, s_coarse16, m, MIPS, M.coarse);
+							if (e == 0u) break;
+							if ((e << m) >= (best_empty << best_mip)) { best_mip = m; best_empty = e; }
+						}
+						mip = best_mip;
+						empty = best_empty;
 					}
 				}
 				if (PROF) p_skip[empty == 16u ? 2 : (empty == 4u ? 1 : 0)] += 1ull;

@@ -303,7 +303,9 @@ def test_block_jumps_are_the_only_source_of_sample_set_changes(which, gpu_ctx, o
     # (a lattice point within rounding of a block face); those rays are the outliers assert_image_close's `hard` bound
     # allows for, and there are no others.
     delta = np.abs(on - off).max(-1)
-    assert np.median(delta) < 1e-3 and (delta > 1e-2).mean() < 2e-4, f"{(delta > 1e-2).sum()} of {delta.size} pixels move by more than 1e-2"
+    # (cascaded scene: since the climb keeps the farthest-reaching empty block the jumps are longer -- 16^3 blocks of outer cascades -- and a
+    # few more lattice points coincide with a block face: measured 15 of 57600 pixels, 31 of 586512 samples)
+    assert np.median(delta) < 1e-3 and (delta > 1e-2).mean() < (2e-4 if which == "unit" else 5e-4), f"{(delta > 1e-2).sum()} of {delta.size} pixels move by more than 1e-2"
     assert abs(int(st_on["n_samples"]) - int(st_off["n_samples"])) <= 1e-4 * st_off["n_samples"] + 2
     assert d_on[delta <= 1e-2].max() < max(tol, 2e-2) and d_on.max() < 0.3
 
