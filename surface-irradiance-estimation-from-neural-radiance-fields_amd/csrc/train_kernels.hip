@@ -128,10 +128,10 @@ __global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_sampl
 	const f3 d = normalize3(d_un);
 	float bmax[3] = {M.aabb_min[0] + M.aabb_diag[0], M.aabb_min[1] + M.aabb_diag[1], M.aabb_min[2] + M.aabb_diag[2]};
 	const float tmin = fmaxf(aabb_ray_entry(M.aabb_min, bmax, o, d), 0.0f);
-	const float cone_angle = M.cone_angle;
+	const Stepping stepping = make_stepping(M.cone_angle); // (once per thread: three logf / two expf the step functions would otherwise rebuild per call)
 	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 
-	float t = advance_n_steps(tmin, cone_angle, rng.next_float()); // row-uniform from here on
+	float t = advance_n_steps(tmin, stepping, rng.next_float()); // row-uniform from here on
 	uint32_t j = 0;
 	bool dense = true;
 	const int row_shift = 16 * g;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_sampl
 			if (!done && dense) {
 				float tt = t;
 				for (int k = 0; k < GEN_CAND; ++k) {
-					const float dt = calc_dt(tt, cone_angle);
+					const float dt = calc_dt(tt, stepping);
 					if (c == k) { my_t = tt; my_dt = dt; }
 					tt += dt;
 				}
@@ -152,11 +152,11 @@ __global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_sampl
 			if (!done && !dense) {
 				float tt = t;
 				for (int k = 0; k < GEN_CAND; ++k) {
-					const float dt = calc_dt(tt, cone_angle);
+					const float dt = calc_dt(tt, stepping);
 					const f3 pos = add3(o, scale3(d, tt));
 					const uint32_t mip = mip_from_dt(dt, pos, M.max_cascade);
 					if (c == k) { my_t = tt; my_dt = dt; }
-					tt = advance_to_next_voxel(tt, cone_angle, pos, d, idir, mip);
+					tt = advance_to_next_voxel(tt, stepping, pos, d, idir, mip);
 				}
 				next_t = tt;
 			}
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_sampl
 			if (j >= NERF_STEPS || (stop == first_out && stop < GEN_CAND)) done = true; // full, or the ray left the box
 			else if (stop == GEN_CAND) t = next_t;
 			else { // position `stop` is inside and empty: one jump from it, then look for the next occupied cell
-				t = advance_to_next_voxel(t_pick, cone_angle, add3(o, scale3(d, t_pick)), d, idir, mip_pick);
+				t = advance_to_next_voxel(t_pick, stepping, add3(o, scale3(d, t_pick)), d, idir, mip_pick);
 				dense = false;
 			}
 		} else {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES_PER_BLOCK) void train_generate_sampl
 	const f3 amin = mk3(M.aabb_min[0], M.aabb_min[1], M.aabb_min[2]), adiag = mk3(M.aabb_diag[0], M.aabb_diag[1], M.aabb_diag[2]);
 	for (uint32_t k = (uint32_t)c; k < numsteps; k += 16) {
 		const float tk = my_ts[k];
-		const float dt = calc_dt(tk, cone_angle);
+		const float dt = calc_dt(tk, stepping);
 		const f3 w = div3(sub3(add3(o, scale3(d, tk)), amin), adiag);
 		float* co = B.coords + (size_t)(base + k) * TRAIN_COORD_FLOATS;
 		co[0] = w.x; co[1] = w.y; co[2] = w.z; co[3] = warp_dt(dt); co[4] = wdir.x; co[5] = wdir.y; co[6] = wdir.z;
