@@ -16,6 +16,7 @@ depth = torch.zeros((h, w), device="cuda")
 cases = {
     "plain pinhole": dict(),
     "depth of field (aperture 0.01)": dict(aperture_size=0.01, focus_z=3.0),
+    "depth of field (aperture 1e-6: the code path without the divergence)": dict(aperture_size=1e-6, focus_z=3.0),
     "OpenCV lens (k1 = 0.05)": dict(lens_mode=1, lens_params=(0.05, 0.0, 0.0, 0.0)),
 }
 for name, kw in cases.items():
